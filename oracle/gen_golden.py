@@ -1,0 +1,188 @@
+"""Golden-vector generator (test infrastructure; runs ONLY in the build container).
+
+Imports the *reference itself* from /root/reference (with inert stubs for absent third-party imports,
+oracle/_ref_import.py), runs its EDM network / noise schedule / sampler on seeded inputs and writes
+small fixtures to tests/golden/.  The reference never travels to the GPU box; the fixtures do.
+
+Weights and inputs are not stored: they are regenerated from seeds by oracle/edm_ref.py
+(random_state_dict, seeded torch CPU generator); every fixture stores checksums of what it was fed so a
+drift of the RNG stream is detected instead of silently comparing different problems.
+
+Usage:  python oracle/gen_golden.py            (writes tests/golden/*.pt)
+"""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_import  # noqa: E402
+import edm_ref  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def checksum(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach().to(torch.float64).reshape(-1)
+    w = torch.arange(1, t.numel() + 1, dtype=torch.float64) % 7 + 1
+    return torch.stack([t.sum(), (t * w).sum(), t.abs().max()])
+
+
+def sd_checksum(sd) -> torch.Tensor:
+    return torch.stack([checksum(v) for _, v in sorted(sd.items())]).sum(0)
+
+
+def ref_net(edm_net, cfg: edm_ref.SongUNetConfig, sd):
+    net = edm_net.EDMPrecond(
+        img_resolution=cfg.img_resolution, img_channels=cfg.img_channels, label_dim=cfg.label_dim,
+        sigma_shift=cfg.sigma_shift, sigma_data=cfg.sigma_data, model_type="SongUNet", augment_dim=cfg.augment_dim,
+        model_channels=cfg.model_channels, channel_mult=list(cfg.channel_mult), channel_mult_noise=cfg.channel_mult_noise,
+        num_blocks=cfg.num_blocks, attn_resolutions=list(cfg.attn_resolutions),
+        embedding_type="positional", encoder_type="standard", decoder_type="standard", resample_filter=[1, 1],
+        dropout=0.0, label_dropout=0, r_timestep=False, drop_precond=None,
+    )
+    ref_sd = net.state_dict()
+    assert set(ref_sd) == set(sd), (set(ref_sd) ^ set(sd))
+    for k in ref_sd:
+        assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), k
+    net.load_state_dict(sd, strict=True)
+    return net.eval()
+
+
+def seeded(shape, seed, dtype=torch.float32):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)).to(dtype)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    edm_net, ns, model = _ref_import.import_reference()
+    torch.manual_seed(0)
+
+    # ---- (i)+(ii) schedule ------------------------------------------------------------------
+    sched = ns.EDMNoiseSchedule()
+    fx = {"sigmas_head": sched.sigmas[:3].clone(), "sigmas_tail": sched.sigmas[-3:].clone()}
+    for n in (1, 2, 4):
+        fx[f"t_list_{n}"] = sched.get_t_list(n)
+    x = seeded((2, 3, 8, 8), 11)
+    e = seeded((2, 3, 8, 8), 12)
+    t = torch.tensor([17.498123, 0.1726], dtype=torch.float64)
+    fx["fp_out"] = sched.forward_process(x, e, t)
+    fx["lat_out"] = sched.latents(x, t_init=torch.tensor(79.5638, dtype=torch.float64))
+    fx["x0eps_out"] = sched.x0_to_eps(x, e, t)
+    torch.save(fx, os.path.join(OUT, "schedule.pt"))
+
+    # ---- names / shapes of the full CIFAR-10 network --------------------------------------------
+    cfg = edm_ref.CIFAR10
+    sd = edm_ref.random_state_dict(cfg, seed=1234)
+    net = ref_net(edm_net, cfg, sd)
+    with open(os.path.join(OUT, "state_dict_keys.txt"), "w") as f:
+        for k, v in net.state_dict().items():
+            f.write(f"{k} {' '.join(str(d) for d in v.shape)}\n")
+
+    # ---- (iii) embedding + (v) full forward, full width, B=2 ---------------------------------------
+    B = 2
+    xin = seeded((B, 3, 32, 32), 21)
+    cond = torch.nn.functional.one_hot(torch.tensor([3, 7]), 10).float()
+    tt = torch.tensor([17.4981, 0.1726], dtype=torch.float64)
+    trace = {}
+    hooks = []
+    named = [("enc." + n, m) for n, m in net.model.enc.items()] + [("dec." + n, m) for n, m in net.model.dec.items()]
+    for name, blk in named:
+        hooks.append(blk.register_forward_hook(lambda m, i, o, name=name: trace.__setitem__(name, o.detach().clone())))
+    hooks.append(net.model.map_layer1.register_forward_hook(
+        lambda m, i, o: trace.__setitem__("emb", torch.nn.functional.silu(o.detach().clone()))))
+    with torch.inference_mode():
+        out = net(xin * tt.reshape(B, 1, 1, 1).float(), tt, condition=cond, fwd_pred_type="x0")
+    for h in hooks:
+        h.remove()
+    fx = {"sd_checksum": sd_checksum(sd), "x_checksum": checksum(xin), "out": out.clone(), "emb": trace["emb"],
+          "t": tt, "cond": cond}
+    # strided samples + moments of every block output (full tensors would be ~60 MB)
+    for name, v in trace.items():
+        if name == "emb":
+            continue
+        fx[f"blk/{name}/moments"] = torch.stack([v.double().mean(), v.double().std(), v.double().abs().max()])
+        fx[f"blk/{name}/sample"] = v.reshape(-1)[:: max(1, v.numel() // 4096)][:4096].clone()
+    torch.save(fx, os.path.join(OUT, "forward_full_b2.pt"))
+
+    # ---- (iv) UNetBlock variants, full width, small batch ---------------------------------------------
+    enc, dec = edm_ref.layout(cfg)
+    spec = {b.key.split(".")[-1] + ("_dec" if ".dec." in b.key else ""): b for b in enc + dec}
+    emb = trace["emb"]
+    cases = {
+        "enc_first": ("32x32_block0", 1),  # 128 -> 256, 1x1 skip
+        "enc_plain": ("8x8_block1", 2),  # 256 -> 256 @ 8x8
+        "enc_attn": ("16x16_block1", 2),  # 256 -> 256 + attention, T = 256
+        "enc_down": ("16x16_down", 1),  # 32 -> 16 avg-pool + skip 1x1
+        "dec_in0": ("8x8_in0_dec", 2),  # attention, T = 64
+        "dec_up": ("16x16_up_dec", 2),  # 8 -> 16 nearest
+        "dec_cat512": ("16x16_block1_dec", 1),  # 512 -> 256
+        "dec_cat384": ("32x32_block4_dec", 1),  # 384 -> 256 (12 channels per group)
+        "dec_cat_attn": ("16x16_block4_dec", 1),  # 512 -> 256 + attention
+    }
+    fxb = {"sd_checksum": sd_checksum(sd)}
+    for cname, (bname, bs) in cases.items():
+        b = spec[bname]
+        mod = (net.model.enc if ".enc." in b.key else net.model.dec)[b.key.split(".")[-1]]
+        rin = b.res * 2 if b.down else (b.res // 2 if b.up else b.res)
+        xb = seeded((bs, b.cin, rin, rin), 100 + len(fxb))
+        with torch.inference_mode():
+            yb = mod(xb, emb[:bs])
+        fxb[f"{cname}/key"] = b.key
+        fxb[f"{cname}/seed"] = torch.tensor(100 + len(fxb) - 1)
+        fxb[f"{cname}/x_checksum"] = checksum(xb)
+        fxb[f"{cname}/out"] = yb.clone()
+        # own restatement must agree already here (fails loudly at generation time)
+        yo = edm_ref.unet_block(sd, b, xb, emb[:bs])
+        assert torch.allclose(yo, yb, rtol=1e-5, atol=1e-5), (cname, (yo - yb).abs().max())
+    fxb["emb"] = emb
+    torch.save(fxb, os.path.join(OUT, "blocks_full.pt"))
+
+    # ---- (vi) 4-step generator_fn trace with injected eps, full width, B=2 ----------------------------------
+    noise = seeded((B, 3, 32, 32), 0)
+    eps_list = [seeded((B, 3, 32, 32), s) for s in (1, 2, 3)]
+    it = iter(eps_list)
+    orig_randn_like = torch.randn_like
+    preds = []
+    hook = net.register_forward_hook(lambda m, i, o: preds.append(o.detach().clone()))
+    try:
+        torch.randn_like = lambda x, **k: next(it).to(x.dtype)
+        out_sde = model.FastGenModel.generator_fn(net, noise, condition=cond, student_sample_steps=4,
+                                                 student_sample_type="sde")
+    finally:
+        torch.randn_like = orig_randn_like
+    sde_preds = [p.clone() for p in preds]
+    preds.clear()
+    out_ode = model.FastGenModel.generator_fn(net, noise, condition=cond, student_sample_steps=4,
+                                             student_sample_type="ode")
+    out_1 = model.FastGenModel.generator_fn(net, noise, condition=cond, student_sample_steps=1)
+    out_tl = model.FastGenModel.generator_fn(net, noise, condition=cond, student_sample_steps=2,
+                                            t_list=[40.0, 1.5, 0.0], student_sample_type="ode")
+    hook.remove()
+    torch.save({"sd_checksum": sd_checksum(sd), "noise_checksum": checksum(noise), "cond": cond,
+                "out_sde": out_sde.clone(), "x_pred_sde": torch.stack(sde_preds), "out_ode": out_ode.clone(),
+                "out_1step": out_1.clone(), "out_tlist": out_tl.clone()},
+               os.path.join(OUT, "sampler_full_b2.pt"))
+
+    # ---- reduced-width whole-net trace (oracle unit test; the reference's own test sizes, tests/test_dmd2model.py:13-44)
+    small = edm_ref.SongUNetConfig(img_resolution=8, model_channels=32, channel_mult=(1, 2), num_blocks=1,
+                                   attn_resolutions=(4,))
+    sds = edm_ref.random_state_dict(small, seed=77)
+    nets = ref_net(edm_net, small, sds)
+    xs = seeded((3, 3, 8, 8), 31)
+    ts = torch.tensor([80.0, 2.5, 0.002], dtype=torch.float64)
+    cs = torch.nn.functional.one_hot(torch.tensor([0, 5, 9]), 10).float()
+    with torch.inference_mode():
+        outs = nets(xs, ts, condition=cs, fwd_pred_type="x0")
+        outs_nocond = nets(xs, ts, condition=None, fwd_pred_type="x0")
+    torch.save({"sd_checksum": sd_checksum(sds), "out": outs.clone(), "out_nocond": outs_nocond.clone()},
+               os.path.join(OUT, "forward_small.pt"))
+
+    print("golden fixtures written to", OUT)
+    for f in sorted(os.listdir(OUT)):
+        print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()

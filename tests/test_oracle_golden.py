@@ -1,0 +1,131 @@
+"""Pins oracle/edm_ref.py (the CPU restatement) to golden vectors recorded from the reference itself
+(oracle/gen_golden.py).  CPU only."""
+import os
+
+import pytest
+import torch
+
+from oracle import edm_ref as R
+
+
+def _load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), weights_only=True)
+
+
+def _cs(t):
+    t = t.detach().to(torch.float64).reshape(-1)
+    w = torch.arange(1, t.numel() + 1, dtype=torch.float64) % 7 + 1
+    return torch.stack([t.sum(), (t * w).sum(), t.abs().max()])
+
+
+def _sd_cs(sd):
+    return torch.stack([_cs(v) for _, v in sorted(sd.items())]).sum(0)
+
+
+def _seeded(shape, seed):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.fixture(scope="module")
+def full_sd():
+    return R.random_state_dict(R.CIFAR10, seed=1234)
+
+
+def test_state_dict_names_match_reference(golden_dir):
+    """429 entries, names and shapes exactly as the reference's EDMPrecond.state_dict()."""
+    want = {}
+    for line in open(os.path.join(golden_dir, "state_dict_keys.txt")):
+        parts = line.split()
+        want[parts[0]] = tuple(int(p) for p in parts[1:])
+    got = R.param_shapes(R.CIFAR10)
+    assert len(want) == 429
+    assert got == want
+
+
+def test_schedule(golden_dir):
+    fx = _load(golden_dir, "schedule.pt")
+    sig = R.edm_sigmas()
+    assert torch.equal(sig[:3], fx["sigmas_head"]) and torch.equal(sig[-3:], fx["sigmas_tail"])
+    for n in (1, 2, 4):
+        assert torch.equal(R.edm_t_list(n), fx[f"t_list_{n}"])
+    x, e = _seeded((2, 3, 8, 8), 11), _seeded((2, 3, 8, 8), 12)
+    t = torch.tensor([17.498123, 0.1726], dtype=torch.float64)
+    assert torch.equal(R.forward_process(x, e, t), fx["fp_out"])
+    assert torch.equal(R.latents(x, torch.tensor(79.5638, dtype=torch.float64)), fx["lat_out"])
+    assert torch.equal(R.x0_to_eps(x, e, t), fx["x0eps_out"])
+
+
+def test_schedule_analytic_identities():
+    """The reference's own schedule checks (tests/test_network.py:112-131): EDM has alpha=1, sigma=t."""
+    x, e = _seeded((4, 3, 8, 8), 1), _seeded((4, 3, 8, 8), 2)
+    t = torch.tensor([0.002, 1.0, 10.0, 80.0], dtype=torch.float64)
+    xt = R.forward_process(x, e, t)
+    assert torch.allclose(xt, x + e * t.float().reshape(-1, 1, 1, 1), atol=1e-5)
+    assert torch.allclose(R.x0_to_eps(xt, x, t), e, atol=2e-3)
+    tl = R.edm_t_list(4)
+    assert tl[-1] == 0 and torch.all(tl[:-1] > tl[1:]) and tl[0] <= 80.0
+
+
+def test_forward_small(golden_dir):
+    fx = _load(golden_dir, "forward_small.pt")
+    cfg = R.SongUNetConfig(img_resolution=8, model_channels=32, channel_mult=(1, 2), num_blocks=1, attn_resolutions=(4,))
+    sd = R.random_state_dict(cfg, seed=77)
+    assert torch.allclose(_sd_cs(sd), fx["sd_checksum"])
+    x = _seeded((3, 3, 8, 8), 31)
+    t = torch.tensor([80.0, 2.5, 0.002], dtype=torch.float64)
+    c = torch.nn.functional.one_hot(torch.tensor([0, 5, 9]), 10).float()
+    with torch.inference_mode():
+        assert torch.allclose(R.edm_precond_forward(sd, cfg, x, t, c), fx["out"], rtol=1e-5, atol=1e-5)
+        assert torch.allclose(R.edm_precond_forward(sd, cfg, x, t, None), fx["out_nocond"], rtol=1e-5, atol=1e-5)
+
+
+def test_forward_full_b2(golden_dir, full_sd):
+    fx = _load(golden_dir, "forward_full_b2.pt")
+    assert torch.allclose(_sd_cs(full_sd), fx["sd_checksum"])
+    x = _seeded((2, 3, 32, 32), 21)
+    assert torch.allclose(_cs(x), fx["x_checksum"])
+    trace = {}
+    with torch.inference_mode():
+        out = R.edm_precond_forward(full_sd, R.CIFAR10, x * fx["t"].reshape(2, 1, 1, 1).float(), fx["t"], fx["cond"], trace)
+    assert torch.allclose(trace["emb"], fx["emb"], rtol=1e-5, atol=1e-6)
+    for key, v in trace.items():
+        if key == "emb":
+            continue
+        name = key.replace("model.", "")
+        want = fx[f"blk/{name}/sample"]
+        got = v.reshape(-1)[:: max(1, v.numel() // 4096)][:4096]
+        assert torch.allclose(got, want, rtol=1e-4, atol=1e-4), name
+    assert torch.allclose(out, fx["out"], rtol=1e-4, atol=1e-5)
+
+
+def test_blocks_full(golden_dir, full_sd):
+    fx = _load(golden_dir, "blocks_full.pt")
+    enc, dec = R.layout(R.CIFAR10)
+    by_key = {b.key: b for b in enc + dec}
+    names = sorted({k.split("/")[0] for k in fx if "/" in k})
+    assert len(names) == 9
+    for n in names:
+        b = by_key[fx[f"{n}/key"]]
+        bs = fx[f"{n}/out"].shape[0]
+        rin = b.res * 2 if b.down else (b.res // 2 if b.up else b.res)
+        x = _seeded((bs, b.cin, rin, rin), int(fx[f"{n}/seed"]))
+        assert torch.allclose(_cs(x), fx[f"{n}/x_checksum"])
+        with torch.inference_mode():
+            y = R.unet_block(full_sd, b, x, fx["emb"][:bs])
+        assert torch.allclose(y, fx[f"{n}/out"], rtol=1e-5, atol=1e-5), n
+
+
+def test_sampler_full_b2(golden_dir, full_sd):
+    fx = _load(golden_dir, "sampler_full_b2.pt")
+    noise = _seeded((2, 3, 32, 32), 0)
+    assert torch.allclose(_cs(noise), fx["noise_checksum"])
+    eps = [_seeded((2, 3, 32, 32), s) for s in (1, 2, 3)]
+    tr = {}
+    out = R.generator_fn(full_sd, R.CIFAR10, noise, fx["cond"], 4, sample_type="sde", eps_list=eps, trace=tr)
+    assert torch.allclose(torch.stack(tr["x_pred"]), fx["x_pred_sde"], rtol=1e-4, atol=2e-5)
+    assert torch.allclose(out, fx["out_sde"], rtol=1e-4, atol=2e-5)
+    assert torch.allclose(R.generator_fn(full_sd, R.CIFAR10, noise, fx["cond"], 4, sample_type="ode"), fx["out_ode"],
+                          rtol=1e-4, atol=2e-5)
+    assert torch.allclose(R.generator_fn(full_sd, R.CIFAR10, noise, fx["cond"], 1), fx["out_1step"], rtol=1e-4, atol=2e-5)
+    assert torch.allclose(R.generator_fn(full_sd, R.CIFAR10, noise, fx["cond"], 2, t_list=[40.0, 1.5, 0.0],
+                                         sample_type="ode"), fx["out_tlist"], rtol=1e-4, atol=2e-5)
