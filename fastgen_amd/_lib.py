@@ -1,0 +1,79 @@
+"""ctypes binding of libfastgen_amd.so (C ABI: include/fastgen_amd.h).  There is no fallback: if the library is
+missing or a call fails, this raises."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfastgen_amd.so")
+
+FG_MAX_LEVELS = 8
+FG_DTYPE_F32, FG_DTYPE_BF16 = 0, 1
+FG_SAMPLE_SDE, FG_SAMPLE_ODE = 0, 1
+
+
+class fg_edm_config(ctypes.Structure):
+    _fields_ = [
+        ("img_resolution", c_int), ("img_channels", c_int), ("label_dim", c_int), ("augment_dim", c_int),
+        ("model_channels", c_int), ("num_levels", c_int), ("channel_mult", c_int * FG_MAX_LEVELS),
+        ("channel_mult_emb", c_int), ("num_blocks", c_int), ("num_attn_resolutions", c_int),
+        ("attn_resolutions", c_int * FG_MAX_LEVELS), ("channel_mult_noise", c_int), ("sigma_data", c_double),
+        ("sigma_shift", c_double), ("compute_dtype", c_int),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/fastgen_amd.h declares
+SIGNATURES = {
+    "fg_last_error": (c_char_p, []),
+    "fg_version": (c_char_p, []),
+    "fg_edm_create": (c_int, [POINTER(fg_edm_config), POINTER(c_void_p)]),
+    "fg_edm_destroy": (None, [c_void_p]),
+    "fg_edm_num_params": (c_int, [c_void_p]),
+    "fg_edm_param_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int), POINTER(c_int64)]),
+    "fg_edm_bind_param": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
+    "fg_edm_pack_weights": (c_int, [c_void_p, c_void_p]),
+    "fg_edm_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "fg_edm_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "fg_sampler_run": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double), c_int, c_int, c_void_p, c_uint64,
+                               c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
+    "fg_edm_t_list": (c_int, [c_int, POINTER(c_double)]),
+    "fg_edm_num_blocks": (c_int, [c_void_p]),
+    "fg_edm_block_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int), POINTER(c_int), POINTER(c_int),
+                                  POINTER(c_int), POINTER(c_int)]),
+    "fg_edm_run_block": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                 c_size_t, c_void_p]),
+    "fg_op_gn_coeffs": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]),
+    "fg_op_latents": (c_int, [c_void_p, c_double, c_void_p, c_int64, c_void_p]),
+    "fg_op_forward_process": (c_int, [c_void_p, c_void_p, c_double, c_void_p, c_int64, c_void_p]),
+    "fg_op_x0_to_eps": (c_int, [c_void_p, c_void_p, c_double, c_void_p, c_int64, c_void_p]),
+    "fg_op_randn": (c_int, [c_void_p, c_int64, c_uint64, c_uint64, c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the library.  Raises if it has not been built: there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C fastgen_amd/csrc`).  fastgen_amd has no non-HIP fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class FastGenAMDError(RuntimeError):
+    pass
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = lib().fg_last_error().decode("utf-8", "replace")
+        raise FastGenAMDError(f"fastgen_amd error {rc}: {msg}")

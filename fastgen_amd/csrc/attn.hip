@@ -1,0 +1,156 @@
+// Single-head self-attention of the EDM U-Net blocks (reference fastgen/networks/EDM/network.py:160-168, 290-296):
+//     w = softmax_k( q^T (k / sqrt(C)) )  in fp32,   a[c,q] = sum_k w[q,k] v[c,k]
+// C = 256 channels = ONE head of dim 256, T = 256 (16x16) or 64 (8x8) tokens.
+//
+// One wave owns 32 queries end to end; nothing goes through LDS:
+//   1. S^T = K Q^T on the matrix cores with the KEY on the accumulator rows and the QUERY on the lane, so a lane
+//      holds half of the T logits of its query (the other half sits in lane^32) and the softmax is in-register.
+//   2. The normalised P^T accumulators are reused directly as the A operand of O = P V (an accumulator tile whose
+//      column is on the lane feeds the next MFMA that sums over its row index); V is read from a [C][T] plane the
+//      qkv projection already wrote, in the K order the accumulator layout dictates.
+#include "common.h"
+#include "misc.h"
+
+namespace {
+
+template <typename T>
+struct PFrag;  // the P^T accumulator registers 8s..8s+7 as an A operand
+template <>
+struct PFrag<__bf16> {
+    static __device__ __forceinline__ Frag8<__bf16> make(const f32x16& p, int s) {
+        Frag8<__bf16> f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)p[8 * s + j];
+        return f;
+    }
+};
+template <>
+struct PFrag<float> {
+    static __device__ __forceinline__ Frag8<float> make(const f32x16& p, int s) {
+        Frag8<float> f;
+        f.lo = f32x4{p[8 * s + 0], p[8 * s + 1], p[8 * s + 2], p[8 * s + 3]};
+        f.hi = f32x4{p[8 * s + 4], p[8 * s + 5], p[8 * s + 6], p[8 * s + 7]};
+        return f;
+    }
+};
+
+// V fragment for k-step s of key tile kt: element j <-> key kt*32 + 16s + 8(j>>2) + 4h + (j&3)
+__device__ __forceinline__ Frag8<__bf16> load_v(const __bf16* row, int key0) {
+    Frag8<__bf16> f;
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(row + key0);
+    const bf16x4 b = *reinterpret_cast<const bf16x4*>(row + key0 + 8);
+    f.v = bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return f;
+}
+__device__ __forceinline__ Frag8<float> load_v(const float* row, int key0) {
+    Frag8<float> f;
+    f.lo = *reinterpret_cast<const f32x4*>(row + key0);
+    f.hi = *reinterpret_cast<const f32x4*>(row + key0 + 8);
+    return f;
+}
+
+template <typename T, int NT>  // NT = T/32 key tiles
+__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                        const T* __restrict__ vt, float* __restrict__ out, int B) {
+    constexpr int Tn = NT * 32;
+    constexpr int D = 256;
+    constexpr bool FAST = DT<T>::FAST;
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);  // global wave id = (image, 32-query slab)
+    const int n = gw / NT, q0 = (gw % NT) * 32;
+    if (n >= B) return;  // wave-uniform
+
+    const T* qrow = q + ((size_t)n * Tn + q0 + r) * D + 8 * h;
+    const T* kbase = k + ((size_t)n * Tn + r) * D + 8 * h;
+
+    // ---- S^T[key][query] = sum_d K[key][d] Q[query][d] --------------------------------------------------
+    f32x16 st[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[kt][i] = 0.f;
+#pragma unroll 2
+    for (int kk = 0; kk < D / 16; ++kk) {
+        const Frag8<T> qf = load_frag(qrow + kk * 16);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const Frag8<T> kf = load_frag(kbase + (size_t)kt * 32 * D + kk * 16);
+            mma16(st[kt], kf, qf);
+        }
+    }
+
+    // ---- softmax over keys (registers + the partner half-wave) ---------------------------------------------
+    const float sc = 0.0625f;  // 1/sqrt(256): the reference scales k, an exact power of two either way
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m = fmaxf(m, st[kt][i]);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float z = (st[kt][i] - m) * sc;
+            const float e = FAST ? __builtin_amdgcn_exp2f(1.44269504088896341f * z) : expf(z);
+            st[kt][i] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 32);
+    const float inv = FAST ? __builtin_amdgcn_rcpf(sum) : 1.0f / sum;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[kt][i] = FAST ? st[kt][i] * inv : st[kt][i] / sum;
+
+    // ---- O[query][dim] = sum_key P[query][key] V[key][dim], four 32-wide dim tiles at a time ---------------
+    const T* vbase = vt + ((size_t)n * D + r) * Tn + 4 * h;
+    float* obase = out + ((size_t)n * Tn + q0) * D + r;
+#pragma unroll 1
+    for (int dg = 0; dg < D / 128; ++dg) {
+        f32x16 o[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const Frag8<T> pf = PFrag<T>::make(st[kt], s);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const Frag8<T> vf = load_v(vbase + (size_t)(dg * 128 + d * 32) * Tn, kt * 32 + 16 * s);
+                    mma16(o[d], pf, vf);
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) obase[(size_t)acc_row(i, h) * D + dg * 128 + d * 32] = o[d][i];
+    }
+}
+
+}  // namespace
+
+int launch_attention(int dtype, const void* q, const void* k, const void* vt, float* out, int B, int T, hipStream_t s) {
+    if (T != 256 && T != 64) return (int)hipErrorInvalidValue;
+    const int nt = T / 32;
+    const int waves = B * nt;
+    dim3 grid((waves + 3) / 4), block(256);
+    if (dtype) {
+        if (nt == 8)
+            hipLaunchKernelGGL((attention_kernel<__bf16, 8>), grid, block, 0, s, (const __bf16*)q, (const __bf16*)k, (const __bf16*)vt, out, B);
+        else
+            hipLaunchKernelGGL((attention_kernel<__bf16, 2>), grid, block, 0, s, (const __bf16*)q, (const __bf16*)k, (const __bf16*)vt, out, B);
+    } else {
+        if (nt == 8)
+            hipLaunchKernelGGL((attention_kernel<float, 8>), grid, block, 0, s, (const float*)q, (const float*)k, (const float*)vt, out, B);
+        else
+            hipLaunchKernelGGL((attention_kernel<float, 2>), grid, block, 0, s, (const float*)q, (const float*)k, (const float*)vt, out, B);
+    }
+    return (int)hipGetLastError();
+}

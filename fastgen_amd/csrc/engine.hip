@@ -1,0 +1,774 @@
+// fastgen_amd engine: network plan, weight packing, workspace arena, forward orchestration, sampler loop with hipGraph
+// replay, and the C ABI declared in include/fastgen_amd.h.  Host-side C++ only; every kernel lives in conv/attn/misc.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fastgen_amd.h"
+#include "conv.h"
+#include "misc.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (hipError_t)(expr);                                                                    \
+        if (e_ != hipSuccess) return fail(FG_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct Param {
+    std::string name;
+    int ndim = 0;
+    int64_t shape[4] = {1, 1, 1, 1};
+    int64_t numel = 0;
+    const float* ptr = nullptr;  // borrowed device pointer (fp32, reference layout)
+};
+
+enum Kind { K_STEM, K_BLOCK, K_AUX_NORM, K_AUX_CONV };
+
+struct Block {
+    std::string key;
+    Kind kind = K_BLOCK;
+    int cin = 0, cout = 0, res_in = 0, res_out = 0;
+    bool up = false, down = false, attn = false, has_skip = false, is_dec = false;
+    int skip_c = 0;    // decoder: channels taken from the skip stack (concat), else 0
+    int temb_off = 0;  // column offset of this block's affine() in the stacked embedding projection
+    // parameter indices (-1 = absent)
+    int norm0_w = -1, norm0_b = -1, conv0_w = -1, conv0_b = -1, aff_w = -1, aff_b = -1, norm1_w = -1, norm1_b = -1,
+        conv1_w = -1, conv1_b = -1, skip_w = -1, skip_b = -1, norm2_w = -1, norm2_b = -1, qkv_w = -1, qkv_b = -1,
+        proj_w = -1, proj_b = -1, w = -1, b = -1;
+    // packed weights (owned device memory, compute dtype)
+    void *p_conv0 = nullptr, *p_conv1 = nullptr, *p_skip = nullptr, *p_qkv = nullptr, *p_proj = nullptr;
+    float* qkv_bias = nullptr;  // [3C] permuted to q|k|v
+};
+
+struct Arena {
+    char* base = nullptr;
+    size_t off = 0, cap = 0;
+    bool dry = false;
+    void* take(size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        void* p = dry ? nullptr : base + off;
+        off += bytes;
+        return p;
+    }
+    template <typename T>
+    T* get(size_t n) {
+        return reinterpret_cast<T*>(take(n * sizeof(T)));
+    }
+};
+
+struct Workspace {
+    float *coef, *emb0, *emb1, *emb, *temb;
+    float2 *ab0, *ab1, *ab2;
+    std::vector<float*> skip;  // encoder outputs
+    float *xa, *xb, *h, *sbuf, *xattn, *aout;
+    void *q, *k, *vt;
+    // sampler state
+    float *x, *x_pred, *eps;
+    double* tl;      // [65]
+    uint64_t* seed;  // [2]
+};
+
+struct GraphKey {
+    int B = 0, steps = 0, type = 0;
+    uint64_t zero_mask = 0;
+    const void *noise = nullptr, *labels = nullptr, *eps = nullptr, *out = nullptr, *ws = nullptr;
+    bool device_rng = false;
+    bool operator==(const GraphKey& o) const {
+        return B == o.B && steps == o.steps && type == o.type && zero_mask == o.zero_mask && noise == o.noise &&
+               labels == o.labels && eps == o.eps && out == o.out && ws == o.ws && device_rng == o.device_rng;
+    }
+};
+
+}  // namespace
+
+struct fg_edm {
+    fg_edm_config cfg;
+    int dtype = 0;
+    int emb_ch = 0, noise_ch = 0;
+    std::vector<Param> params;
+    std::vector<Block> enc, dec;  // dec includes aux_norm / aux_conv entries
+    std::vector<Block*> blocks;   // UNetBlocks only, encoder then decoder order
+    int temb_total = 0;
+    bool packed = false;
+    bool device_ready = false;
+    // owned device memory
+    float* freqs = nullptr;      // [noise_ch/2]
+    float* aff_w = nullptr;      // [temb_total][emb_ch]
+    float* aff_b = nullptr;      // [temb_total]
+    std::vector<void*> owned;
+    // graph cache
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    GraphKey graph_key;
+    double* tl_pinned = nullptr;      // [65]
+    uint64_t* seed_pinned = nullptr;  // [2]
+    hipStream_t cap_stream = nullptr;  // capture-only stream (the legacy default stream cannot be captured)
+
+    int find(const std::string& n) const {
+        for (size_t i = 0; i < params.size(); ++i)
+            if (params[i].name == n) return (int)i;
+        return -1;
+    }
+    int add(const std::string& n, std::initializer_list<int64_t> shp) {
+        Param p;
+        p.name = n;
+        p.ndim = (int)shp.size();
+        p.numel = 1;
+        int i = 0;
+        for (int64_t s : shp) {
+            p.shape[i++] = s;
+            p.numel *= s;
+        }
+        params.push_back(p);
+        return (int)params.size() - 1;
+    }
+    const float* P(int idx) const { return idx >= 0 ? params[idx].ptr : nullptr; }
+};
+
+namespace {
+
+// Module order of SongUNet (standard encoder / decoder), reference EDM/network.py:417-486; state-dict names as there.
+void build_layout(fg_edm* h) {
+    const fg_edm_config& c = h->cfg;
+    const int E = h->emb_ch, N = h->noise_ch;
+    if (c.label_dim) {
+        h->add("model.map_label.weight", {N, c.label_dim});
+        h->add("model.map_label.bias", {N});
+    }
+    if (c.augment_dim) h->add("model.map_augment.weight", {N, c.augment_dim});
+    h->add("model.map_layer0.weight", {E, N});
+    h->add("model.map_layer0.bias", {E});
+    h->add("model.map_layer1.weight", {E, E});
+    h->add("model.map_layer1.bias", {E});
+
+    auto is_attn_res = [&](int res) {
+        for (int i = 0; i < c.num_attn_resolutions; ++i)
+            if (c.attn_resolutions[i] == res) return true;
+        return false;
+    };
+    auto make_block = [&](const std::string& key, int cin, int cout, int res_out, bool up, bool down, bool attn,
+                          int skip_c, bool is_dec) {
+        Block b;
+        b.key = key;
+        b.kind = K_BLOCK;
+        b.cin = cin;
+        b.cout = cout;
+        b.res_out = res_out;
+        b.res_in = down ? res_out * 2 : (up ? res_out / 2 : res_out);
+        b.up = up;
+        b.down = down;
+        b.attn = attn;
+        b.skip_c = skip_c;
+        b.is_dec = is_dec;
+        b.has_skip = (cin != cout) || up || down;
+        b.norm0_w = h->add(key + ".norm0.weight", {cin});
+        b.norm0_b = h->add(key + ".norm0.bias", {cin});
+        b.conv0_w = h->add(key + ".conv0.weight", {cout, cin, 3, 3});
+        b.conv0_b = h->add(key + ".conv0.bias", {cout});
+        b.aff_w = h->add(key + ".affine.weight", {cout, E});
+        b.aff_b = h->add(key + ".affine.bias", {cout});
+        b.norm1_w = h->add(key + ".norm1.weight", {cout});
+        b.norm1_b = h->add(key + ".norm1.bias", {cout});
+        b.conv1_w = h->add(key + ".conv1.weight", {cout, cout, 3, 3});
+        b.conv1_b = h->add(key + ".conv1.bias", {cout});
+        if (b.has_skip) {
+            b.skip_w = h->add(key + ".skip.weight", {cout, cin, 1, 1});
+            b.skip_b = h->add(key + ".skip.bias", {cout});
+        }
+        if (attn) {
+            b.norm2_w = h->add(key + ".norm2.weight", {cout});
+            b.norm2_b = h->add(key + ".norm2.bias", {cout});
+            b.qkv_w = h->add(key + ".qkv.weight", {3 * cout, cout, 1, 1});
+            b.qkv_b = h->add(key + ".qkv.bias", {3 * cout});
+            b.proj_w = h->add(key + ".proj.weight", {cout, cout, 1, 1});
+            b.proj_b = h->add(key + ".proj.bias", {cout});
+        }
+        b.temb_off = h->temb_total;
+        h->temb_total += cout;
+        return b;
+    };
+    auto res_name = [](int r) { return std::to_string(r) + "x" + std::to_string(r); };
+
+    std::vector<int> skips;
+    int cout = c.img_channels;
+    for (int level = 0; level < c.num_levels; ++level) {
+        const int res = c.img_resolution >> level;
+        if (level == 0) {
+            Block b;
+            b.key = "model.enc." + res_name(res) + "_conv";
+            b.kind = K_STEM;
+            b.cin = cout;
+            b.cout = cout = c.model_channels;
+            b.res_in = b.res_out = res;
+            b.w = h->add(b.key + ".weight", {b.cout, b.cin, 3, 3});
+            b.b = h->add(b.key + ".bias", {b.cout});
+            h->enc.push_back(b);
+        } else {
+            h->enc.push_back(make_block("model.enc." + res_name(res) + "_down", cout, cout, res, false, true, false, 0, false));
+        }
+        skips.push_back(cout);
+        for (int idx = 0; idx < c.num_blocks; ++idx) {
+            const int cin = cout;
+            cout = c.model_channels * c.channel_mult[level];
+            h->enc.push_back(make_block("model.enc." + res_name(res) + "_block" + std::to_string(idx), cin, cout, res,
+                                        false, false, is_attn_res(res), 0, false));
+            skips.push_back(cout);
+        }
+    }
+    for (int level = c.num_levels - 1; level >= 0; --level) {
+        const int res = c.img_resolution >> level;
+        if (level == c.num_levels - 1) {
+            h->dec.push_back(make_block("model.dec." + res_name(res) + "_in0", cout, cout, res, false, false, true, 0, true));
+            h->dec.push_back(make_block("model.dec." + res_name(res) + "_in1", cout, cout, res, false, false, false, 0, true));
+        } else {
+            h->dec.push_back(make_block("model.dec." + res_name(res) + "_up", cout, cout, res, true, false, false, 0, true));
+        }
+        for (int idx = 0; idx <= c.num_blocks; ++idx) {
+            const int sk = skips.back();
+            skips.pop_back();
+            const int cin = cout + sk;
+            cout = c.model_channels * c.channel_mult[level];
+            const bool attn = (idx == c.num_blocks) && is_attn_res(res);
+            h->dec.push_back(make_block("model.dec." + res_name(res) + "_block" + std::to_string(idx), cin, cout, res,
+                                        false, false, attn, sk, true));
+        }
+        if (level == 0) {
+            Block n;
+            n.key = "model.dec." + res_name(res) + "_aux_norm";
+            n.kind = K_AUX_NORM;
+            n.cin = n.cout = cout;
+            n.res_in = n.res_out = res;
+            n.w = h->add(n.key + ".weight", {cout});
+            n.b = h->add(n.key + ".bias", {cout});
+            h->dec.push_back(n);
+            Block a;
+            a.key = "model.dec." + res_name(res) + "_aux_conv";
+            a.kind = K_AUX_CONV;
+            a.cin = cout;
+            a.cout = c.img_channels;
+            a.res_in = a.res_out = res;
+            a.w = h->add(a.key + ".weight", {a.cout, a.cin, 3, 3});
+            a.b = h->add(a.key + ".bias", {a.cout});
+            h->dec.push_back(a);
+        }
+    }
+    h->add("model.logvar_linear.weight", {1, N});
+    h->add("model.logvar_linear.bias", {1});
+    for (auto& b : h->enc)
+        if (b.kind == K_BLOCK) h->blocks.push_back(&b);
+    for (auto& b : h->dec)
+        if (b.kind == K_BLOCK) h->blocks.push_back(&b);
+}
+
+int check_supported(const fg_edm* h) {
+    const fg_edm_config& c = h->cfg;
+    const int kc = h->dtype ? 64 : 32;
+    if (c.img_resolution != 32 && c.img_resolution != 16 && c.img_resolution != 8)
+        return fail(FG_EINVAL, "img_resolution %d unsupported (8, 16, 32)", c.img_resolution);
+    if ((c.img_resolution >> (c.num_levels - 1)) < 8)
+        return fail(FG_EINVAL, "lowest resolution %d < 8 unsupported", c.img_resolution >> (c.num_levels - 1));
+    if (c.img_channels > 4) return fail(FG_EINVAL, "img_channels %d > 4 unsupported", c.img_channels);
+    for (const Block* b : h->blocks) {
+        if (b->cout != 256) return fail(FG_EINVAL, "%s: out_channels %d unsupported (kernels are tiled for 256)", b->key.c_str(), b->cout);
+        if (b->cin % kc || (b->cin - b->skip_c) % kc)
+            return fail(FG_EINVAL, "%s: in_channels %d not a multiple of %d", b->key.c_str(), b->cin, kc);
+        if (b->attn && b->res_out > 16) return fail(FG_EINVAL, "%s: attention at %dx%d unsupported", b->key.c_str(), b->res_out, b->res_out);
+    }
+    return FG_OK;
+}
+
+size_t plan_workspace(const fg_edm* h, int B, Arena& A, Workspace& w) {
+    const fg_edm_config& c = h->cfg;
+    const size_t tsz = h->dtype ? 2 : 4;
+    const int R = c.img_resolution;
+    size_t max_act = 0;  // largest [res,res,C] activation per image
+    int max_c = 0, max_attn_hw = 0;
+    for (const Block& b : h->enc) max_act = std::max(max_act, (size_t)b.res_out * b.res_out * b.cout);
+    for (const Block* b : h->blocks) {
+        max_act = std::max(max_act, (size_t)b->res_out * b->res_out * b->cout);
+        max_c = std::max(max_c, std::max(b->cin, b->cout));
+        if (b->attn) max_attn_hw = std::max(max_attn_hw, b->res_out * b->res_out);
+    }
+    w.coef = A.get<float>(4 * (size_t)B);
+    w.emb0 = A.get<float>((size_t)B * h->noise_ch);
+    w.emb1 = A.get<float>((size_t)B * h->emb_ch);
+    w.emb = A.get<float>((size_t)B * h->emb_ch);
+    w.temb = A.get<float>((size_t)B * h->temb_total);
+    w.ab0 = A.get<float2>((size_t)B * max_c);
+    w.ab1 = A.get<float2>((size_t)B * max_c);
+    w.ab2 = A.get<float2>((size_t)B * max_c);
+    w.skip.clear();
+    for (const Block& b : h->enc) w.skip.push_back(A.get<float>((size_t)B * b.res_out * b.res_out * b.cout));
+    w.xa = A.get<float>((size_t)B * max_act);
+    w.xb = A.get<float>((size_t)B * max_act);
+    w.h = A.get<float>((size_t)B * max_act);
+    w.sbuf = A.get<float>((size_t)B * max_act);
+    w.xattn = A.get<float>((size_t)B * max_attn_hw * 256);
+    w.aout = A.get<float>((size_t)B * max_attn_hw * 256);
+    w.q = A.take((size_t)B * max_attn_hw * 256 * tsz);
+    w.k = A.take((size_t)B * max_attn_hw * 256 * tsz);
+    w.vt = A.take((size_t)B * max_attn_hw * 256 * tsz);
+    const size_t img = (size_t)B * c.img_channels * R * R;
+    w.x = A.get<float>(img);
+    w.x_pred = A.get<float>(img);
+    w.eps = A.get<float>(img);
+    w.tl = A.get<double>(72);
+    w.seed = A.get<uint64_t>(8);
+    return (A.off + 255) & ~(size_t)255;
+}
+
+int dev_alloc(fg_edm* h, void** p, size_t bytes) {
+    HIP_TRY(hipMalloc(p, bytes));
+    h->owned.push_back(*p);
+    return FG_OK;
+}
+
+const float kSkipScale = (float)std::sqrt(0.5);  // block_kwargs.skip_scale, EDM/network.py:385
+const float kBlockEps = 1e-6f;                   // block_kwargs.eps :386, aux_norm :483
+
+// One UNetBlock (EDM/network.py:274-299) as 3-8 kernel launches.
+int run_block(fg_edm* h, const Block& b, const float* x1, int c1, const float* x2, int c2, const float* temb,
+              float* out, int B, Workspace& w, hipStream_t s) {
+    if (c1 + c2 != b.cin) return fail(FG_EINVAL, "%s: got %d+%d input channels, expected %d", b.key.c_str(), c1, c2, b.cin);
+    const int hw_in = b.res_in * b.res_in;
+    const int res_mode = b.down ? RES_DOWN : (b.up ? RES_UP : RES_NONE);
+    // h = conv0(silu(norm0(x))) + affine(emb)
+    HIP_TRY(launch_gn_coeffs(x1, c1, x2, c2, h->P(b.norm0_w), h->P(b.norm0_b), kBlockEps, w.ab0, B, hw_in, s));
+    ConvArgs a{};
+    a.src1 = x1; a.src2 = x2; a.C1 = c1; a.C2 = c2;
+    a.Hs = a.Ws = b.res_in; a.H = a.W = b.res_out; a.B = B;
+    a.ab = w.ab0; a.wpack = b.p_conv0; a.bias = h->P(b.conv0_b);
+    a.temb = temb + b.temb_off; a.temb_stride = h->temb_total;
+    a.resid = nullptr; a.scale = 1.0f; a.out = w.h; a.Cout = b.cout;
+    HIP_TRY(launch_conv_fused(h->dtype, 3, PRO_GN_SILU, res_mode, OUT_NHWC, a, s));
+    // skip path
+    const float* resid = x1;
+    if (b.has_skip) {
+        ConvArgs k{};
+        k.src1 = x1; k.src2 = x2; k.C1 = c1; k.C2 = c2;
+        k.Hs = k.Ws = b.res_in; k.H = k.W = b.res_out; k.B = B;
+        k.wpack = b.p_skip; k.bias = h->P(b.skip_b); k.scale = 1.0f; k.out = w.sbuf; k.Cout = b.cout;
+        HIP_TRY(launch_conv_fused(h->dtype, 1, PRO_NONE, res_mode, OUT_NHWC, k, s));
+        resid = w.sbuf;
+    }
+    // x = (conv1(silu(norm1(h))) + skip) * sqrt(.5)
+    const int hw = b.res_out * b.res_out;
+    HIP_TRY(launch_gn_coeffs(w.h, b.cout, nullptr, 0, h->P(b.norm1_w), h->P(b.norm1_b), kBlockEps, w.ab1, B, hw, s));
+    float* x_mid = b.attn ? w.xattn : out;
+    ConvArgs d{};
+    d.src1 = w.h; d.C1 = b.cout; d.Hs = d.Ws = d.H = d.W = b.res_out; d.B = B;
+    d.ab = w.ab1; d.wpack = b.p_conv1; d.bias = h->P(b.conv1_b);
+    d.resid = resid; d.scale = kSkipScale; d.out = x_mid; d.Cout = b.cout;
+    HIP_TRY(launch_conv_fused(h->dtype, 3, PRO_GN_SILU, RES_NONE, OUT_NHWC, d, s));
+    if (b.attn) {
+        HIP_TRY(launch_gn_coeffs(x_mid, b.cout, nullptr, 0, h->P(b.norm2_w), h->P(b.norm2_b), kBlockEps, w.ab2, B, hw, s));
+        ConvArgs q{};
+        q.src1 = x_mid; q.C1 = b.cout; q.Hs = q.Ws = q.H = q.W = b.res_out; q.B = B;
+        q.ab = w.ab2; q.wpack = b.p_qkv; q.bias = b.qkv_bias; q.scale = 1.0f; q.Cout = 3 * b.cout;
+        q.q_out = w.q; q.k_out = w.k; q.vt_out = w.vt;
+        HIP_TRY(launch_conv_fused(h->dtype, 1, PRO_GN, RES_NONE, OUT_QKV, q, s));
+        HIP_TRY(launch_attention(h->dtype, w.q, w.k, w.vt, w.aout, B, hw, s));
+        ConvArgs p{};
+        p.src1 = w.aout; p.C1 = b.cout; p.Hs = p.Ws = p.H = p.W = b.res_out; p.B = B;
+        p.wpack = b.p_proj; p.bias = h->P(b.proj_b); p.resid = x_mid; p.scale = kSkipScale; p.out = out; p.Cout = b.cout;
+        HIP_TRY(launch_conv_fused(h->dtype, 1, PRO_NONE, RES_NONE, OUT_NHWC, p, s));
+    }
+    return FG_OK;
+}
+
+int run_mapping(fg_edm* h, const float* labels, int B, Workspace& w, hipStream_t s) {
+    const fg_edm_config& c = h->cfg;
+    HIP_TRY(launch_mapping_in(w.coef + B, h->freqs, labels, c.label_dim, h->P(h->find("model.map_label.weight")),
+                              h->P(h->find("model.map_label.bias")), w.emb0, B, h->noise_ch, s));
+    HIP_TRY(launch_linear(w.emb0, h->P(h->find("model.map_layer0.weight")), h->P(h->find("model.map_layer0.bias")), w.emb1,
+                          B, h->noise_ch, h->emb_ch, 1, s));
+    HIP_TRY(launch_linear(w.emb1, h->P(h->find("model.map_layer1.weight")), h->P(h->find("model.map_layer1.bias")), w.emb, B,
+                          h->emb_ch, h->emb_ch, 1, s));
+    HIP_TRY(launch_linear(w.emb, h->aff_w, h->aff_b, w.temb, B, h->emb_ch, h->temb_total, 0, s));
+    return FG_OK;
+}
+
+// EDMPrecond.forward (eval, fwd_pred_type = x0): EDM/network.py:881-974 + SongUNet.forward :489-574.
+int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, const float* labels, float* out, int B,
+                Workspace& w, hipStream_t s) {
+    const fg_edm_config& c = h->cfg;
+    HIP_TRY(launch_precond_coef(t, t_stride, c.sigma_data, c.sigma_shift, 1e-6, w.coef, B, s));
+    int rc = run_mapping(h, labels, B, w, s);
+    if (rc) return rc;
+    // encoder
+    const float* x = nullptr;
+    for (size_t i = 0; i < h->enc.size(); ++i) {
+        const Block& b = h->enc[i];
+        if (b.kind == K_STEM) {
+            HIP_TRY(launch_conv_in(x_t, w.coef, h->P(b.w), h->P(b.b), w.skip[i], B, b.res_out, b.cin, b.cout, s));
+        } else {
+            rc = run_block(h, b, x, b.cin, nullptr, 0, w.temb, w.skip[i], B, w, s);
+            if (rc) return rc;
+        }
+        x = w.skip[i];
+    }
+    // decoder (skip stack popped from the back; concat is virtual)
+    int sp = (int)h->enc.size();
+    float* pong[2] = {w.xa, w.xb};
+    int cur = 0;
+    const float2* aux_ab = nullptr;
+    for (const Block& b : h->dec) {
+        if (b.kind == K_BLOCK) {
+            const float* x2 = nullptr;
+            if (b.skip_c) x2 = w.skip[--sp];
+            rc = run_block(h, b, x, b.cin - b.skip_c, x2, b.skip_c, w.temb, pong[cur], B, w, s);
+            if (rc) return rc;
+            x = pong[cur];
+            cur ^= 1;
+        } else if (b.kind == K_AUX_NORM) {
+            HIP_TRY(launch_gn_coeffs(x, b.cin, nullptr, 0, h->P(b.w), h->P(b.b), kBlockEps, w.ab0, B, b.res_in * b.res_in, s));
+            aux_ab = w.ab0;
+        } else if (b.kind == K_AUX_CONV) {
+            HIP_TRY(launch_aux_out(h->dtype, x, aux_ab, h->P(b.w), h->P(b.b), x_t, w.coef, out, B, b.res_out, b.cin, b.cout, s));
+        }
+    }
+    return FG_OK;
+}
+
+int enqueue_sampler(fg_edm* h, const float* noise, const float* labels, const double* t_list, int steps, int type,
+                    const float* eps, float* out, int B, Workspace& w, hipStream_t s) {
+    const fg_edm_config& c = h->cfg;
+    const int64_t total = (int64_t)B * c.img_channels * c.img_resolution * c.img_resolution;
+    HIP_TRY(hipMemcpyAsync(w.tl, h->tl_pinned, sizeof(double) * (steps + 1), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(w.seed, h->seed_pinned, sizeof(uint64_t) * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_latents(noise, 0.0, w.tl, 0, w.x, total, s));  // latents = noise * sigma(t_0), noise_schedule.py:72-88
+    for (int i = 0; i < steps; ++i) {
+        float* pred = (i == steps - 1) ? out : w.x_pred;
+        int rc = run_forward(h, w.x, w.tl + i, 0, labels, pred, B, w, s);
+        if (rc) return rc;
+        if (t_list[i + 1] > 0) {  // methods/model.py:356 — decided on the host, baked into the graph
+            const float* e = nullptr;
+            if (type == FG_SAMPLE_SDE) {
+                if (eps) {
+                    e = eps + (size_t)i * total;
+                } else {
+                    HIP_TRY(launch_randn(w.eps, total, 0, (uint64_t)i, w.seed, s));
+                    e = w.eps;
+                }
+            } else {
+                HIP_TRY(launch_x0_to_eps(w.x, pred, 0.0, w.tl, i, 1e-6, w.eps, total, s));
+                e = w.eps;
+            }
+            HIP_TRY(launch_forward_process(pred, e, 0.0, w.tl, i + 1, w.x, total, s));
+            if (i == steps - 1) {
+                // t_list[-1] must be 0 (model.py:410), so the last step never re-noises; unreachable by contract
+            }
+        }
+    }
+    return FG_OK;
+}
+
+void drop_graph(fg_edm* h) {
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    h->graph_exec = nullptr;
+    h->graph = nullptr;
+}
+
+int setup_ws(const fg_edm* h, int B, void* workspace, size_t bytes, Workspace& w) {
+    if (B <= 0) return fail(FG_EINVAL, "batch must be positive");
+    if (!workspace) return fail(FG_EINVAL, "workspace is null");
+    if (((uintptr_t)workspace) & 255) return fail(FG_EINVAL, "workspace must be 256-byte aligned");
+    Arena A;
+    A.base = (char*)workspace;
+    const size_t need = plan_workspace(h, B, A, w);
+    if (need > bytes) return fail(FG_ENOMEM, "workspace too small: need %zu bytes for batch %d, got %zu", need, B, bytes);
+    return FG_OK;
+}
+
+// Device-side state (packed-weight storage, stacked affine matrix, frequency table, pinned staging).  Deferred to the
+// first fg_edm_pack_weights() so that fg_edm_create() is host-only and works without a GPU.
+int ensure_device_state(fg_edm* h) {
+    if (h->device_ready) return FG_OK;
+    int rc;
+    const size_t tsz = h->dtype ? 2 : 4;
+    for (Block* b : h->blocks) {
+        if ((rc = dev_alloc(h, &b->p_conv0, conv_pack_elems(b->cout, b->cin, 3) * tsz))) return rc;
+        if ((rc = dev_alloc(h, &b->p_conv1, conv_pack_elems(b->cout, b->cout, 3) * tsz))) return rc;
+        if (b->has_skip && (rc = dev_alloc(h, &b->p_skip, conv_pack_elems(b->cout, b->cin, 1) * tsz))) return rc;
+        if (b->attn) {
+            if ((rc = dev_alloc(h, &b->p_qkv, conv_pack_elems(3 * b->cout, b->cout, 1) * tsz))) return rc;
+            if ((rc = dev_alloc(h, &b->p_proj, conv_pack_elems(b->cout, b->cout, 1) * tsz))) return rc;
+            if ((rc = dev_alloc(h, (void**)&b->qkv_bias, sizeof(float) * 3 * b->cout))) return rc;
+        }
+    }
+    if ((rc = dev_alloc(h, (void**)&h->aff_w, sizeof(float) * (size_t)h->temb_total * h->emb_ch))) return rc;
+    if ((rc = dev_alloc(h, (void**)&h->aff_b, sizeof(float) * (size_t)h->temb_total))) return rc;
+    // PositionalEmbedding(endpoint=True) frequencies in fp32, EDM/network.py:314-316
+    const int half = h->noise_ch / 2;
+    std::vector<float> fr(half);
+    for (int j = 0; j < half; ++j) fr[j] = powf(1.0f / 10000.0f, (float)j / (float)(half - 1));
+    if ((rc = dev_alloc(h, (void**)&h->freqs, sizeof(float) * half))) return rc;
+    HIP_TRY(hipMemcpy(h->freqs, fr.data(), sizeof(float) * half, hipMemcpyHostToDevice));
+    if (conv_prepare_all(h->dtype) != 0) return fail(FG_EHIP, "hipFuncSetAttribute(dynamic LDS) failed");
+    HIP_TRY(hipHostMalloc((void**)&h->tl_pinned, sizeof(double) * 72));
+    HIP_TRY(hipHostMalloc((void**)&h->seed_pinned, sizeof(uint64_t) * 8));
+    h->device_ready = true;
+    return FG_OK;
+}
+
+}  // namespace
+
+// ================================================ C ABI =====================================================
+extern "C" {
+
+const char* fg_last_error(void) { return g_err.c_str(); }
+const char* fg_version(void) { return "fastgen_amd 0.1 gfx950"; }
+
+int fg_edm_create(const fg_edm_config* cfg, fg_edm** out) {
+    if (!cfg || !out) return fail(FG_EINVAL, "null argument");
+    if (cfg->num_levels < 1 || cfg->num_levels > FG_MAX_LEVELS || cfg->num_attn_resolutions < 0 ||
+        cfg->num_attn_resolutions > FG_MAX_LEVELS)
+        return fail(FG_EINVAL, "bad num_levels / num_attn_resolutions");
+    if (cfg->compute_dtype != FG_DTYPE_F32 && cfg->compute_dtype != FG_DTYPE_BF16) return fail(FG_EINVAL, "bad compute_dtype");
+    if (cfg->model_channels <= 0 || cfg->model_channels % 16 || cfg->channel_mult_noise < 1 || cfg->channel_mult_emb < 1)
+        return fail(FG_EINVAL, "bad channel configuration");
+    fg_edm* h = new fg_edm();
+    h->cfg = *cfg;
+    h->dtype = cfg->compute_dtype;
+    h->emb_ch = cfg->model_channels * cfg->channel_mult_emb;
+    h->noise_ch = cfg->model_channels * cfg->channel_mult_noise;
+    build_layout(h);
+    int rc = check_supported(h);
+    if (rc) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return FG_OK;
+}
+
+void fg_edm_destroy(fg_edm* h) {
+    if (!h) return;
+    drop_graph(h);
+    for (void* p : h->owned) (void)hipFree(p);
+    if (h->tl_pinned) (void)hipHostFree(h->tl_pinned);
+    if (h->seed_pinned) (void)hipHostFree(h->seed_pinned);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    delete h;
+}
+
+int fg_edm_num_params(const fg_edm* h) { return h ? (int)h->params.size() : 0; }
+
+int fg_edm_param_info(const fg_edm* h, int index, const char** name, int* ndim, int64_t shape[4]) {
+    if (!h || index < 0 || index >= (int)h->params.size()) return fail(FG_EINVAL, "param index out of range");
+    const Param& p = h->params[index];
+    if (name) *name = p.name.c_str();
+    if (ndim) *ndim = p.ndim;
+    if (shape)
+        for (int i = 0; i < 4; ++i) shape[i] = p.shape[i];
+    return FG_OK;
+}
+
+int fg_edm_bind_param(fg_edm* h, const char* name, const float* device_ptr, int64_t numel) {
+    if (!h || !name || !device_ptr) return fail(FG_EINVAL, "null argument");
+    const int i = h->find(name);
+    if (i < 0) return fail(FG_EINVAL, "unknown parameter '%s'", name);
+    if (h->params[i].numel != numel)
+        return fail(FG_EINVAL, "parameter '%s': expected %lld elements, got %lld", name, (long long)h->params[i].numel, (long long)numel);
+    h->params[i].ptr = device_ptr;
+    h->packed = false;
+    return FG_OK;
+}
+
+int fg_edm_pack_weights(fg_edm* h, void* stream) {
+    if (!h) return fail(FG_EINVAL, "null handle");
+    hipStream_t s = (hipStream_t)stream;
+    int rc0 = ensure_device_state(h);
+    if (rc0) return rc0;
+    for (const Param& p : h->params) {
+        const bool unused = p.name == "model.map_augment.weight" || p.name.rfind("model.logvar_linear", 0) == 0;
+        if (!p.ptr && !unused) return fail(FG_ENOTREADY, "parameter '%s' is not bound", p.name.c_str());
+    }
+    for (Block* b : h->blocks) {
+        HIP_TRY(launch_pack_conv_weights(h->dtype, h->P(b->conv0_w), b->p_conv0, b->cout, b->cin, 3, 0, s));
+        HIP_TRY(launch_pack_conv_weights(h->dtype, h->P(b->conv1_w), b->p_conv1, b->cout, b->cout, 3, 0, s));
+        if (b->has_skip) HIP_TRY(launch_pack_conv_weights(h->dtype, h->P(b->skip_w), b->p_skip, b->cout, b->cin, 1, 0, s));
+        if (b->attn) {
+            HIP_TRY(launch_pack_conv_weights(h->dtype, h->P(b->qkv_w), b->p_qkv, 3 * b->cout, b->cout, 1, 1, s));
+            HIP_TRY(launch_pack_conv_weights(h->dtype, h->P(b->proj_w), b->p_proj, b->cout, b->cout, 1, 0, s));
+            // bias o' = plane*C + c  <-  reference channel c*3 + plane: three strided 2-D copies
+            for (int plane = 0; plane < 3; ++plane)
+                HIP_TRY(hipMemcpy2DAsync(b->qkv_bias + plane * b->cout, sizeof(float), h->P(b->qkv_b) + plane,
+                                         3 * sizeof(float), sizeof(float), b->cout, hipMemcpyDeviceToDevice, s));
+        }
+        HIP_TRY(hipMemcpyAsync(h->aff_w + (size_t)b->temb_off * h->emb_ch, h->P(b->aff_w),
+                               sizeof(float) * (size_t)b->cout * h->emb_ch, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(h->aff_b + b->temb_off, h->P(b->aff_b), sizeof(float) * b->cout, hipMemcpyDeviceToDevice, s));
+    }
+    drop_graph(h);
+    h->packed = true;
+    return FG_OK;
+}
+
+size_t fg_edm_workspace_bytes(const fg_edm* h, int batch) {
+    if (!h || batch <= 0) return 0;
+    Arena A;
+    A.dry = true;
+    Workspace w;
+    return plan_workspace(h, batch, A, w);
+}
+
+int fg_edm_forward(fg_edm* h, const float* x_t, const double* t, const float* class_labels, float* out, float* emb_out,
+                   int batch, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !x_t || !t || !out) return fail(FG_EINVAL, "null argument");
+    if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
+    if (out == x_t) return fail(FG_EINVAL, "out must not alias x_t");
+    Workspace w;
+    int rc = setup_ws(h, batch, workspace, workspace_bytes, w);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    rc = run_forward(h, x_t, t, 1, class_labels, out, batch, w, s);
+    if (rc) return rc;
+    if (emb_out) HIP_TRY(hipMemcpyAsync(emb_out, w.emb, sizeof(float) * (size_t)batch * h->emb_ch, hipMemcpyDeviceToDevice, s));
+    return FG_OK;
+}
+
+int fg_edm_t_list(int sample_steps, double* out_host) {
+    if (sample_steps < 1 || sample_steps > 64 || !out_host) return fail(FG_EINVAL, "bad sample_steps");
+    // EDMNoiseSchedule: sigma table (noise_schedule.py:752-756) and get_t_list (:940-973), all in fp64
+    const int num_steps = 1000;
+    const double min_t = 0.002, max_t = 80.0, rho = 7.0;
+    const double a = std::pow(min_t, 1.0 / rho), b = std::pow(max_t, 1.0 / rho);
+    const int lo = (int)(0.002 * num_steps), hi = (int)(0.998 * num_steps);
+    for (int i = 0; i <= sample_steps; ++i) {
+        // torch.linspace(hi, lo, n+1) in fp32 then .long(): symmetric evaluation as ATen does (first half from start,
+        // second half from end)
+        const int n = sample_steps + 1;
+        const float step = ((float)lo - (float)hi) / (float)(n - 1);
+        const float v = (i < n / 2) ? (float)hi + step * (float)i : (float)lo - step * (float)(n - 1 - i);
+        const int idx = (int)v;
+        // sigmas = flip((b + ramp*(a-b))^rho), ramp = linspace(0,1,1000) in fp64 (same symmetric evaluation)
+        const int j = num_steps - 1 - idx;
+        const double dstep = 1.0 / (double)(num_steps - 1);
+        const double ramp = (j < num_steps / 2) ? dstep * j : 1.0 - dstep * (double)(num_steps - 1 - j);
+        double sig = std::pow(b + ramp * (a - b), rho);
+        if (i == sample_steps) sig = 0.0;
+        out_host[i] = sig > max_t ? max_t : sig;
+    }
+    return FG_OK;
+}
+
+int fg_sampler_run(fg_edm* h, const float* noise, const float* class_labels, const double* t_list, int steps,
+                   int sample_type, const float* eps, uint64_t seed, float* out, int batch, void* workspace,
+                   size_t workspace_bytes, int use_graph, void* stream) {
+    if (!h || !noise || !t_list || !out) return fail(FG_EINVAL, "null argument");
+    if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
+    if (steps < 1 || steps > 64) return fail(FG_EINVAL, "steps must be in [1, 64]");
+    if (sample_type != FG_SAMPLE_SDE && sample_type != FG_SAMPLE_ODE) return fail(FG_EINVAL, "bad sample_type");
+    if (t_list[steps] != 0.0) return fail(FG_EINVAL, "t_list[-1] must be zero");  // methods/model.py:410
+    for (int i = 0; i < steps; ++i)
+        if (!(t_list[i] >= 0.002 * (1 - 1e-12) && t_list[i] <= 80.0 * (1 + 1e-12)))  // is_t_valid, noise_schedule.py:409-423
+            return fail(FG_EINVAL, "t_list[%d] = %g outside [0.002, 80]", i, t_list[i]);
+    Workspace w;
+    int rc = setup_ws(h, batch, workspace, workspace_bytes, w);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i <= steps; ++i) h->tl_pinned[i] = t_list[i];
+    h->seed_pinned[0] = seed;
+    h->seed_pinned[1] = 0;
+    if (!use_graph) return enqueue_sampler(h, noise, class_labels, t_list, steps, sample_type, eps, out, batch, w, s);
+
+    GraphKey key;
+    key.B = batch; key.steps = steps; key.type = sample_type;
+    for (int i = 1; i <= steps; ++i)
+        if (t_list[i] > 0) key.zero_mask |= (1ull << i);
+    key.noise = noise; key.labels = class_labels; key.eps = eps; key.out = out; key.ws = workspace;
+    key.device_rng = (sample_type == FG_SAMPLE_SDE && !eps);
+    if (!h->graph_exec || !(h->graph_key == key)) {
+        drop_graph(h);
+        if (!h->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+        hipStream_t cs = h->cap_stream;  // capture records, it does not execute: the graph is launched on `s` below
+        HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        rc = enqueue_sampler(h, noise, class_labels, t_list, steps, sample_type, eps, out, batch, w, cs);
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(cs, &g);
+        if (rc) {
+            if (g) (void)hipGraphDestroy(g);
+            return rc;
+        }
+        if (e != hipSuccess) return fail(FG_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        h->graph = g;
+        HIP_TRY(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+        h->graph_key = key;
+    }
+    HIP_TRY(hipGraphLaunch(h->graph_exec, s));
+    return FG_OK;
+}
+
+int fg_edm_num_blocks(const fg_edm* h) { return h ? (int)h->blocks.size() : 0; }
+
+int fg_edm_block_info(const fg_edm* h, int index, const char** key, int* cin, int* cout, int* res_in, int* res_out,
+                      int* has_attention) {
+    if (!h || index < 0 || index >= (int)h->blocks.size()) return fail(FG_EINVAL, "block index out of range");
+    const Block* b = h->blocks[index];
+    if (key) *key = b->key.c_str();
+    if (cin) *cin = b->cin;
+    if (cout) *cout = b->cout;
+    if (res_in) *res_in = b->res_in;
+    if (res_out) *res_out = b->res_out;
+    if (has_attention) *has_attention = b->attn ? 1 : 0;
+    return FG_OK;
+}
+
+int fg_edm_run_block(fg_edm* h, int index, const float* x1, int c1, const float* x2, int c2, const float* emb, float* out,
+                     int batch, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !x1 || !emb || !out) return fail(FG_EINVAL, "null argument");
+    if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
+    if (index < 0 || index >= (int)h->blocks.size()) return fail(FG_EINVAL, "block index out of range");
+    Workspace w;
+    int rc = setup_ws(h, batch, workspace, workspace_bytes, w);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(launch_linear(emb, h->aff_w, h->aff_b, w.temb, batch, h->emb_ch, h->temb_total, 0, s));
+    return run_block(h, *h->blocks[index], x1, c1, c2 ? x2 : nullptr, c2, w.temb, out, batch, w, s);
+}
+
+int fg_op_gn_coeffs(const float* x1, int c1, const float* x2, int c2, const float* gamma, const float* beta, float eps,
+                    float* ab_out, int batch, int hw, void* stream) {
+    if (!x1 || !gamma || !beta || !ab_out) return fail(FG_EINVAL, "null argument");
+    HIP_TRY(launch_gn_coeffs(x1, c1, c2 ? x2 : nullptr, c2, gamma, beta, eps, (float2*)ab_out, batch, hw, (hipStream_t)stream));
+    return FG_OK;
+}
+int fg_op_latents(const float* noise, double t_init, float* out, int64_t total, void* stream) {
+    HIP_TRY(launch_latents(noise, t_init, nullptr, 0, out, total, (hipStream_t)stream));
+    return FG_OK;
+}
+int fg_op_forward_process(const float* x0, const float* eps, double t, float* out, int64_t total, void* stream) {
+    HIP_TRY(launch_forward_process(x0, eps, t, nullptr, 0, out, total, (hipStream_t)stream));
+    return FG_OK;
+}
+int fg_op_x0_to_eps(const float* xt, const float* x0, double t, float* out, int64_t total, void* stream) {
+    HIP_TRY(launch_x0_to_eps(xt, x0, t, nullptr, 0, 1e-6, out, total, (hipStream_t)stream));
+    return FG_OK;
+}
+int fg_op_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, void* stream) {
+    HIP_TRY(launch_randn(out, total, seed, offset, nullptr, (hipStream_t)stream));
+    return FG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,415 @@
+// Small kernels around the fused conv: GroupNorm statistics, embedding MLP, stem / output convolutions with the EDM
+// preconditioning folded in, the sampler's elementwise steps and the on-device normal generator.
+// Reference line numbers are relative to fastgen/networks/EDM/network.py unless another file is named.
+#include "common.h"
+#include "misc.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm statistics -> per-(image, channel) affine coefficients  y = a*x + b
+//   a = rstd * gamma,  b = beta - mean * a      (GroupNorm.forward :141-149; groups = min(32, C/4), biased variance)
+// x is the virtual concat [x1 (C1) | x2 (C2)], NHWC.  One workgroup per image; a thread owns one channel quad.
+// HBM-bound: reads the tensor once with 16-byte loads.
+__global__ __launch_bounds__(512) void gn_coeffs_kernel(const float* __restrict__ x1, int C1, const float* __restrict__ x2,
+                                                        int C2, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, float2* __restrict__ ab,
+                                                        int hw) {
+    const int C = C1 + C2;
+    const int Q = C >> 2;                 // channel quads per pixel
+    const int lanes = blockDim.x / Q;     // pixel lanes
+    const int groups = min(32, C / 4);
+    const int cpg = C / groups;
+    const int n = blockIdx.x;
+    const int t = threadIdx.x;
+    __shared__ double s_sum[512], s_sq[512];
+    __shared__ float s_mean[32], s_rstd[32];
+    float s = 0.f, ss = 0.f;
+    if (t < Q * lanes) {
+        const int q = t % Q, pl = t / Q;
+        const int c = q * 4;
+        const float* base = (c < C1) ? x1 + (size_t)n * hw * C1 + c : x2 + (size_t)n * hw * C2 + (c - C1);
+        const int stride = (c < C1) ? C1 : C2;
+        // fp32 partials over <= hw/lanes pixels, four independent chains per thread; combined in fp64 below
+        for (int p = pl; p < hw; p += lanes) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * stride);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+            ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+    }
+    s_sum[t] = s;
+    s_sq[t] = ss;
+    __syncthreads();
+    if (t < groups) {
+        // quads of group t: [t*cpg/4, (t+1)*cpg/4) x all pixel lanes (cpg is a multiple of 4)
+        double a = 0.0, b = 0.0;
+        const int q0 = t * cpg / 4, q1 = (t + 1) * cpg / 4;
+        for (int pl = 0; pl < lanes; ++pl)
+            for (int q = q0; q < q1; ++q) {
+                a += s_sum[pl * Q + q];
+                b += s_sq[pl * Q + q];
+            }
+        const double cnt = (double)cpg * hw;
+        const double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[t] = (float)mean;
+        s_rstd[t] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        const float a = s_rstd[g] * gamma[c];
+        ab[(size_t)n * C + c] = make_float2(a, fmaf(-a, s_mean[g], beta[c]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// EDM preconditioning coefficients in fp64 (precond_input :755-778, precond_output :781-805), cast to fp32 exactly
+// where the reference casts (`.to(x_t.dtype)`).  coef[4][B] = c_in, c_noise, c_skip, c_out.
+__global__ void precond_coef_kernel(const double* __restrict__ t, int t_stride, double sigma_data, double sigma_shift,
+                                    double clamp_min, float* __restrict__ coef, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double tv = t[(size_t)b * t_stride];
+    const double sd2 = sigma_data * sigma_data;
+    coef[b] = (float)(1.0 / sqrt(sd2 + tv * tv));
+    coef[B + b] = (float)(log(fmax(tv, clamp_min)) / 4.0);
+    const double ts = tv - sigma_shift;
+    coef[2 * B + b] = (float)(sd2 / (ts * ts + sd2));
+    coef[3 * B + b] = (float)(ts * sigma_data / sqrt(ts * ts + sd2));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Mapping-network input: positional embedding of c_noise (sin|cos after the flip at :503) + map_label(labels*sqrt(L))
+// (:306-319, :501-517).  out [B][N].
+__global__ void mapping_in_kernel(const float* __restrict__ c_noise, const float* __restrict__ freqs,
+                                  const float* __restrict__ labels, int label_dim, const float* __restrict__ wl,
+                                  const float* __restrict__ bl, float* __restrict__ out, int B, int N) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * N) return;
+    const int b = idx / N, j = idx % N;
+    const int half = N / 2;
+    const float ang = c_noise[b] * freqs[j % half];
+    float v = (j < half) ? sinf(ang) : cosf(ang);
+    if (label_dim > 0) {
+        float acc = 0.f;
+        const float sc = sqrtf((float)label_dim);
+        if (labels)
+            for (int i = 0; i < label_dim; ++i) acc = fmaf(labels[(size_t)b * label_dim + i] * sc, wl[(size_t)j * label_dim + i], acc);
+        v += acc + bl[j];
+    }
+    out[idx] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// y[B,O] = act(x[B,I] @ W[O,I]^T + bias)   (Linear.forward :47-51), fp32 FMA, 64x64 tile, 4x4 per thread.
+template <int ACT>
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ y, int B, int I,
+                                                     int O) {
+    __shared__ float xs[16][65], ws[16][65];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int b0 = blockIdx.y * 64, o0 = blockIdx.x * 64;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < I; k0 += 16) {
+        for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+            const int rr = e >> 4, kk = e & 15;
+            xs[kk][rr] = (b0 + rr < B && k0 + kk < I) ? x[(size_t)(b0 + rr) * I + k0 + kk] : 0.f;
+            ws[kk][rr] = (o0 + rr < O && k0 + kk < I) ? w[(size_t)(o0 + rr) * I + k0 + kk] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float xv[4], wv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xv[i] = xs[kk][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wv[j] = ws[kk][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(xv[i], wv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int b = b0 + ty * 4 + i, o = o0 + tx * 4 + j;
+            if (b < B && o < O) {
+                float v = acc[i][j] + (bias ? bias[o] : 0.f);
+                if (ACT == 1) v = v / (1.0f + expf(-v));
+                y[(size_t)b * O + o] = v;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Stem: out[n,y,x,co] = conv3x3(c_in[n] * x_t)[co] + bias   (precond_input :771-773 folded into enc '{res}x{res}_conv',
+// :426).  x_t is NCHW fp32, out NHWC fp32.  One workgroup per image row; memory-bound on the output write.
+__global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ c_in,
+                                                      const float* __restrict__ w, const float* __restrict__ bias,
+                                                      float* __restrict__ out, int res, int cin, int cout) {
+    extern __shared__ float sw[];  // [cin*9][cout]
+    const int n = blockIdx.x / res, y = blockIdx.x % res;
+    const int K = cin * 9;
+    for (int e = threadIdx.x; e < K * cout; e += blockDim.x) {
+        const int co = e % cout, k = e / cout;
+        sw[e] = w[(size_t)co * K + k];  // OIHW: k = ci*9 + kh*3 + kw
+    }
+    __syncthreads();
+    const float ci_scale = c_in[n];
+    const int per_px = cout / 16;  // threads per pixel, 16 output channels each
+    for (int item = threadIdx.x; item < res * per_px; item += blockDim.x) {
+        const int px = item / per_px, cg = item % per_px;
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        for (int ci = 0; ci < cin; ++ci)
+            for (int kh = 0; kh < 3; ++kh) {
+                const int yy = y + kh - 1;
+                if (yy < 0 || yy >= res) continue;
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int xx = px + kw - 1;
+                    if (xx < 0 || xx >= res) continue;
+                    const float v = ci_scale * x[(((size_t)n * cin + ci) * res + yy) * res + xx];
+                    const float* wr = sw + (size_t)(ci * 9 + kh * 3 + kw) * cout + cg * 16;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+                }
+            }
+        float* o = out + (((size_t)n * res + y) * res + px) * cout + cg * 16;
+#pragma unroll
+        for (int j = 0; j < 16; j += 4)
+            *reinterpret_cast<f32x4*>(o + j) = f32x4{acc[j] + bias[cg * 16 + j], acc[j + 1] + bias[cg * 16 + j + 1],
+                                                     acc[j + 2] + bias[cg * 16 + j + 2], acc[j + 3] + bias[cg * 16 + j + 3]};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Output head: F = aux_conv(silu(aux_norm(x)))  (:553-557) and D = c_skip * x_t + c_out * F  (precond_output :798-805)
+// x NHWC [B,res,res,C] fp32, ab = aux_norm coefficients, w OIHW [cout(<=4)][C][3][3]; x_t / out NCHW.
+// One workgroup per image row: thread = (pixel, 1/8 channel slice); the slices meet in a wave shuffle.
+template <bool FAST>
+__global__ __launch_bounds__(256) void aux_out_kernel(const float* __restrict__ x, const float2* __restrict__ ab,
+                                                      const float* __restrict__ w, const float* __restrict__ bias,
+                                                      const float* __restrict__ x_t, const float* __restrict__ coef,
+                                                      float* __restrict__ out, int B, int res, int C, int cout) {
+    extern __shared__ float smem_f[];
+    float* sw = smem_f;                                               // [9][cout][C]
+    float2* sab = reinterpret_cast<float2*>(smem_f + 9 * cout * C);   // [C]
+    const int n = blockIdx.x / res, y = blockIdx.x % res;
+    for (int e = threadIdx.x; e < 9 * cout * C; e += blockDim.x) {
+        const int c = e % C, co = (e / C) % cout, tap = e / (C * cout);
+        sw[e] = w[((size_t)co * C + c) * 9 + tap];
+    }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) sab[c] = ab[(size_t)n * C + c];
+    __syncthreads();
+    const int slice = C / 8;
+    for (int px0 = 0; px0 < res; px0 += 32) {
+        const int px = px0 + (threadIdx.x >> 3), cs = threadIdx.x & 7;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (px < res) {
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = px + tap % 3 - 1;
+                if (yy < 0 || yy >= res || xx < 0 || xx >= res) continue;
+                const float* xp = x + (((size_t)n * res + yy) * res + xx) * C + cs * slice;
+                for (int c = 0; c < slice; c += 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(xp + c);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const float2 k = sab[cs * slice + c + d];
+                        const float s = silu_f<FAST>(fmaf(v[d], k.x, k.y));
+                        for (int co = 0; co < cout; ++co)
+                            acc[co] = fmaf(s, sw[(tap * cout + co) * C + cs * slice + c + d], acc[co]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < 4; ++co) {
+            acc[co] += __shfl_xor(acc[co], 1);
+            acc[co] += __shfl_xor(acc[co], 2);
+            acc[co] += __shfl_xor(acc[co], 4);
+        }
+        if (cs == 0 && px < res) {
+            const float c_skip = coef[2 * B + n], c_out = coef[3 * B + n];
+            for (int co = 0; co < cout; ++co) {
+                const size_t o = (((size_t)n * cout + co) * res + y) * res + px;
+                out[o] = c_skip * x_t[o] + c_out * (acc[co] + bias[co]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Sampler elementwise steps, fp64 arithmetic then one rounding to fp32 (noise_schedule.py:72-88, 425-449, 544-574).
+// t comes from device memory (tp[ti]) when tp != nullptr so a captured graph can be replayed with new timesteps.
+__device__ __forceinline__ double pick_t(double tv, const double* tp, int ti) { return tp ? tp[ti] : tv; }
+
+__global__ void latents_kernel(const float* __restrict__ noise, double tv, const double* tp, int ti,
+                               float* __restrict__ out, int64_t total) {
+    const double t = pick_t(tv, tp, ti);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (float)((double)noise[i] * t);
+}
+__global__ void forward_process_kernel(const float* __restrict__ x0, const float* __restrict__ eps, double tv,
+                                       const double* tp, int ti, float* __restrict__ out, int64_t total) {
+    const double t = pick_t(tv, tp, ti);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (float)((double)x0[i] * 1.0 + (double)eps[i] * t);  // alpha(t) = 1, sigma(t) = t (EDM, :773-777)
+}
+__global__ void x0_to_eps_kernel(const float* __restrict__ xt, const float* __restrict__ x0, double tv, const double* tp,
+                                 int ti, double clamp_min, float* __restrict__ out, int64_t total) {
+    double t = pick_t(tv, tp, ti);
+    t = (t >= 0.0) ? fmax(t, clamp_min) : fmin(t, -clamp_min);  // non_zero_clamp, noise_schedule.py:123-129
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (float)(((double)xt[i] - (double)x0[i] * 1.0) / t);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller: out[4c..4c+3] from counter (c, offset) and key = seed.  The seed/offset pair is read
+// from device memory when sp != nullptr (graph replay with a fresh seed).
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1;
+    c[3] = (uint32_t)p0;
+    c[0] = n0;
+    c[2] = n2;
+}
+__global__ void randn_kernel(float* __restrict__ out, int64_t total, uint64_t seed_v, uint64_t offset_v,
+                             const uint64_t* sp) {
+    const uint64_t seed = sp ? sp[0] : seed_v;
+    const uint64_t offset = sp ? sp[1] + offset_v : offset_v;
+    const int64_t nquad = (total + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t c[4] = {(uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int rnd = 0; rnd < 10; ++rnd) {
+            philox_round(c, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        float z[4];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float u1 = ((float)c[2 * p] + 0.5f) * 2.3283064365386963e-10f;      // (0,1]
+            const float u2 = ((float)c[2 * p + 1] + 0.5f) * 2.3283064365386963e-10f;
+            const float rad = sqrtf(-2.0f * logf(fmaxf(u1, 1e-37f)));
+            float sn, cs;
+            sincosf(6.283185307179586f * u2, &sn, &cs);
+            z[2 * p] = rad * cs;
+            z[2 * p + 1] = rad * sn;
+        }
+        for (int d = 0; d < 4; ++d)
+            if (4 * q + d < total) out[4 * q + d] = z[d];
+    }
+}
+
+// copy + layout helpers
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int HW) {
+    const int64_t total = (int64_t)B * C * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = i % C;
+        const int64_t t = i / C;
+        const int p = t % HW;
+        const int n = t / HW;
+        out[i] = in[((int64_t)n * C + c) * HW + p];
+    }
+}
+
+inline int ew_grid(int64_t total) {
+    int64_t g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+#define RET_LAST() return (int)hipGetLastError()
+
+int launch_gn_coeffs(const float* x1, int c1, const float* x2, int c2, const float* gamma, const float* beta, float eps,
+                     float2* ab, int batch, int hw, hipStream_t s) {
+    const int C = c1 + c2;
+    if (C % 4 || (c1 % 4) || C < 16 || C > 2048) return (int)hipErrorInvalidValue;
+    const int groups = C / 4 < 32 ? C / 4 : 32;
+    if (C % groups || (C / groups) % 4) return (int)hipErrorInvalidValue;
+    const int Q = C / 4;
+    if (Q > 512) return (int)hipErrorInvalidValue;
+    const int threads = (512 / Q) * Q;
+    hipLaunchKernelGGL(gn_coeffs_kernel, dim3(batch), dim3(threads), 0, s, x1, c1, x2, c2, gamma, beta, eps, ab, hw);
+    RET_LAST();
+}
+
+int launch_precond_coef(const double* t, int t_stride, double sigma_data, double sigma_shift, double clamp_min,
+                        float* coef, int B, hipStream_t s) {
+    hipLaunchKernelGGL(precond_coef_kernel, dim3((B + 127) / 128), dim3(128), 0, s, t, t_stride, sigma_data, sigma_shift,
+                       clamp_min, coef, B);
+    RET_LAST();
+}
+
+int launch_mapping_in(const float* c_noise, const float* freqs, const float* labels, int label_dim, const float* wl,
+                      const float* bl, float* out, int B, int N, hipStream_t s) {
+    hipLaunchKernelGGL(mapping_in_kernel, dim3((B * N + 255) / 256), dim3(256), 0, s, c_noise, freqs, labels, label_dim, wl,
+                       bl, out, B, N);
+    RET_LAST();
+}
+
+int launch_linear(const float* x, const float* w, const float* bias, float* y, int B, int I, int O, int act_silu,
+                  hipStream_t s) {
+    dim3 grid((O + 63) / 64, (B + 63) / 64);
+    if (act_silu)
+        hipLaunchKernelGGL(linear_kernel<1>, grid, dim3(256), 0, s, x, w, bias, y, B, I, O);
+    else
+        hipLaunchKernelGGL(linear_kernel<0>, grid, dim3(256), 0, s, x, w, bias, y, B, I, O);
+    RET_LAST();
+}
+
+int launch_conv_in(const float* x, const float* c_in, const float* w, const float* bias, float* out, int B, int res,
+                   int cin, int cout, hipStream_t s) {
+    if (cout % 16) return (int)hipErrorInvalidValue;
+    const size_t lds = (size_t)cin * 9 * cout * sizeof(float);
+    if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(conv_in_kernel, dim3(B * res), dim3(256), lds, s, x, c_in, w, bias, out, res, cin, cout);
+    RET_LAST();
+}
+
+int launch_aux_out(int fast, const float* x, const float2* ab, const float* w, const float* bias, const float* x_t,
+                   const float* coef, float* out, int B, int res, int C, int cout, hipStream_t s) {
+    if (cout > 4 || C % 32) return (int)hipErrorInvalidValue;
+    const size_t lds = (size_t)9 * cout * C * sizeof(float) + (size_t)C * sizeof(float2);
+    if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
+    if (fast)
+        hipLaunchKernelGGL(aux_out_kernel<true>, dim3(B * res), dim3(256), lds, s, x, ab, w, bias, x_t, coef, out, B, res, C, cout);
+    else
+        hipLaunchKernelGGL(aux_out_kernel<false>, dim3(B * res), dim3(256), lds, s, x, ab, w, bias, x_t, coef, out, B, res, C, cout);
+    RET_LAST();
+}
+
+int launch_latents(const float* noise, double tv, const double* tp, int ti, float* out, int64_t total, hipStream_t s) {
+    hipLaunchKernelGGL(latents_kernel, dim3(ew_grid(total)), dim3(256), 0, s, noise, tv, tp, ti, out, total);
+    RET_LAST();
+}
+int launch_forward_process(const float* x0, const float* eps, double tv, const double* tp, int ti, float* out,
+                           int64_t total, hipStream_t s) {
+    hipLaunchKernelGGL(forward_process_kernel, dim3(ew_grid(total)), dim3(256), 0, s, x0, eps, tv, tp, ti, out, total);
+    RET_LAST();
+}
+int launch_x0_to_eps(const float* xt, const float* x0, double tv, const double* tp, int ti, double clamp_min, float* out,
+                     int64_t total, hipStream_t s) {
+    hipLaunchKernelGGL(x0_to_eps_kernel, dim3(ew_grid(total)), dim3(256), 0, s, xt, x0, tv, tp, ti, clamp_min, out, total);
+    RET_LAST();
+}
+int launch_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, const uint64_t* seed_dev, hipStream_t s) {
+    hipLaunchKernelGGL(randn_kernel, dim3(ew_grid((total + 3) / 4)), dim3(256), 0, s, out, total, seed, offset, seed_dev);
+    RET_LAST();
+}
+int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, hipStream_t s) {
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid((int64_t)B * C * HW)), dim3(256), 0, s, in, out, B, C, HW);
+    RET_LAST();
+}

@@ -1,0 +1,382 @@
+"""`EDMPrecond` drop-in for the reference's `fastgen.networks.EDM.network.EDMPrecond` (SongUNet / DDPM++ variant,
+reference EDM/network.py:808-1026), backed by libfastgen_amd.so.
+
+Select it by pointing a config's `net._target_` at `fastgen_amd.networks.EDM.network.EDMPrecond` (the reference's
+`instantiate`, fastgen/utils/__init__.py:53-98, calls `cls(**kwargs)` with the kwargs of EDM_CIFAR10_Config,
+fastgen/configs/net.py:29-48).  What is kept identical to the reference:
+  * constructor kwargs, `forward(x_t, t, condition, r, return_features_early, feature_indices, return_logvar,
+    fwd_pred_type)` semantics, `.noise_scheduler`, `.net_pred_type`, `.schedule_type`, `.label_dim`, `.sample()`,
+    `.fully_shard()`, `.reset_parameters()`;
+  * `state_dict()` — 429 entries with the reference's key names and OIHW shapes (Checkpointer.load uses
+    strict=False, so a wrong name would be skipped silently, utils/checkpointer.py:155-161).
+Parameters are ordinary fp32 `nn.Parameter`s; the library borrows their device pointers and keeps MFMA-order
+copies of the conv weights that are rebuilt whenever a parameter's storage or version changes.
+
+Not provided on this path (raises, never falls back): training backward, feature taps, `r` timestep, non-SongUNet
+model types, and any device but a HIP GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+from typing import Any, Dict, List, Optional, Set
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from fastgen_amd import _lib
+from fastgen_amd.networks.network import FastGenNetwork
+from fastgen_amd.networks.noise_schedule import NET_PRED_TYPES, expand_like
+
+
+class _Node(nn.Module):
+    """Bare container: the parameter tree only has to reproduce the reference's state-dict key paths."""
+
+
+def _xavier_uniform(shape, fan_in, fan_out):
+    return math.sqrt(6 / (fan_in + fan_out)) * (torch.rand(*shape) * 2 - 1)
+
+
+def _init_value(name: str, shape) -> torch.Tensor:
+    """Same distributions as the reference's constructors (EDM/network.py:22-31, 378-380, 487): xavier-uniform
+    matrices, zero biases, unit norm gains; conv1 / proj / aux_conv scaled by 1e-5, qkv by sqrt(0.2)."""
+    leaf = name.rsplit(".", 2)[-2]
+    if name.endswith(".bias"):
+        return torch.zeros(shape)
+    if "norm" in leaf:
+        return torch.ones(shape)
+    fan_in = int(np.prod(shape[1:]))
+    fan_out = shape[0] * int(np.prod(shape[2:])) if len(shape) > 2 else shape[0]
+    if leaf == "logvar_linear":
+        return math.sqrt(1 / fan_in) * torch.randn(*shape)
+    w = _xavier_uniform(shape, fan_in, fan_out)
+    if leaf in ("conv1", "proj") or leaf.endswith("aux_conv"):
+        w = w * 1e-5
+    elif leaf == "qkv":
+        w = w * math.sqrt(0.2)
+    return w
+
+
+class EDMPrecond(FastGenNetwork):
+    def __init__(
+        self,
+        img_resolution,
+        img_channels,
+        label_dim=0,
+        sigma_data=0.5,
+        sigma_shift=0.0,
+        model_type="DhariwalUNet",
+        drop_precond=None,
+        net_pred_type="x0",
+        schedule_type="edm",
+        compute_dtype: Optional[str] = None,  # extension: "fp32" | "bf16" | None (= follow torch.autocast)
+        **model_kwargs,
+    ):
+        super().__init__(net_pred_type=net_pred_type, schedule_type=schedule_type, **model_kwargs)
+        if model_type != "SongUNet":
+            raise ValueError(f"fastgen_amd implements model_type='SongUNet' only, got '{model_type}'")
+        if drop_precond is not None:
+            if drop_precond not in ["input", "output", "both"]:
+                raise ValueError(f"drop_precond must be one of 'input', 'output', 'both', or None, got {drop_precond}")
+            raise NotImplementedError("drop_precond is not implemented by the fused MI355X path")
+        mk = dict(model_kwargs)
+        unsupported = {
+            "embedding_type": "positional", "encoder_type": "standard", "decoder_type": "standard",
+            "r_timestep": False, "label_dropout": 0,
+        }
+        for k, want in unsupported.items():
+            if mk.get(k, want) != want:
+                raise NotImplementedError(f"{k}={mk[k]!r} is not implemented by the fused MI355X path (only {want!r})")
+        if list(mk.get("resample_filter", [1, 1])) != [1, 1]:
+            raise NotImplementedError("resample_filter other than [1, 1] is not implemented")
+        self.img_resolution = img_resolution
+        self.img_channels = img_channels
+        self.label_dim = label_dim
+        self.sigma_data = sigma_data
+        self.sigma_shift = sigma_shift
+        self.drop_precond = drop_precond
+        self.dropout = mk.get("dropout", 0.10)
+        self.compute_dtype = compute_dtype or os.environ.get("FASTGEN_AMD_COMPUTE_DTYPE") or None
+        if self.compute_dtype not in (None, "fp32", "bf16"):
+            raise ValueError(f"compute_dtype must be 'fp32', 'bf16' or None, got {self.compute_dtype!r}")
+
+        cfg = _lib.fg_edm_config()
+        cfg.img_resolution, cfg.img_channels, cfg.label_dim = img_resolution, img_channels, label_dim
+        cfg.augment_dim = mk.get("augment_dim", 0)
+        cfg.model_channels = mk.get("model_channels", 128)
+        mult = list(mk.get("channel_mult", [1, 2, 2, 2]))
+        attn = list(mk.get("attn_resolutions", [16]))
+        if len(mult) > _lib.FG_MAX_LEVELS or len(attn) > _lib.FG_MAX_LEVELS:
+            raise ValueError("too many resolution levels")
+        cfg.num_levels = len(mult)
+        for i, m in enumerate(mult):
+            cfg.channel_mult[i] = m
+        cfg.channel_mult_emb = mk.get("channel_mult_emb", 4)
+        cfg.num_blocks = mk.get("num_blocks", 4)
+        cfg.num_attn_resolutions = len(attn)
+        for i, a in enumerate(attn):
+            cfg.attn_resolutions[i] = a
+        cfg.channel_mult_noise = mk.get("channel_mult_noise", 1)
+        cfg.sigma_data, cfg.sigma_shift = float(sigma_data), float(sigma_shift)
+        self._cfg = cfg
+        self._engines: Dict[int, ctypes.c_void_p] = {}
+        self._bound_sig: Dict[int, Any] = {}
+        self._pack_refs: Dict[int, list] = {}
+        self._ws: Dict[int, torch.Tensor] = {}
+        self._noise_channels = cfg.model_channels * cfg.channel_mult_noise
+
+        # parameter tree with the reference's key paths; names/shapes come from the library's own plan
+        self.model = _Node()
+        self._param_names: List[str] = []
+        h = self._make_engine(_lib.FG_DTYPE_F32)
+        L = _lib.lib()
+        name, ndim, shape = ctypes.c_char_p(), ctypes.c_int(), (ctypes.c_int64 * 4)()
+        for i in range(L.fg_edm_num_params(h)):
+            _lib.check(L.fg_edm_param_info(h, i, ctypes.byref(name), ctypes.byref(ndim), shape))
+            full = name.value.decode()
+            shp = tuple(shape[j] for j in range(ndim.value))
+            self._param_names.append(full)
+            node, parts = self, full.split(".")
+            for p in parts[:-1]:
+                if p not in node._modules:
+                    node.add_module(p, _Node())
+                node = node._modules[p]
+            node.register_parameter(parts[-1], nn.Parameter(_init_value(full, shp)))
+            # the reference keeps the constant 2x2 resampling kernel as a persistent buffer (EDM/network.py:89-91)
+            if parts[-1] == "weight" and parts[-2] in ("conv0", "skip") and (parts[-3].endswith("_down") or parts[-3].endswith("_up")):
+                node.register_buffer("resample_filter", torch.full((1, 1, 2, 2), 0.25))
+        self._engines[_lib.FG_DTYPE_F32] = h
+
+    # ------------------------------------------------------------------------------------------------
+    def _make_engine(self, dtype: int):
+        cfg = _lib.fg_edm_config.from_buffer_copy(self._cfg)
+        cfg.compute_dtype = dtype
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().fg_edm_create(ctypes.byref(cfg), ctypes.byref(h)))
+        return h
+
+    def __del__(self):
+        try:
+            for h in getattr(self, "_engines", {}).values():
+                _lib.lib().fg_edm_destroy(h)
+        except Exception:
+            pass
+
+    def _named_weights(self):
+        sd = dict(self.named_parameters())
+        return [(n, sd[n]) for n in self._param_names]
+
+    def _select_dtype(self) -> int:
+        if self.compute_dtype is not None:
+            return _lib.FG_DTYPE_BF16 if self.compute_dtype == "bf16" else _lib.FG_DTYPE_F32
+        if torch.is_autocast_enabled():
+            ad = torch.get_autocast_gpu_dtype()
+            if ad == torch.bfloat16:
+                return _lib.FG_DTYPE_BF16
+            if ad != torch.float32:
+                raise NotImplementedError(f"autocast dtype {ad} is not implemented (bf16 or fp32)")
+        return _lib.FG_DTYPE_F32
+
+    def _engine(self, device: torch.device):
+        """Engine for the active compute dtype with up-to-date weights bound and packed."""
+        dt = self._select_dtype()
+        if dt not in self._engines:
+            self._engines[dt] = self._make_engine(dt)
+        h = self._engines[dt]
+        weights = self._named_weights()
+        sig = tuple((p.data_ptr(), p._version, p.dtype) for _, p in weights)
+        if self._bound_sig.get(dt) != sig:
+            L = _lib.lib()
+            refs = []
+            for n, p in weights:
+                if p.device.type != "cuda":
+                    raise RuntimeError(f"parameter {n} is on {p.device}; fastgen_amd runs on a HIP GPU only (no CPU path)")
+                q = p.detach()
+                if q.dtype != torch.float32 or not q.is_contiguous():
+                    q = q.to(torch.float32).contiguous()
+                refs.append(q)
+                _lib.check(L.fg_edm_bind_param(h, n.encode(), ctypes.c_void_p(q.data_ptr()), q.numel()))
+            _lib.check(L.fg_edm_pack_weights(h, ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+            self._pack_refs[dt] = refs
+            self._bound_sig[dt] = sig
+        return dt, h
+
+    def _workspace(self, dt: int, h, batch: int, device) -> torch.Tensor:
+        need = _lib.lib().fg_edm_workspace_bytes(h, batch)
+        ws = self._ws.get(dt)
+        if ws is None or ws.numel() < need or ws.device != device:
+            ws = torch.empty(need, dtype=torch.uint8, device=device)
+            self._ws[dt] = ws
+        return ws
+
+    @staticmethod
+    def _stream(device) -> ctypes.c_void_p:
+        return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+    def _check_inference(self):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "fastgen_amd.EDMPrecond computes the forward pass only (no autograd graph); call it under "
+                "torch.no_grad() / torch.inference_mode() as generator_fn does (fastgen/methods/model.py:405)")
+
+    def _labels(self, condition, batch: int, device) -> Optional[torch.Tensor]:
+        if isinstance(condition, dict) and "aug_condition" in condition:
+            raise NotImplementedError("augmentation labels are a training-time input and are not implemented here")
+        if self.label_dim == 0 or condition is None:
+            return None  # the library broadcasts map_label(zeros) as the reference does (EDM/network.py:919-925)
+        c = condition.reshape(-1, self.label_dim).to(device=device, dtype=torch.float32)
+        if c.shape[0] == 1 and batch > 1:
+            c = c.expand(batch, -1)
+        if c.shape[0] != batch:
+            raise ValueError(f"condition has {c.shape[0]} rows, expected {batch}")
+        return c.contiguous()
+
+    # ------------------------------------------------------------------------------------------------
+    def reset_parameters(self):
+        with torch.no_grad():
+            for n, p in self._named_weights():
+                p.copy_(_init_value(n, tuple(p.shape)).to(p.dtype))
+        super().reset_parameters()
+
+    def fully_shard(self, **kwargs):
+        """Same wrapping granularity as the reference (EDM/network.py:861-879): every UNetBlock, then the U-Net.
+        The fused forward reads whole parameters, so callers must unshard (`self.model.unshard()`) around it."""
+        from torch.distributed.fsdp import fully_shard
+
+        for group in (self.model._modules["enc"], self.model._modules["dec"]):
+            for _, block in group._modules.items():
+                if "conv0" in block._modules:
+                    fully_shard(block, **kwargs)
+        fully_shard(self.model, **kwargs)
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(
+        self,
+        x_t: torch.Tensor,
+        t: torch.Tensor,
+        condition: Optional[torch.Tensor] = None,
+        r: Optional[torch.Tensor] = None,
+        return_features_early: bool = False,
+        feature_indices: Optional[Set[int]] = None,
+        return_logvar: bool = False,
+        fwd_pred_type: Optional[str] = None,
+        **fwd_kwargs,
+    ):
+        if feature_indices is None:
+            feature_indices = {}
+        if return_features_early and len(feature_indices) == 0:
+            return []
+        if fwd_pred_type is None:
+            fwd_pred_type = self.net_pred_type
+        else:
+            assert fwd_pred_type in NET_PRED_TYPES, f"{fwd_pred_type} is not supported as fwd_pred_type"
+        if len(feature_indices) or return_features_early:
+            raise NotImplementedError("feature taps (feature_indices) belong to the training path; not implemented")
+        if r is not None:
+            raise ValueError("r_noise_labels provided, but r_timestep is not set")
+        if fwd_kwargs:
+            raise TypeError(f"unexpected forward kwargs: {sorted(fwd_kwargs)}")
+        if self.training and self.dropout:
+            raise NotImplementedError("dropout in training mode is not implemented (call .eval())")
+        self._check_inference()
+        if x_t.device.type != "cuda":
+            raise RuntimeError("fastgen_amd runs on a HIP GPU only (no CPU path); got a tensor on " + str(x_t.device))
+        if x_t.dim() != 4 or x_t.shape[1] != self.img_channels or x_t.shape[2] != self.img_resolution or x_t.shape[3] != self.img_resolution:
+            raise ValueError(f"x_t must be [B,{self.img_channels},{self.img_resolution},{self.img_resolution}], got {tuple(x_t.shape)}")
+        B, dev = x_t.shape[0], x_t.device
+        x32 = x_t.detach().to(torch.float32).contiguous()
+        t64 = torch.atleast_1d(t.detach()).to(device=dev, dtype=torch.float64)
+        if t64.numel() == 1 and B > 1:
+            t64 = t64.expand(B)
+        t64 = t64.contiguous()
+        if t64.numel() != B:
+            raise ValueError(f"t has {t64.numel()} entries, expected {B}")
+        labels = self._labels(condition, B, dev)
+        dt, h = self._engine(dev)
+        ws = self._workspace(dt, h, B, dev)
+        out = torch.empty_like(x32)
+        _lib.check(_lib.lib().fg_edm_forward(
+            h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
+            ctypes.c_void_p(labels.data_ptr() if labels is not None else None), ctypes.c_void_p(out.data_ptr()), None,
+            B, ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream(dev)))
+        out = out.to(x_t.dtype)
+        out = self.noise_scheduler.convert_model_output(x_t, out, t64, src_pred_type=self.net_pred_type,
+                                                        target_pred_type=fwd_pred_type)
+        if return_logvar:
+            return out, self._logvar(t64)
+        return out
+
+    def _logvar(self, t64: torch.Tensor) -> torch.Tensor:
+        """logvar_linear(PositionalEmbedding(c_noise)) — the un-flipped [cos|sin] embedding (EDM/network.py:501,571)."""
+        c_noise = (t64.clamp(min=self.noise_scheduler.clamp_min).log() / 4).to(torch.float32)
+        half = self._noise_channels // 2
+        freqs = torch.arange(half, dtype=torch.float32, device=t64.device) / (half - 1)
+        freqs = (1 / 10000) ** freqs
+        ang = c_noise.ger(freqs)
+        emb = torch.cat([ang.cos(), ang.sin()], dim=1)
+        lv = self.model._modules["logvar_linear"]
+        return emb @ lv.weight.to(emb.dtype).t() + lv.bias.to(emb.dtype)
+
+    # ------------------------------------------------------------------------------------------------
+    def few_step_sample(self, noise: torch.Tensor, condition: Optional[torch.Tensor], t_list, sample_type: str = "sde",
+                        eps: Optional[torch.Tensor] = None, seed: Optional[int] = None, use_graph: bool = True,
+                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The whole student sampling loop (methods/model.py:374-420) as ONE library call / one hipGraph replay.
+
+        t_list: steps+1 decreasing timesteps ending in 0.  sample_type 'sde' re-noises with `eps`
+        ([steps-1,B,C,H,W], injected) or, if eps is None, with normals drawn on the device from `seed`;
+        'ode' re-uses the implied noise (x0_to_eps)."""
+        self._check_inference()
+        if noise.device.type != "cuda":
+            raise RuntimeError("fastgen_amd runs on a HIP GPU only (no CPU path); got a tensor on " + str(noise.device))
+        if sample_type not in ("sde", "ode"):
+            raise NotImplementedError(f"student_sample_type must be one of 'sde', 'ode' but got {sample_type}")
+        B, dev = noise.shape[0], noise.device
+        tl = [float(v) for v in (t_list.tolist() if isinstance(t_list, torch.Tensor) else t_list)]
+        steps = len(tl) - 1
+        assert tl[-1] == 0, "t_list[-1] must be zero"
+        n32 = noise if (noise.dtype == torch.float32 and noise.is_contiguous()) else noise.to(torch.float32).contiguous()
+        labels = self._labels(condition, B, dev)
+        if eps is not None:
+            eps = eps.to(device=dev, dtype=torch.float32).contiguous()
+            if eps.numel() != max(steps - 1, 0) * n32.numel():
+                raise ValueError(f"eps must hold steps-1 = {steps - 1} noise tensors shaped like `noise`")
+        if seed is None:
+            seed = int(torch.randint(0, 2**62, (1,)).item())  # host RNG: follows torch.manual_seed / set_random_seed
+        dt, h = self._engine(dev)
+        ws = self._workspace(dt, h, B, dev)
+        if out is None:
+            out = torch.empty_like(n32)
+        tl_arr = (ctypes.c_double * (steps + 1))(*tl)
+        self._keep = (n32, labels, eps)  # graph replays read these buffers; keep them alive
+        _lib.check(_lib.lib().fg_sampler_run(
+            h, ctypes.c_void_p(n32.data_ptr()), ctypes.c_void_p(labels.data_ptr() if labels is not None else None),
+            tl_arr, steps, _lib.FG_SAMPLE_SDE if sample_type == "sde" else _lib.FG_SAMPLE_ODE,
+            ctypes.c_void_p(eps.data_ptr() if eps is not None and eps.numel() else None), ctypes.c_uint64(seed),
+            ctypes.c_void_p(out.data_ptr()), B, ctypes.c_void_p(ws.data_ptr()), ws.numel(), 1 if use_graph else 0,
+            self._stream(dev)))
+        return out
+
+    # ------------------------------------------------------------------------------------------------
+    def sample(self, noise: torch.Tensor, condition: Optional[torch.Tensor] = None,
+               neg_condition: Optional[torch.Tensor] = None, guidance_scale: Optional[float] = 5.0, num_steps: int = 50,
+               **kwargs) -> torch.Tensor:
+        """Deterministic Euler sampler of the (teacher) EDM network with optional classifier-free guidance
+        (EDM/network.py:976-1026)."""
+        assert self.schedule_type == "edm", f"{self.schedule_type} is not supported"
+        sigmas = self.noise_scheduler.get_t_list(num_steps, device=noise.device)
+        x = self.noise_scheduler.latents(noise=noise, t_init=sigmas[0])
+        for sigma, sigma_next in zip(sigmas[:-1], sigmas[1:]):
+            t = sigma.expand(x.shape[0])
+            if guidance_scale is not None and guidance_scale > 1.0 and neg_condition is not None:
+                x0 = self(torch.cat([x, x], 0), torch.cat([t, t], 0), condition=torch.cat([neg_condition, condition], 0),
+                          fwd_pred_type="x0")
+                x0_uncond, x0_cond = x0.chunk(2)
+                x0 = x0_uncond + guidance_scale * (x0_cond - x0_uncond)
+            else:
+                x0 = self(x, t, condition=condition, fwd_pred_type="x0")
+            d = (x - x0) / expand_like(t, x)
+            x = x + (sigma_next - sigma).to(x.dtype) * d
+        return x

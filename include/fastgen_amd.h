@@ -1,0 +1,135 @@
+/*
+ * fastgen_amd — C ABI of the MI355X-native few-step diffusion sampling path (libfastgen_amd.so).
+ *
+ * Drop-in boundary for ONE hot path of the reference (paths relative to the reference repo root):
+ *     FastGenModel.generator_fn / _student_sample_loop      fastgen/methods/model.py:315-420
+ *       -> EDMPrecond.forward -> SongUNet.forward             fastgen/networks/EDM/network.py:881-974, 489-574
+ *       -> EDMNoiseSchedule.{latents,forward_process,x0_to_eps}  fastgen/networks/noise_schedule.py:72-88,425-449,544-574
+ *
+ * Everything here is plain C: opaque handle, raw device pointers, sizes, an explicit HIP stream
+ * (passed as void* = hipStream_t).  No torch types.  All functions return 0 on success and a
+ * non-zero FG_E* code on failure; fg_last_error() returns a thread-local message.  A handle is
+ * re-entrant per stream only in the sense that calls on ONE handle must be serialised by the
+ * caller (one Python thread per process in the reference).
+ *
+ * Tensors at the boundary keep the reference's layout and dtype: images are fp32 NCHW [B,C,H,W],
+ * timesteps are fp64 [B] (noise_schedule.py:41,50), class labels fp32 [B,label_dim], parameters
+ * are fp32 in the reference's state-dict shapes (OIHW conv weights).  Internally activations are
+ * NHWC and weights are re-packed into MFMA fragment order; that never leaks through this ABI.
+ */
+#ifndef FASTGEN_AMD_H
+#define FASTGEN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FG_OK 0
+#define FG_EINVAL 1      /* bad argument / unsupported configuration */
+#define FG_ENOTREADY 2   /* a parameter is unbound or weights were not packed */
+#define FG_EHIP 3        /* a HIP runtime call failed (message holds hipGetErrorString) */
+#define FG_ENOMEM 4      /* workspace too small */
+
+#define FG_DTYPE_F32 0   /* exact fp32: v_mfma_f32_32x32x2_f32, fp32 activations */
+#define FG_DTYPE_BF16 1  /* bf16 MFMA operands, fp32 accumulate, fp32 residual stream / norm statistics / softmax */
+
+#define FG_SAMPLE_SDE 0  /* student_sample_type='sde'  (methods/model.py:358-359) */
+#define FG_SAMPLE_ODE 1  /* student_sample_type='ode'  (methods/model.py:360-361) */
+
+#define FG_MAX_LEVELS 8
+
+/* kwargs of EDMPrecond(model_type="SongUNet", embedding_type="positional", encoder_type=decoder_type="standard",
+ * resample_filter=[1,1], dropout=0) — fastgen/configs/net.py:29-48 and EDM/network.py:347-367, 809-821. */
+typedef struct fg_edm_config {
+    int img_resolution;                  /* 32 */
+    int img_channels;                    /* 3 */
+    int label_dim;                       /* 10 (0 = unconditional) */
+    int augment_dim;                     /* 9: map_augment exists in the state dict but is skipped when sampling */
+    int model_channels;                  /* 128 */
+    int num_levels;                      /* len(channel_mult) */
+    int channel_mult[FG_MAX_LEVELS];     /* {2,2,2} */
+    int channel_mult_emb;                /* 4 */
+    int num_blocks;                      /* 4 */
+    int num_attn_resolutions;
+    int attn_resolutions[FG_MAX_LEVELS]; /* {16} */
+    int channel_mult_noise;              /* 1 */
+    double sigma_data;                   /* 0.5 */
+    double sigma_shift;                  /* 0.0 (applied in eval mode only, EDM/network.py:956) */
+    int compute_dtype;                   /* FG_DTYPE_* */
+} fg_edm_config;
+
+typedef struct fg_edm fg_edm; /* opaque */
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* fg_last_error(void);
+/* "fastgen_amd <version> gfx950" */
+const char* fg_version(void);
+
+/* ---- network object: replaces EDMPrecond.__init__ / state-dict ownership (EDM/network.py:808-839) ---- */
+int fg_edm_create(const fg_edm_config* cfg, fg_edm** out);
+void fg_edm_destroy(fg_edm* h);
+
+/* State-dict view: the entries of the reference's EDMPrecond.state_dict() that carry weights (parameters
+ * only; the constant resample_filter buffers are folded into the kernels).  Same names, same shapes. */
+int fg_edm_num_params(const fg_edm* h);
+int fg_edm_param_info(const fg_edm* h, int index, const char** name, int* ndim, int64_t shape[4]);
+
+/* Bind a parameter to caller-owned DEVICE memory (fp32, reference layout).  The pointer is borrowed: it is
+ * read again by every fg_edm_pack_weights() and must stay valid until then.  Used instead of a one-shot
+ * load so FSDP2 / optimizer updates can re-bind and re-pack. */
+int fg_edm_bind_param(fg_edm* h, const char* name, const float* device_ptr, int64_t numel);
+/* Build the kernel-layout copies (MFMA fragment order, compute dtype) of all bound parameters. */
+int fg_edm_pack_weights(fg_edm* h, void* stream);
+
+/* Bytes of caller-provided scratch needed for a batch (activations, skip stack, norm statistics ...). */
+size_t fg_edm_workspace_bytes(const fg_edm* h, int batch);
+
+/* EDMPrecond.forward(x_t, t, condition=class_labels, fwd_pred_type="x0") in eval mode
+ * (EDM/network.py:881-974).  x_t,out: [B,C,H,W] fp32; t: [B] fp64; class_labels: [B,label_dim] fp32 or NULL
+ * (NULL = the reference's zeros([1,label_dim]) broadcast, :919-925).  All device pointers.  x_t is not modified;
+ * out may not alias x_t.  emb_out (nullable): [B, model_channels*channel_mult_emb] mapping-network output. */
+int fg_edm_forward(fg_edm* h, const float* x_t, const double* t, const float* class_labels, float* out,
+                   float* emb_out, int batch, void* workspace, size_t workspace_bytes, void* stream);
+
+/* FastGenModel.generator_fn + _student_sample_loop (methods/model.py:315-420) for this network:
+ *   x = noise * t_list[0]; for i: x0 = forward(x, t_i); if t_{i+1} > 0: x = x0 + t_{i+1} * eps_i; return x0.
+ * t_list: HOST array of steps+1 doubles, t_list[steps] must be 0 (model.py:410).  sample_type FG_SAMPLE_*.
+ * eps: device [steps-1][B,C,H,W] noise to inject in 'sde' mode, or NULL to draw it on device from
+ * (seed, step) with Philox4x32-10.  use_graph != 0 replays a cached hipGraph of the whole loop. */
+int fg_sampler_run(fg_edm* h, const float* noise, const float* class_labels, const double* t_list, int steps,
+                   int sample_type, const float* eps, uint64_t seed, float* out, int batch, void* workspace,
+                   size_t workspace_bytes, int use_graph, void* stream);
+
+/* EDMNoiseSchedule.get_t_list(sample_steps) (noise_schedule.py:940-973) -> steps+1 doubles on the host. */
+int fg_edm_t_list(int sample_steps, double* out_host);
+
+/* ---- single-op entry points (used by the parity tests; same kernels the network path launches) ---- */
+
+/* One UNetBlock (EDM/network.py:274-299) by index into the encoder+decoder block list.  Inputs NHWC fp32:
+ * x1 [B,Hin,Win,c1] (+ optional x2 [B,Hin,Win,c2] = the skip tensor of the decoder's channel concat),
+ * emb [B,emb_channels]; out [B,H,W,cout] NHWC. */
+int fg_edm_num_blocks(const fg_edm* h);
+int fg_edm_block_info(const fg_edm* h, int index, const char** key, int* cin, int* cout, int* res_in, int* res_out,
+                      int* has_attention);
+int fg_edm_run_block(fg_edm* h, int index, const float* x1, int c1, const float* x2, int c2, const float* emb,
+                     float* out, int batch, void* workspace, size_t workspace_bytes, void* stream);
+
+/* GroupNorm statistics folded with the affine parameters: ab[b][c] = {a, b} with y = a*x + b
+ * (GroupNorm.forward, EDM/network.py:141-149; groups = min(32, C/4)).  x NHWC fp32 [B,HW,C]. */
+int fg_op_gn_coeffs(const float* x1, int c1, const float* x2, int c2, const float* gamma, const float* beta,
+                    float eps, float* ab_out, int batch, int hw, void* stream);
+
+/* Elementwise sampler steps in fp64 (noise_schedule.py:72-88, 425-449, 544-574); n = elements per sample. */
+int fg_op_latents(const float* noise, double t_init, float* out, int64_t total, void* stream);
+int fg_op_forward_process(const float* x0, const float* eps, double t, float* out, int64_t total, void* stream);
+int fg_op_x0_to_eps(const float* xt, const float* x0, double t, float* out, int64_t total, void* stream);
+/* Standard normal draws: Philox4x32-10(key = seed, counter = (offset, index/4)) + Box-Muller. */
+int fg_op_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTGEN_AMD_H */
