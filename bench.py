@@ -1,0 +1,213 @@
+"""Headline benchmark: images/sec of 4-step DMD2-style student sampling with the EDM CIFAR-10 U-Net
+(BASELINE.json configs[1]: batch 512 per MI355X, synthetic latents, random-init weights of that architecture).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: FastGenModel.generator_fn(net, noise[512,3,32,32], 4 steps,
+'sde') on each rank = one hipGraph replay of latents -> 4 x (U-Net forward, re-noise).  Inputs are resident in HBM
+before the timed region.  Ranks are independent replicas (sampling shards by image, no collective on the data path);
+the timed region is bracketed by barrier + device synchronize on both sides and the MAX over ranks is reported.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     — the dominant kernel (fused GN+SiLU+conv3x3 at 32x32) timed live with HIP events on its launch stream
+  cpu_baseline — the CPU oracle (torch fp32 restatement of the reference path, oracle/edm_ref.py) on this host's cores
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GFLOP_PER_IMAGE_FWD = 42.383  # BASELINE.md section 2 (conv 42.034 + attention 0.340 + linear 0.009), 2*MAC
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md:41-43
+EDM_CIFAR10 = dict(img_resolution=32, img_channels=3, label_dim=10, sigma_shift=0.0, sigma_data=0.5,
+                   model_type="SongUNet", augment_dim=9, model_channels=128, channel_mult=[2, 2, 2],
+                   channel_mult_noise=1, embedding_type="positional", encoder_type="standard",
+                   decoder_type="standard", resample_filter=[1, 1], dropout=0.0, label_dropout=0, r_timestep=False,
+                   drop_precond=None)
+
+
+def dist_env():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init_dist(world: int, backend: str):
+    """One process per GPU; rendezvous from MASTER_ADDR/PORT (torch.distributed.run sets them)."""
+    import torch.distributed as dist
+
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend=backend, init_method="env://")
+    return dist
+
+
+def timed_region(step_fn, steps: int, warmup: int, world: int, sync_fn, device=None) -> float:
+    """W untimed warm-up steps, then EXACTLY `steps` steps between barrier+sync fences; returns the max over ranks
+    of the elapsed seconds.  Shared by the GPU bench and the gloo CPU test (tests/test_dist_gloo.py)."""
+    import torch.distributed as dist
+
+    for _ in range(warmup):
+        step_fn()
+    sync_fn()
+    if world > 1:
+        dist.barrier()
+    sync_fn()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync_fn()
+    if world > 1:
+        dist.barrier()
+    sync_fn()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device if device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def host_cores() -> int:
+    """CPU threads this process may really use: min(affinity mask, cgroup cpu.max quota, 16 = the per-GPU host share
+    of the benchmark boxes).  Asking torch for more threads than the quota allows makes the CPU leg crawl."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(budget_s: float = 20.0):
+    """The oracle (kind 'port': the repo's torch-CPU restatement, pinned to reference fixtures) on this host:
+    EDM CIFAR-10, fp32, batch 16, 4-step 'sde' with injected eps — BASELINE.md section 4."""
+    from oracle import edm_ref as R
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    cfg = R.CIFAR10
+    sd = R.random_state_dict(cfg, seed=1234)
+    B = 16
+    noise = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(0))
+    cond = torch.nn.functional.one_hot(torch.arange(B) % 10, 10).float()
+    eps = [torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(s)) for s in (1, 2, 3)]
+    R.generator_fn(sd, cfg, noise, cond, 4, sample_type="sde", eps_list=eps)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while n < 1 or (time.perf_counter() - t0 < budget_s and n < 6):
+        R.generator_fn(sd, cfg, noise, cond, 4, sample_type="sde", eps_list=eps)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 3), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": f"{n} batches of 16 images, 4-step sde, fp32 torch-CPU oracle ({dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=512, help="images per GPU per step")
+    ap.add_argument("--sample-steps", type=int, default=4)
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    rank, local_rank, world = dist_env()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with python -m torch.distributed.run "
+                             f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the fastgen_amd path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = init_dist(world, "nccl")
+
+    from fastgen_amd import _lib
+    from fastgen_amd.methods.model import FastGenModel
+    from fastgen_amd.networks.EDM.network import EDMPrecond
+
+    # random-init weights of the named architecture; seeded N(0, 1/fan_in) so activations stay O(1) (the reference's
+    # default init scales the residual branches by 1e-5, which makes the data trivial)
+    net = EDMPrecond(**EDM_CIFAR10).randomize_parameters_(seed=1234).to(dev).eval()
+    amp = torch.bfloat16 if args.dtype == "bf16" else None
+
+    B = args.batch
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)  # seed + rank, utils/basic_utils.py:140-143
+    noise = torch.randn(B, 3, 32, 32, device=dev, generator=gen)
+    cond = torch.nn.functional.one_hot(torch.arange(B, device=dev) % 10, 10).float()
+    step_seed = [0]
+
+    def step():
+        step_seed[0] += 1
+        return FastGenModel.generator_fn(net, noise, condition=cond, student_sample_steps=args.sample_steps,
+                                         student_sample_type="sde", precision_amp=amp, seed=step_seed[0] * world + rank,
+                                         use_graph=not args.no_graph)
+
+    dt = timed_region(step, args.steps, args.warmup, world, lambda: torch.cuda.synchronize(dev), dev)
+    imgs = B * args.steps * world
+    value = imgs / dt
+    out = step()
+    assert torch.isfinite(out).all(), "non-finite samples"
+
+    # ---- roofline of the dominant kernel, measured live with HIP events on its launch stream -------------------
+    roof = None
+    if rank == 0:
+        with torch.inference_mode(), torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+            _, h = net._engine(dev)
+        L = _lib.lib()
+        _lib.check(L.fg_edm_profile_begin(h))
+        for _ in range(2):
+            step()
+        n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(L.fg_edm_profile_end(h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)))
+        ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        peak = PEAK_TFLOPS[args.dtype]
+        roof = {"bound": "mfma", "kernel": "conv_fused_kernel<T,3,PRO_GN_SILU,RES_NONE,32x32>",
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2),
+                "avg_launch_gflop": round(fl.value / max(n.value, 1) / 1e9, 2),
+                "whole_step": {"achieved": round(value / world * GFLOP_PER_IMAGE_FWD * args.sample_steps / 1e3, 2),
+                               "frac": round(value / world * GFLOP_PER_IMAGE_FWD * args.sample_steps / 1e3 / peak, 4),
+                               "note": "all kernels of the 4-step graph, 42.383 GFLOP/image/forward"}}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+        line = {
+            "metric": "images/sec at 4-step distilled (DMD2) sampling", "value": round(value, 2), "unit": "img/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"EDM CIFAR-10 32x32 SongUNet (55.7M params) DMD2 {args.sample_steps}-step 'sde' sampling, "
+                                   f"batch={B} per GPU", "global_batch": B * world, "sample_steps": args.sample_steps,
+                       "parallelism": f"replicas x{world} (no data-path collective)", "graph": not args.no_graph},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,8 @@ SIGNATURES = {
     "fg_sampler_run": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double), c_int, c_int, c_void_p, c_uint64,
                                c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "fg_edm_t_list": (c_int, [c_int, POINTER(c_double)]),
+    "fg_edm_profile_begin": (c_int, [c_void_p]),
+    "fg_edm_profile_end": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
     "fg_edm_num_blocks": (c_int, [c_void_p]),
     "fg_edm_block_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int), POINTER(c_int), POINTER(c_int),
                                   POINTER(c_int), POINTER(c_int)]),

@@ -59,8 +59,9 @@ __global__ __launch_bounds__(512, 2) void conv_fused_kernel(const ConvArgs a) {
     constexpr int NITEMS = (G::HALO_PIX * OPP + 511) / 512;      // staging items per thread and chunk
     constexpr int IPS = (NITEMS + G::TAPS - 1) / G::TAPS;        // items staged per (chunk, tap) step
     constexpr int ABUF = G::HALO_PIX * PITCH;
-    constexpr bool DEFER = (RES != RES_DOWN);                    // split load / transform+write around the MFMAs
+    constexpr bool DEFER = (RES != RES_DOWN) && (KS == 3);       // split load / transform+write around the MFMAs
     constexpr bool AB_REGS = (PRO != PRO_NONE) && (G::IMGS == 1);  // per-chunk GN coefficients live in registers
+    constexpr bool PIPE_A = (sizeof(T) == 2);                      // two A-fragment register sets (bf16 only)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -154,30 +155,30 @@ __global__ __launch_bounds__(512, 2) void conv_fused_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = 0.f;
             }
-        } else {  // RES_DOWN: mean of the four transformed source pixels
+        } else {  // synchronous path: RES_DOWN (mean of the four transformed source pixels) and all 1x1 convs
+            constexpr int ND = (RES == RES_DOWN) ? 4 : 1;
             int n, y, x;
             const bool ok = decode(hq, n, y, x);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = 0.f;
             if (ok) {
                 float2 ab[8];
-                if (PRO != PRO_NONE) {
-                    if (AB_REGS) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) ab[j] = abr[j];
-                    } else {
-                        load_ab(chunk, n, ab);
-                    }
-                }
+                for (int j = 0; j < 8; ++j) ab[j] = AB_REGS ? abr[j] : make_float2(1.f, 0.f);
+                if (PRO != PRO_NONE && !AB_REGS) load_ab(chunk, n, ab);
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
+                for (int d = 0; d < ND; ++d) {
                     float v[8];
-                    load8(src_ptr(chunk, n, 2 * y + (d >> 1), 2 * x + (d & 1)), v);
+                    const int sy = (RES == RES_DOWN) ? 2 * y + (d >> 1) : ((RES == RES_UP) ? (y >> 1) : y);
+                    const int sx = (RES == RES_DOWN) ? 2 * x + (d & 1) : ((RES == RES_UP) ? (x >> 1) : x);
+                    load8(src_ptr(chunk, n, sy, sx), v);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] += pro_apply<PRO, FAST>(v[j], (PRO != PRO_NONE) ? ab[j] : make_float2(1.f, 0.f));
+                    for (int j = 0; j < 8; ++j) o[j] += pro_apply<PRO, FAST>(v[j], ab[j]);
                 }
+                if (ND == 4) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] *= 0.25f;
+                    for (int j = 0; j < 8; ++j) o[j] *= 0.25f;
+                }
             }
         }
         store_frag(reinterpret_cast<T*>(abuf + hq * PITCH) + oct * 8, o);
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void conv_fused_kernel(const ConvArgs a) {
         if (DEFER) item_load(0, i, raw, valid);
         item_finish(0, i, smem, raw, valid);
     }
-    Frag8<T> bcur[KK], bnext[KK];
+    Frag8<T> bcur[KK];
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) bcur[kk] = load_frag(wp + kk * 512);
 
@@ -213,13 +214,9 @@ __global__ __launch_bounds__(512, 2) void conv_fused_kernel(const ConvArgs a) {
         const bool stage_next = (chunk + 1 < nchunk);
 #pragma unroll 1
         for (int tap = 0; tap < G::TAPS; ++tap, ++step) {
-            // (1) weights of the next step -> registers (clamped: the last step re-reads itself)
-            {
-                const int snext = (step + 1 < nsteps) ? step + 1 : step;
-                const T* p = wp + (size_t)snext * (KK * 512);
-#pragma unroll
-                for (int kk = 0; kk < KK; ++kk) bnext[kk] = load_frag(p + kk * 512);
-            }
+            // (1) weights: each fragment is refilled in place for the NEXT step right after its last use below
+            //     (clamped: the last step re-reads itself), so B needs KK fragments, one step of prefetch distance
+            const T* pnext = wp + (size_t)((step + 1 < nsteps) ? step + 1 : step) * (KK * 512);
             // (2) issue this step's share of the next chunk's activation loads
             float raw[IPS][8];
             bool valid[IPS];
@@ -231,16 +228,44 @@ __global__ __launch_bounds__(512, 2) void conv_fused_kernel(const ConvArgs a) {
                     for (int q = 0; q < IPS; ++q) item_load(chunk + 1, tap * IPS + q, raw[q], valid[q]);
                 }
             }
-            // (3) multiply: 8 pixel tiles x KK k-steps against this wave's 32 output channels
+            // (3) multiply: 8 pixel tiles x KK k-steps against this wave's 32 output channels.  The 8 A fragments of
+            //     a k-step are read from LDS as one group (latency paid once per group, not per MFMA); with bf16
+            //     operands the next k-step's group is issued before this k-step's 8 back-to-back MFMAs.
             const int tap_off = ((tap / KS) * G::HW_ + (tap % KS)) * PITCH;
             const char* abase = abuf + lane_off + tap_off;
+            auto read_a = [&](int kk, Frag8<T> (&af)[8]) {
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) {
+                for (int mt = 0; mt < 8; ++mt)
+                    af[mt] = load_frag(reinterpret_cast<const T*>(abase + G::hp0(mt * 32) * PITCH) + kk * 16);
+            };
+            if (PIPE_A) {
+                Frag8<T> a0[8], a1[8];
+                read_a(0, a0);
 #pragma unroll
-                for (int mt = 0; mt < 8; ++mt) {
-                    const Frag8<T> af =
-                        load_frag(reinterpret_cast<const T*>(abase + G::hp0(mt * 32) * PITCH) + kk * 16);
-                    mma16(acc[mt], af, bcur[kk]);
+                for (int kk = 0; kk < KK; kk += 2) {
+                    read_a(kk + 1, a1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mt = 0; mt < 8; ++mt) mma16(acc[mt], a0[mt], bcur[kk]);
+                    bcur[kk] = load_frag(pnext + kk * 512);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kk + 2 < KK) read_a(kk + 2, a0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mt = 0; mt < 8; ++mt) mma16(acc[mt], a1[mt], bcur[kk + 1]);
+                    bcur[kk + 1] = load_frag(pnext + (kk + 1) * 512);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+                    Frag8<T> af[8];
+                    read_a(kk, af);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mt = 0; mt < 8; ++mt) mma16(acc[mt], af[mt], bcur[kk]);
+                    bcur[kk] = load_frag(pnext + kk * 512);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             // (4) transform + park the staged items
@@ -249,8 +274,6 @@ __global__ __launch_bounds__(512, 2) void conv_fused_kernel(const ConvArgs a) {
                 for (int q = 0; q < IPS; ++q)
                     if (tap * IPS + q < NITEMS) item_finish(chunk + 1, tap * IPS + q, anext, raw[q], valid[q]);
             }
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk) bcur[kk] = bnext[kk];
         }
         __syncthreads();
     }

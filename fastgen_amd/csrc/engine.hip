@@ -119,8 +119,22 @@ struct fg_edm {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     GraphKey graph_key;
-    double* tl_pinned = nullptr;      // [65]
-    uint64_t* seed_pinned = nullptr;  // [2]
+    // Per-call scalars (timesteps, RNG seed) reach the device through a ring of pinned host slots, copied on the
+    // caller's stream BEFORE the graph launch (not a graph node: a node would re-read host memory that the next call
+    // may already have overwritten).  A slot is reused only after the event recorded behind its copy has completed.
+    static constexpr int kSlots = 8;
+    struct Slot {
+        double tl[72];
+        uint64_t seed[8];
+    };
+    Slot* slots = nullptr;  // pinned
+    hipEvent_t slot_ev[kSlots] = {};
+    bool slot_used[kSlots] = {};
+    int slot_next = 0;
+    // live timing of the dominant kernel (conv 3x3, no resample, 32x32 output): HIP events on the launch stream
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;  // start/stop pairs
+    double prof_flops = 0.0;
     hipStream_t cap_stream = nullptr;  // capture-only stream (the legacy default stream cannot be captured)
 
     int find(const std::string& n) const {
@@ -342,6 +356,24 @@ int dev_alloc(fg_edm* h, void** p, size_t bytes) {
     return FG_OK;
 }
 
+// launch_conv_fused + optional event pair when profiling the dominant kernel class
+int conv_launch(fg_edm* h, int ks, int pro, int res, int outmode, const ConvArgs& a, hipStream_t s) {
+    const bool timed = h->prof_on && ks == 3 && res == RES_NONE && a.W == 32 && outmode == OUT_NHWC;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) {
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (int)hipErrorUnknown;
+        (void)hipEventRecord(e0, s);
+    }
+    const int rc = launch_conv_fused(h->dtype, ks, pro, res, outmode, a, s);
+    if (timed) {
+        (void)hipEventRecord(e1, s);
+        h->prof_ev.push_back(e0);
+        h->prof_ev.push_back(e1);
+        h->prof_flops += 2.0 * a.B * a.H * a.W * (double)a.Cout * 9.0 * (a.C1 + a.C2);
+    }
+    return rc;
+}
+
 const float kSkipScale = (float)std::sqrt(0.5);  // block_kwargs.skip_scale, EDM/network.py:385
 const float kBlockEps = 1e-6f;                   // block_kwargs.eps :386, aux_norm :483
 
@@ -359,7 +391,7 @@ int run_block(fg_edm* h, const Block& b, const float* x1, int c1, const float* x
     a.ab = w.ab0; a.wpack = b.p_conv0; a.bias = h->P(b.conv0_b);
     a.temb = temb + b.temb_off; a.temb_stride = h->temb_total;
     a.resid = nullptr; a.scale = 1.0f; a.out = w.h; a.Cout = b.cout;
-    HIP_TRY(launch_conv_fused(h->dtype, 3, PRO_GN_SILU, res_mode, OUT_NHWC, a, s));
+    HIP_TRY(conv_launch(h, 3, PRO_GN_SILU, res_mode, OUT_NHWC, a, s));
     // skip path
     const float* resid = x1;
     if (b.has_skip) {
@@ -367,7 +399,7 @@ int run_block(fg_edm* h, const Block& b, const float* x1, int c1, const float* x
         k.src1 = x1; k.src2 = x2; k.C1 = c1; k.C2 = c2;
         k.Hs = k.Ws = b.res_in; k.H = k.W = b.res_out; k.B = B;
         k.wpack = b.p_skip; k.bias = h->P(b.skip_b); k.scale = 1.0f; k.out = w.sbuf; k.Cout = b.cout;
-        HIP_TRY(launch_conv_fused(h->dtype, 1, PRO_NONE, res_mode, OUT_NHWC, k, s));
+        HIP_TRY(conv_launch(h, 1, PRO_NONE, res_mode, OUT_NHWC, k, s));
         resid = w.sbuf;
     }
     // x = (conv1(silu(norm1(h))) + skip) * sqrt(.5)
@@ -378,19 +410,19 @@ int run_block(fg_edm* h, const Block& b, const float* x1, int c1, const float* x
     d.src1 = w.h; d.C1 = b.cout; d.Hs = d.Ws = d.H = d.W = b.res_out; d.B = B;
     d.ab = w.ab1; d.wpack = b.p_conv1; d.bias = h->P(b.conv1_b);
     d.resid = resid; d.scale = kSkipScale; d.out = x_mid; d.Cout = b.cout;
-    HIP_TRY(launch_conv_fused(h->dtype, 3, PRO_GN_SILU, RES_NONE, OUT_NHWC, d, s));
+    HIP_TRY(conv_launch(h, 3, PRO_GN_SILU, RES_NONE, OUT_NHWC, d, s));
     if (b.attn) {
         HIP_TRY(launch_gn_coeffs(x_mid, b.cout, nullptr, 0, h->P(b.norm2_w), h->P(b.norm2_b), kBlockEps, w.ab2, B, hw, s));
         ConvArgs q{};
         q.src1 = x_mid; q.C1 = b.cout; q.Hs = q.Ws = q.H = q.W = b.res_out; q.B = B;
         q.ab = w.ab2; q.wpack = b.p_qkv; q.bias = b.qkv_bias; q.scale = 1.0f; q.Cout = 3 * b.cout;
         q.q_out = w.q; q.k_out = w.k; q.vt_out = w.vt;
-        HIP_TRY(launch_conv_fused(h->dtype, 1, PRO_GN, RES_NONE, OUT_QKV, q, s));
+        HIP_TRY(conv_launch(h, 1, PRO_GN, RES_NONE, OUT_QKV, q, s));
         HIP_TRY(launch_attention(h->dtype, w.q, w.k, w.vt, w.aout, B, hw, s));
         ConvArgs p{};
         p.src1 = w.aout; p.C1 = b.cout; p.Hs = p.Ws = p.H = p.W = b.res_out; p.B = B;
         p.wpack = b.p_proj; p.bias = h->P(b.proj_b); p.resid = x_mid; p.scale = kSkipScale; p.out = out; p.Cout = b.cout;
-        HIP_TRY(launch_conv_fused(h->dtype, 1, PRO_NONE, RES_NONE, OUT_NHWC, p, s));
+        HIP_TRY(conv_launch(h, 1, PRO_NONE, RES_NONE, OUT_NHWC, p, s));
     }
     return FG_OK;
 }
@@ -453,8 +485,6 @@ int enqueue_sampler(fg_edm* h, const float* noise, const float* labels, const do
                     const float* eps, float* out, int B, Workspace& w, hipStream_t s) {
     const fg_edm_config& c = h->cfg;
     const int64_t total = (int64_t)B * c.img_channels * c.img_resolution * c.img_resolution;
-    HIP_TRY(hipMemcpyAsync(w.tl, h->tl_pinned, sizeof(double) * (steps + 1), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(w.seed, h->seed_pinned, sizeof(uint64_t) * 2, hipMemcpyHostToDevice, s));
     HIP_TRY(launch_latents(noise, 0.0, w.tl, 0, w.x, total, s));  // latents = noise * sigma(t_0), noise_schedule.py:72-88
     for (int i = 0; i < steps; ++i) {
         float* pred = (i == steps - 1) ? out : w.x_pred;
@@ -525,8 +555,8 @@ int ensure_device_state(fg_edm* h) {
     if ((rc = dev_alloc(h, (void**)&h->freqs, sizeof(float) * half))) return rc;
     HIP_TRY(hipMemcpy(h->freqs, fr.data(), sizeof(float) * half, hipMemcpyHostToDevice));
     if (conv_prepare_all(h->dtype) != 0) return fail(FG_EHIP, "hipFuncSetAttribute(dynamic LDS) failed");
-    HIP_TRY(hipHostMalloc((void**)&h->tl_pinned, sizeof(double) * 72));
-    HIP_TRY(hipHostMalloc((void**)&h->seed_pinned, sizeof(uint64_t) * 8));
+    HIP_TRY(hipHostMalloc((void**)&h->slots, sizeof(fg_edm::Slot) * fg_edm::kSlots));
+    for (int i = 0; i < fg_edm::kSlots; ++i) HIP_TRY(hipEventCreateWithFlags(&h->slot_ev[i], hipEventDisableTiming));
     h->device_ready = true;
     return FG_OK;
 }
@@ -566,9 +596,11 @@ void fg_edm_destroy(fg_edm* h) {
     if (!h) return;
     drop_graph(h);
     for (void* p : h->owned) (void)hipFree(p);
-    if (h->tl_pinned) (void)hipHostFree(h->tl_pinned);
-    if (h->seed_pinned) (void)hipHostFree(h->seed_pinned);
+    if (h->slots) (void)hipHostFree(h->slots);
+    for (hipEvent_t e : h->slot_ev)
+        if (e) (void)hipEventDestroy(e);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -688,10 +720,20 @@ int fg_sampler_run(fg_edm* h, const float* noise, const float* class_labels, con
     int rc = setup_ws(h, batch, workspace, workspace_bytes, w);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    for (int i = 0; i <= steps; ++i) h->tl_pinned[i] = t_list[i];
-    h->seed_pinned[0] = seed;
-    h->seed_pinned[1] = 0;
-    if (!use_graph) return enqueue_sampler(h, noise, class_labels, t_list, steps, sample_type, eps, out, batch, w, s);
+    {   // upload this call's timesteps and seed (see fg_edm::Slot)
+        const int si = h->slot_next;
+        h->slot_next = (si + 1) % fg_edm::kSlots;
+        if (h->slot_used[si]) HIP_TRY(hipEventSynchronize(h->slot_ev[si]));
+        fg_edm::Slot& sl = h->slots[si];
+        for (int i = 0; i <= steps; ++i) sl.tl[i] = t_list[i];
+        sl.seed[0] = seed;
+        sl.seed[1] = 0;
+        HIP_TRY(hipMemcpyAsync(w.tl, sl.tl, sizeof(double) * (steps + 1), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(w.seed, sl.seed, sizeof(uint64_t) * 2, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(h->slot_ev[si], s));
+        h->slot_used[si] = true;
+    }
+    if (!use_graph || h->prof_on) return enqueue_sampler(h, noise, class_labels, t_list, steps, sample_type, eps, out, batch, w, s);
 
     GraphKey key;
     key.B = batch; key.steps = steps; key.type = sample_type;
@@ -717,6 +759,33 @@ int fg_sampler_run(fg_edm* h, const float* noise, const float* class_labels, con
         h->graph_key = key;
     }
     HIP_TRY(hipGraphLaunch(h->graph_exec, s));
+    return FG_OK;
+}
+
+int fg_edm_profile_begin(fg_edm* h) {
+    if (!h) return fail(FG_EINVAL, "null handle");
+    for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
+    h->prof_ev.clear();
+    h->prof_flops = 0.0;
+    h->prof_on = true;
+    return FG_OK;
+}
+
+int fg_edm_profile_end(fg_edm* h, int64_t* launches, double* total_ms, double* total_flops) {
+    if (!h) return fail(FG_EINVAL, "null handle");
+    h->prof_on = false;
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < h->prof_ev.size(); i += 2) {
+        HIP_TRY(hipEventSynchronize(h->prof_ev[i + 1]));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, h->prof_ev[i], h->prof_ev[i + 1]));
+        ms += t;
+    }
+    if (launches) *launches = (int64_t)h->prof_ev.size() / 2;
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = h->prof_flops;
+    for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
+    h->prof_ev.clear();
     return FG_OK;
 }
 

@@ -106,6 +106,13 @@ int fg_sampler_run(fg_edm* h, const float* noise, const float* class_labels, con
 /* EDMNoiseSchedule.get_t_list(sample_steps) (noise_schedule.py:940-973) -> steps+1 doubles on the host. */
 int fg_edm_t_list(int sample_steps, double* out_host);
 
+/* ---- measurement hook (bench.py): time every launch of the dominant kernel — the fused 3x3 conv at 32x32 output
+ * without resampling — with a hipEvent pair on the stream it is launched on.  While active the sampler runs eagerly
+ * (no graph replay).  profile_end() synchronises the events and returns launches, summed milliseconds and summed
+ * algorithmic FLOPs (2 * B*H*W * Cout * 9*Cin per launch). */
+int fg_edm_profile_begin(fg_edm* h);
+int fg_edm_profile_end(fg_edm* h, int64_t* launches, double* total_ms, double* total_flops);
+
 /* ---- single-op entry points (used by the parity tests; same kernels the network path launches) ---- */
 
 /* One UNetBlock (EDM/network.py:274-299) by index into the encoder+decoder block list.  Inputs NHWC fp32:

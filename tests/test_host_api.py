@@ -1,0 +1,187 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports what include/*.h declares, the nn.Module
+drop-in reproduces the reference's state-dict, the schedule mirror matches the golden vectors, loud failures."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from fastgen_amd import _lib
+from fastgen_amd.methods.model import FastGenModel
+from fastgen_amd.networks.EDM.network import EDMPrecond
+from fastgen_amd.networks.noise_schedule import EDMNoiseSchedule, get_noise_schedule
+from oracle import edm_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KW = dict(img_resolution=32, img_channels=3, label_dim=10, sigma_shift=0.0, sigma_data=0.5, model_type="SongUNet",
+          augment_dim=9, model_channels=128, channel_mult=[2, 2, 2], channel_mult_noise=1, embedding_type="positional",
+          encoder_type="standard", decoder_type="standard", resample_filter=[1, 1], dropout=0.0, label_dropout=0,
+          r_timestep=False, drop_precond=None)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "fastgen_amd.h")).read()
+    declared = set(re.findall(r"\b(fg_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    L = _lib.lib()
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert b"gfx950" in L.fg_version()
+
+
+def test_create_rejects_unsupported_configs():
+    L = _lib.lib()
+    cfg = _lib.fg_edm_config()
+    cfg.img_resolution, cfg.img_channels, cfg.label_dim, cfg.model_channels = 32, 3, 10, 32  # 64-wide blocks
+    cfg.num_levels, cfg.channel_mult_emb, cfg.num_blocks, cfg.channel_mult_noise = 1, 4, 1, 1
+    cfg.channel_mult[0] = 2
+    cfg.sigma_data = 0.5
+    h = ctypes.c_void_p()
+    assert L.fg_edm_create(ctypes.byref(cfg), ctypes.byref(h)) == 1
+    assert b"unsupported" in L.fg_last_error()
+    cfg.compute_dtype = 7
+    assert L.fg_edm_create(ctypes.byref(cfg), ctypes.byref(h)) == 1
+    with pytest.raises(_lib.FastGenAMDError):
+        _lib.check(L.fg_edm_create(None, None))
+
+
+def test_t_list_c_abi(golden_dir):
+    fx = torch.load(os.path.join(golden_dir, "schedule.pt"), weights_only=True)
+    for n in (1, 2, 4):
+        arr = (ctypes.c_double * (n + 1))()
+        _lib.check(_lib.lib().fg_edm_t_list(n, arr))
+        got = torch.tensor(list(arr), dtype=torch.float64)
+        assert torch.allclose(got, fx[f"t_list_{n}"], rtol=1e-14, atol=0)
+        assert got[-1] == 0
+
+
+@pytest.fixture(scope="module")
+def net():
+    return EDMPrecond(**KW)
+
+
+def test_state_dict_is_the_references(net, golden_dir):
+    want = {}
+    for line in open(os.path.join(golden_dir, "state_dict_keys.txt")):
+        p = line.split()
+        want[p[0]] = tuple(int(v) for v in p[1:])
+    got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert got == want and list(got) == list(want)  # same names, shapes AND order
+    assert sum(p.numel() for p in net.parameters()) == 55_735_428
+    # a reference-format checkpoint loads strictly, and strict=False reports nothing missing/unexpected
+    sd = R.random_state_dict(R.CIFAR10, seed=5)
+    res = net.load_state_dict(sd, strict=False)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert torch.equal(net.state_dict()["model.enc.32x32_block0.conv0.weight"], sd["model.enc.32x32_block0.conv0.weight"])
+
+
+def test_default_init_follows_reference_scales(net):
+    m = EDMPrecond(**KW)
+    sd = m.state_dict()
+    assert sd["model.enc.32x32_block0.conv1.weight"].abs().max() < 1e-5 * 0.1  # init_zero: xavier * 1e-5
+    assert sd["model.dec.32x32_aux_conv.weight"].abs().max() < 1e-5
+    assert torch.all(sd["model.enc.32x32_block0.norm0.weight"] == 1) and torch.all(sd["model.enc.32x32_conv.bias"] == 0)
+    w = sd["model.enc.32x32_block0.conv0.weight"]
+    bound = (6 / (128 * 9 + 256 * 9)) ** 0.5
+    assert w.abs().max() <= bound and w.abs().max() > 0.9 * bound
+    assert sd["model.enc.16x16_down.conv0.resample_filter"].tolist() == [[[[0.25, 0.25], [0.25, 0.25]]]]
+
+
+def test_module_surface(net):
+    assert net.net_pred_type == "x0" and net.schedule_type == "edm" and net.label_dim == 10
+    assert isinstance(net.noise_scheduler, EDMNoiseSchedule)
+    assert net.noise_scheduler.max_t == 80.0 and net.noise_scheduler.t_precision == torch.float64
+    assert len(net.noise_scheduler.state_dict()) == 0
+    for attr in ("forward", "sample", "fully_shard", "reset_parameters", "few_step_sample"):
+        assert callable(getattr(net, attr))
+    assert net(torch.zeros(1, 3, 32, 32), torch.ones(1), return_features_early=True) == []
+
+
+def test_constructor_errors():
+    with pytest.raises(ValueError):
+        EDMPrecond(**{**KW, "model_type": "DhariwalUNet"})
+    with pytest.raises(ValueError):
+        EDMPrecond(**{**KW, "drop_precond": "sideways"})
+    with pytest.raises(NotImplementedError):
+        EDMPrecond(**{**KW, "embedding_type": "fourier"})
+    with pytest.raises(ValueError):
+        EDMPrecond(**{**KW, "net_pred_type": "score"})
+    with pytest.raises(KeyError):
+        get_noise_schedule("nope")
+    with pytest.raises(_lib.FastGenAMDError):
+        EDMPrecond(**{**KW, "model_channels": 32})  # 64-wide blocks: kernels are tiled for 256
+
+
+def test_product_path_fails_loudly_without_gpu(net):
+    x, t = torch.zeros(2, 3, 32, 32), torch.ones(2, dtype=torch.float64)
+    with pytest.raises(NotImplementedError):  # autograd requested
+        net(x, t)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="HIP GPU only"):
+            net(x, t)
+        with pytest.raises(RuntimeError, match="HIP GPU only"):
+            FastGenModel.generator_fn(net, x, student_sample_steps=4)
+        with pytest.raises(ValueError):
+            net(x, t, r=t)
+        with pytest.raises(NotImplementedError):
+            net(x, t, feature_indices={0})
+
+
+def test_schedule_mirror_matches_golden(golden_dir):
+    fx = torch.load(os.path.join(golden_dir, "schedule.pt"), weights_only=True)
+    s = EDMNoiseSchedule()
+    assert torch.equal(s.sigmas[:3], fx["sigmas_head"]) and torch.equal(s.sigmas[-3:], fx["sigmas_tail"])
+    for n in (1, 2, 4):
+        assert torch.equal(s.get_t_list(n), fx[f"t_list_{n}"])
+    g = lambda seed: torch.randn((2, 3, 8, 8), generator=torch.Generator().manual_seed(seed))  # noqa: E731
+    x, e = g(11), g(12)
+    t = torch.tensor([17.498123, 0.1726], dtype=torch.float64)
+    assert torch.equal(s.forward_process(x, e, t), fx["fp_out"])
+    assert torch.equal(s.latents(x, t_init=torch.tensor(79.5638, dtype=torch.float64)), fx["lat_out"])
+    assert torch.equal(s.x0_to_eps(x, e, t), fx["x0eps_out"])
+    # round trips of the prediction-type conversions
+    x0 = g(13)
+    xt = s.forward_process(x0, e, t)
+    assert torch.allclose(s.convert_model_output(xt, x0, t, "x0", "eps"), e, atol=2e-3)
+    assert torch.allclose(s.convert_model_output(xt, s.convert_model_output(xt, x0, t, "x0", "flow"), t, "flow", "x0"), x0, atol=1e-4)
+    assert s.convert_model_output(xt, x0, t, "x0", "x0") is x0
+    with pytest.raises(AssertionError):
+        s.convert_model_output(xt, x0, t, "x0", "v")
+    with pytest.raises(AssertionError):
+        s.forward_process(x, e, torch.tensor([100.0, 1.0], dtype=torch.float64))
+
+
+class _FakeNet(torch.nn.Module):
+    """FastGenNetwork-shaped CPU module for the generic (non-fused) sampler loop."""
+
+    def __init__(self):
+        super().__init__()
+        self.noise_scheduler = EDMNoiseSchedule()
+        self.calls = []
+
+    def forward(self, x, t, condition=None, fwd_pred_type=None):
+        self.calls.append((t.clone(), self.training, torch.is_inference_mode_enabled()))
+        return 0.5 * x / (1 + t.float().reshape(-1, 1, 1, 1))
+
+
+def test_generic_sampler_loop_matches_reference_semantics():
+    net = _FakeNet().train()
+    noise = torch.randn(3, 3, 8, 8, generator=torch.Generator().manual_seed(0))
+    out = FastGenModel.generator_fn(net, noise, student_sample_steps=4, student_sample_type="ode")
+    assert net.training  # restored
+    assert len(net.calls) == 4 and all((not tr) and inf for _, tr, inf in net.calls)
+    tl = EDMNoiseSchedule().get_t_list(4)
+    assert all(torch.equal(c[0], tl[i].expand(3)) for i, c in enumerate(net.calls))
+    # same loop written out with the oracle's schedule functions
+    x = R.latents(noise, tl[0])
+    for t_cur, t_next in zip(tl[:-1], tl[1:]):
+        xp = 0.5 * x / (1 + t_cur.float())
+        if t_next > 0:
+            x = R.forward_process(xp, R.x0_to_eps(x, xp, t_cur.expand(3)), t_next.expand(3))
+    assert torch.equal(out, xp)
+    with pytest.raises(AssertionError):
+        FastGenModel.generator_fn(net, noise, student_sample_steps=2, t_list=[10.0, 1.0, 0.5])
+    with pytest.raises(NotImplementedError):
+        FastGenModel.generator_fn(net, noise, student_sample_steps=2, student_sample_type="euler")
