@@ -51,7 +51,7 @@ __device__ __forceinline__ Frag8<float> load_v(const float* row, int key0) {
 
 template <typename T, int NT>  // NT = T/32 key tiles
 __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q, const T* __restrict__ k,
-                                                        const T* __restrict__ vt, float* __restrict__ out, int B) {
+                                                        const T* __restrict__ vt, T* __restrict__ out, int B) {
     constexpr int Tn = NT * 32;
     constexpr int D = 256;
     constexpr bool FAST = DT<T>::FAST;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
 
     // ---- O[query][dim] = sum_key P[query][key] V[key][dim], four 32-wide dim tiles at a time ---------------
     const T* vbase = vt + ((size_t)n * D + r) * Tn + 4 * h;
-    float* obase = out + ((size_t)n * Tn + q0) * D + r;
+    T* obase = out + ((size_t)n * Tn + q0) * D + r;
 #pragma unroll 1
     for (int dg = 0; dg < D / 128; ++dg) {
         f32x16 o[4];
@@ -130,27 +130,27 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) obase[(size_t)acc_row(i, h) * D + dg * 128 + d * 32] = o[d][i];
+            for (int i = 0; i < 16; ++i) obase[(size_t)acc_row(i, h) * D + dg * 128 + d * 32] = (T)o[d][i];
     }
 }
 
 }  // namespace
 
-int launch_attention(int dtype, const void* q, const void* k, const void* vt, float* out, int B, int T, hipStream_t s) {
+int launch_attention(int dtype, const void* q, const void* k, const void* vt, void* out, int B, int T, hipStream_t s) {
     if (T != 256 && T != 64) return (int)hipErrorInvalidValue;
     const int nt = T / 32;
     const int waves = B * nt;
     dim3 grid((waves + 3) / 4), block(256);
     if (dtype) {
         if (nt == 8)
-            hipLaunchKernelGGL((attention_kernel<__bf16, 8>), grid, block, 0, s, (const __bf16*)q, (const __bf16*)k, (const __bf16*)vt, out, B);
+            hipLaunchKernelGGL((attention_kernel<__bf16, 8>), grid, block, 0, s, (const __bf16*)q, (const __bf16*)k, (const __bf16*)vt, (__bf16*)out, B);
         else
-            hipLaunchKernelGGL((attention_kernel<__bf16, 2>), grid, block, 0, s, (const __bf16*)q, (const __bf16*)k, (const __bf16*)vt, out, B);
+            hipLaunchKernelGGL((attention_kernel<__bf16, 2>), grid, block, 0, s, (const __bf16*)q, (const __bf16*)k, (const __bf16*)vt, (__bf16*)out, B);
     } else {
         if (nt == 8)
-            hipLaunchKernelGGL((attention_kernel<float, 8>), grid, block, 0, s, (const float*)q, (const float*)k, (const float*)vt, out, B);
+            hipLaunchKernelGGL((attention_kernel<float, 8>), grid, block, 0, s, (const float*)q, (const float*)k, (const float*)vt, (float*)out, B);
         else
-            hipLaunchKernelGGL((attention_kernel<float, 2>), grid, block, 0, s, (const float*)q, (const float*)k, (const float*)vt, out, B);
+            hipLaunchKernelGGL((attention_kernel<float, 2>), grid, block, 0, s, (const float*)q, (const float*)k, (const float*)vt, (float*)out, B);
     }
     return (int)hipGetLastError();
 }

@@ -78,6 +78,23 @@ __device__ __forceinline__ void store_frag(float* p, const float (&x)[8]) {
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{x[4], x[5], x[6], x[7]};
 }
 
+// 4 consecutive activation elements <-> fp32
+__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4(const __bf16* p) {
+    const bf16x4 q = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
+}
+// stores v in the activation dtype and returns the stored values widened back to fp32
+__device__ __forceinline__ f32x4 store4(float* p, f32x4 v) {
+    *reinterpret_cast<f32x4*>(p) = v;
+    return v;
+}
+__device__ __forceinline__ f32x4 store4(__bf16* p, f32x4 v) {
+    const bf16x4 q = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = q;
+    return f32x4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
+}
+
 // SiLU = x * sigmoid(x) (torch.nn.functional.silu, used at EDM/network.py:276,283,520-521,556).
 template <bool FAST>
 __device__ __forceinline__ float silu_f(float x) {

@@ -3,10 +3,10 @@
 #include <hip/hip_runtime.h>
 
 struct ConvArgs {
-    // A operand: NHWC fp32 activations; the input channels are the virtual concat [src1 (C1) | src2 (C2)]
-    // (torch.cat at EDM/network.py:560 never materialises).
-    const float* src1;
-    const float* src2;
+    // A operand: NHWC activations; the input channels are the virtual concat [src1 (C1) | src2 (C2)]
+    // (torch.cat at EDM/network.py:560 never materialises).  Stored in the compute dtype.
+    const void* src1;
+    const void* src2;
     int C1, C2;
     int Hs, Ws;  // source spatial size (before the 2x resample folded into the load)
     int H, W;    // output spatial size (H == W, W in {8,16,32})
@@ -16,10 +16,15 @@ struct ConvArgs {
     const float* bias;  // [Cout] or nullptr
     const float* temb;  // [B][temb_stride] per-image per-channel additive term (affine(emb)), or nullptr
     int temb_stride;
-    const float* resid;  // [B,H,W,Cout] residual added before `scale`, or nullptr
+    const void* resid;   // [B,H,W,Cout] residual (compute dtype) added before `scale`, or nullptr
     float scale;
-    float* out;  // [B,H,W,Cout] fp32 (OUT_NHWC)
+    void* out;  // [B,H,W,Cout] in the compute dtype (OUT_NHWC)
     int Cout;
+    // GroupNorm partial statistics of the OUTPUT tensor, written by the epilogue (or nullptr):
+    // stats[b][slot][c/4] = {sum, sum of squares} over the tile's pixels of channels 4q..4q+3; slots per image =
+    // conv_stat_slots(W).  gn_finalize turns them into the next norm's coefficients without re-reading the tensor.
+    float2* stats;
+    int dbg;  // ablation flags for scripts/conv_ablate.py (0 in production): 1 no staging, 2 no weight refill, 4 no epilogue, 8 no MFMA
     // OUT_QKV: compute-dtype planes q,k: [B][HW][256]; vt: [B][256][HW]
     void* q_out;
     void* k_out;
@@ -30,8 +35,11 @@ enum { PRO_NONE = 0, PRO_GN = 1, PRO_GN_SILU = 2 };
 enum { RES_NONE = 0, RES_DOWN = 1, RES_UP = 2 };
 enum { OUT_NHWC = 0, OUT_QKV = 1 };
 
-// dtype: 0 fp32, 1 bf16.  Returns hipError_t as int.
+// dtype: 0 fp32, 1 bf16 — also the storage type of every activation tensor (src1/src2/resid/out).
+// Returns hipError_t as int.
 int launch_conv_fused(int dtype, int ks, int pro, int res, int outmode, const ConvArgs& a, hipStream_t stream);
+// partial-statistics slots per image for an output of width W (= pixel tiles per image, 1 when a tile spans images)
+int conv_stat_slots(int W);
 // set the dynamic-LDS attribute of every instantiation of this dtype (call once, outside stream capture)
 int conv_prepare_all(int dtype);
 // elements of packed weight storage for a conv with these dims

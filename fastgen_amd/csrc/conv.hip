@@ -1,42 +1,53 @@
-// Fused GroupNorm-apply + SiLU -> Conv2d(3x3 | 1x1) -> bias (+temb) (+residual) * scale, as an implicit GEMM on
-// the CDNA4 matrix cores.  Replaces, per UNetBlock (reference fastgen/networks/EDM/network.py:274-299):
+// Fused GroupNorm-apply + SiLU -> Conv2d(3x3 | 1x1) -> bias (+temb) (+residual) * scale (+ GroupNorm partial statistics
+// of the result), as an implicit GEMM on the CDNA4 matrix cores.  Replaces, per UNetBlock (reference
+// fastgen/networks/EDM/network.py:274-299):
 //     conv0(silu(norm0(x))) + affine(emb)        -> PRO_GN_SILU, temb epilogue
 //     (conv1(silu(norm1(h))) + skip) * sqrt(.5)  -> PRO_GN_SILU, residual epilogue
 //     skip / qkv / proj 1x1 convs                -> KS = 1
 // and the resampling of Conv2d.forward (:114-121) folded into the operand load (RES_DOWN = 2x2 mean of the
 // *transformed* input, RES_UP = nearest replication), and torch.cat (:560) as two source pointers.
 //
-// Tiling (one workgroup = 512 threads = 8 waves, one workgroup per CU):
-//   M = 256 output pixels (8 rows x 32 | 16 x 16 | 4 images x 8 x 8), N = 256 output channels, K = taps x Cin.
-//   wave w owns output channels [32w, 32w+32) for all 256 pixels: 8 accumulator tiles of 32x32 (128 VGPRs).
+// Tiling — one workgroup = 256 threads = 4 waves; TWO workgroups are resident per CU (<= 66 KB LDS, 256 VGPRs), so one
+// workgroup's memory-bound prologue/epilogue overlaps the other's MFMA main loop:
+//   M = 128 output pixels (4 rows x 32 | 8 x 16 | 2 images x 8 x 8), N = 256 output channels, K = taps x Cin.
+//   wave w owns output channels [64w, 64w+64) for all 128 pixels: 4 x 2 accumulator tiles of 32x32 (128 VGPRs).
 //   A (activations): per K-chunk of KC input channels the (rows+2) x (W+2) halo of the pixel tile is transformed
-//     ONCE (GN affine + SiLU, cast to the compute dtype) and parked in LDS (144-byte pixel pitch: conflict-free
-//     ds_read_b128); all 9 taps read shifted windows of it.  Double-buffered: chunk c+1 is staged while chunk c
-//     is multiplied, global loads issued before the MFMA block and consumed after it.  One barrier per chunk.
-//   B (weights): pre-packed in MFMA fragment order, read straight from global/L2 into registers one (chunk, tap)
-//     step ahead — each wave reads only its own 32 output channels, so no LDS and no barrier for B.
+//     ONCE (GN affine + SiLU, cast to the compute dtype) and parked in LDS; all 9 taps read shifted windows of it.
+//     144-byte pixel pitch (+ a per-row pad at W = 16 / 8) keeps every ds_read_b128 of a fragment conflict-free.
+//     Double-buffered: chunk c+1 is staged while chunk c is multiplied, global loads issued before the MFMA block and
+//     consumed after it.  One barrier per chunk.
+//   B (weights): pre-packed in MFMA fragment order, read straight from global/L2 into registers and refilled in place
+//     one (chunk, tap) step ahead — each wave reads only its own 64 output channels: no LDS, no barrier for B.
+//   Epilogue: besides the store, each wave reduces sum / sum-of-squares of its outputs per (image, 4-channel quad) and
+//     writes them to a small side buffer, so the NEXT GroupNorm never re-reads the tensor (misc.hip gn_finalize).
 #include "common.h"
 #include "conv.h"
 
 namespace {
 
 constexpr int PITCH = 144;  // bytes per halo pixel in LDS: 128 B of channels + 16 B pad (odd multiple of 16 B)
+constexpr int NTHR = 256;
 
 template <int KS, int LOGW>
 struct Geom {
     static constexpr int W = 1 << LOGW;
-    static constexpr int LOGTH = (LOGW == 4) ? 4 : 3;
+    static constexpr int LOGTH = (LOGW == 5) ? 2 : 3;
     static constexpr int TH = 1 << LOGTH;           // tile rows per image
-    static constexpr int IMGS = 256 / (TH * W);     // images per tile (4 at 8x8, else 1)
-    static constexpr int TPI = (W * W) / (TH * W) > 0 ? (W * W) / (TH * W) : 1;  // tiles per image (square images)
+    static constexpr int IMGS = 128 / (TH * W);     // images per tile (2 at 8x8, else 1)
+    static constexpr int TPI = (IMGS > 1) ? 1 : W / TH;  // tiles (= statistics slots) per image
     static constexpr int PAD = KS / 2;
     static constexpr int HW_ = W + 2 * PAD;
     static constexpr int HH_ = TH + 2 * PAD;
     static constexpr int HALO_PIX = IMGS * HH_ * HW_;
     static constexpr int TAPS = KS * KS;
-    // halo index (tap 0,0) of tile pixel p in [0,256); additive in (p & ~31) and (p & 31)
-    static __host__ __device__ constexpr int hp0(int p) {
-        return (((p >> (LOGW + LOGTH)) * HH_) + ((p >> LOGW) & (TH - 1))) * HW_ + (p & (W - 1));
+    // LDS row stride.  A 32-pixel MFMA row tile spans 1 / 2 / 4 halo rows at W = 32 / 16 / 8; the row stride in 16-byte
+    // slots must be 0 (W=16) or 8 (W=8) mod 16 for the 16-lane ds_read_b128 groups to hit 16 distinct slots.
+    static constexpr int ROWPAD = (LOGW == 5) ? 0 : 16 * ((((LOGW == 4) ? 0 : 8) - (HW_ * 9) % 16 + 32) % 16);
+    static constexpr int RS = HW_ * PITCH + ROWPAD;
+    static constexpr int ABUF = IMGS * HH_ * RS;
+    // LDS byte offset (tap 0,0) of tile pixel p in [0,128); additive in (p & ~31) and (p & 31)
+    static __host__ __device__ constexpr int off0(int p) {
+        return (((p >> (LOGW + LOGTH)) * HH_) + ((p >> LOGW) & (TH - 1))) * RS + (p & (W - 1)) * PITCH;
     }
 };
 
@@ -48,20 +59,35 @@ __device__ __forceinline__ float pro_apply(float x, float2 ab) {
     return y;
 }
 
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(p + 4);
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+}
+__device__ __forceinline__ void load8(const __bf16* p, float (&v)[8]) {
+    const bf16x8 q = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)q[j];
+}
+
+// Activations (sources, residual, output) are stored in the compute dtype T: fp32 in fp32 mode, bf16 in bf16 mode (the
+// reference's own bf16 autocast keeps conv outputs — hence the residual stream — in bf16, EDM/network.py:285-287).
 template <typename T, int KS, int PRO, int RES, int LOGW, int OUTMODE>
-__global__ __launch_bounds__(512, 2) void conv_fused_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
     using G = Geom<KS, LOGW>;
+    using ST = T;
     constexpr int KC = DT<T>::KC;
     constexpr bool FAST = DT<T>::FAST;
     constexpr int KK = KC / 16;   // 16-deep MFMA steps per chunk
     constexpr int OPP = KC / 8;   // 8-channel octets per pixel and chunk
     constexpr int LOG_OPP = (OPP == 8) ? 3 : 2;
-    constexpr int NITEMS = (G::HALO_PIX * OPP + 511) / 512;      // staging items per thread and chunk
-    constexpr int IPS = (NITEMS + G::TAPS - 1) / G::TAPS;        // items staged per (chunk, tap) step
-    constexpr int ABUF = G::HALO_PIX * PITCH;
-    constexpr bool DEFER = (RES != RES_DOWN) && (KS == 3);       // split load / transform+write around the MFMAs
-    constexpr bool AB_REGS = (PRO != PRO_NONE) && (G::IMGS == 1);  // per-chunk GN coefficients live in registers
-    constexpr bool PIPE_A = (sizeof(T) == 2);                      // two A-fragment register sets (bf16 only)
+    constexpr int PSTRIDE = NTHR / OPP;                               // halo pixels covered per staging item
+    constexpr int NITEMS = (G::HALO_PIX * OPP + NTHR - 1) / NTHR;     // staging items per thread and chunk
+    constexpr int IPS = (NITEMS + G::TAPS - 1) / G::TAPS;             // items staged per (chunk, tap) step
+    constexpr bool DEFER = (RES != RES_DOWN) && (KS == 3);            // split load / transform+write around the MFMAs
+    constexpr bool AB_REGS = (PRO != PRO_NONE) && (G::IMGS == 1);     // per-chunk GN coefficients live in registers
+    constexpr bool PIPE_A = (sizeof(T) == 2);                         // two A-fragment register sets (bf16 only)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -76,17 +102,22 @@ __global__ __launch_bounds__(512, 2) void conv_fused_kernel(const ConvArgs a) {
     const int H = a.H;  // == W == G::W
 
     const int n_base = (G::IMGS > 1) ? tile * G::IMGS : tile / G::TPI;
-    const int row0 = (G::IMGS > 1) ? 0 : (tile % G::TPI) * G::TH;
+    const int slot = (G::IMGS > 1) ? 0 : tile % G::TPI;
+    const int row0 = slot * G::TH;
 
-    // this wave's packed weights: [cout/32][step][kk][lane][8]
-    const T* wp = reinterpret_cast<const T*>(a.wpack) + (size_t)(nblk * 8 + wave) * nsteps * (KK * 512) + lane * 8;
+    // this wave's packed weights: [cout/32][step][kk][lane][8], two consecutive 32-channel groups
+    const size_t wstride = (size_t)nsteps * (KK * 512);
+    const T* wp = reinterpret_cast<const T*>(a.wpack) + (size_t)(nblk * 8 + wave * 2) * wstride + lane * 8;
 
-    // staging role of this thread: fixed channel octet, halo pixels hq0 + i*(512/OPP)
+    const ST* src1 = reinterpret_cast<const ST*>(a.src1);
+    const ST* src2 = reinterpret_cast<const ST*>(a.src2);
+
+    // staging role of this thread: fixed channel octet, halo pixels hq0 + i*PSTRIDE
     const int oct = tid & (OPP - 1);
     const int hq0 = tid >> LOG_OPP;
 
     // ---- staging helpers ------------------------------------------------------------------------------
-    auto decode = [&](int hq, int& n, int& y, int& x) -> bool {
+    auto decode = [&](int hq, int& n, int& y, int& x, int& lds_off) -> bool {
         const int hx = hq % G::HW_;
         const int t = hq / G::HW_;
         const int hy = t % G::HH_;
@@ -94,18 +125,13 @@ __global__ __launch_bounds__(512, 2) void conv_fused_kernel(const ConvArgs a) {
         y = row0 + hy - G::PAD;
         x = hx - G::PAD;
         n = n_base + img;
+        lds_off = (img * G::HH_ + hy) * G::RS + hx * PITCH + oct * (8 * (int)sizeof(T));
         return (hq < G::HALO_PIX) && (y >= 0) && (y < H) && (x >= 0) && (x < G::W) && (n < a.B);
     };
-    auto src_ptr = [&](int chunk, int n, int sy, int sx) -> const float* {
+    auto src_ptr = [&](int chunk, int n, int sy, int sx) -> const ST* {
         const int c0 = chunk * KC + oct * 8;
         const size_t sp = ((size_t)n * a.Hs + sy) * a.Ws + sx;
-        return (c0 < a.C1) ? a.src1 + sp * a.C1 + c0 : a.src2 + sp * a.C2 + (c0 - a.C1);
-    };
-    auto load8 = [&](const float* p, float (&v)[8]) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(p);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(p + 4);
-        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return (c0 < a.C1) ? src1 + sp * a.C1 + c0 : src2 + sp * a.C2 + (c0 - a.C1);
     };
     auto load_ab = [&](int chunk, int n, float2 (&ab)[8]) {
         const float2* p = a.ab + (size_t)n * Cin + chunk * KC + oct * 8;
@@ -121,10 +147,10 @@ __global__ __launch_bounds__(512, 2) void conv_fused_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) abr[j] = make_float2(1.f, 0.f);
 
-    // phase 1 of an item: issue the global loads (RES_NONE / RES_UP only)
+    // phase 1 of an item: issue the global loads (3x3, RES_NONE / RES_UP only)
     auto item_load = [&](int chunk, int i, float (&raw)[8], bool& valid) {
-        int n, y, x;
-        valid = decode(hq0 + i * (512 / OPP), n, y, x);
+        int n, y, x, lo;
+        valid = decode(hq0 + i * PSTRIDE, n, y, x, lo);
 #pragma unroll
         for (int j = 0; j < 8; ++j) raw[j] = 0.f;
         if (valid) {
@@ -135,14 +161,16 @@ __global__ __launch_bounds__(512, 2) void conv_fused_kernel(const ConvArgs a) {
     };
     // phase 2: transform and park in LDS
     auto item_finish = [&](int chunk, int i, char* abuf, float (&raw)[8], bool valid) {
-        const int hq = hq0 + i * (512 / OPP);
+        const int hq = hq0 + i * PSTRIDE;
         if (hq >= G::HALO_PIX) return;
+        int n, y, x, lo;
+        const bool ok = decode(hq, n, y, x, lo);
         float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = 0.f;
         if (DEFER) {
             if (valid) {
                 if (PRO != PRO_NONE && !AB_REGS) {
-                    int n, y, x;
-                    decode(hq, n, y, x);
                     float2 ab[8];
                     load_ab(chunk, n, ab);
 #pragma unroll
@@ -151,37 +179,28 @@ __global__ __launch_bounds__(512, 2) void conv_fused_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = pro_apply<PRO, FAST>(raw[j], abr[j]);
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = 0.f;
             }
-        } else {  // synchronous path: RES_DOWN (mean of the four transformed source pixels) and all 1x1 convs
+        } else if (ok) {  // synchronous path: RES_DOWN (mean of the four transformed source pixels) and all 1x1 convs
             constexpr int ND = (RES == RES_DOWN) ? 4 : 1;
-            int n, y, x;
-            const bool ok = decode(hq, n, y, x);
+            float2 ab[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = 0.f;
-            if (ok) {
-                float2 ab[8];
+            for (int j = 0; j < 8; ++j) ab[j] = AB_REGS ? abr[j] : make_float2(1.f, 0.f);
+            if (PRO != PRO_NONE && !AB_REGS) load_ab(chunk, n, ab);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ab[j] = AB_REGS ? abr[j] : make_float2(1.f, 0.f);
-                if (PRO != PRO_NONE && !AB_REGS) load_ab(chunk, n, ab);
+            for (int d = 0; d < ND; ++d) {
+                float v[8];
+                const int sy = (RES == RES_DOWN) ? 2 * y + (d >> 1) : ((RES == RES_UP) ? (y >> 1) : y);
+                const int sx = (RES == RES_DOWN) ? 2 * x + (d & 1) : ((RES == RES_UP) ? (x >> 1) : x);
+                load8(src_ptr(chunk, n, sy, sx), v);
 #pragma unroll
-                for (int d = 0; d < ND; ++d) {
-                    float v[8];
-                    const int sy = (RES == RES_DOWN) ? 2 * y + (d >> 1) : ((RES == RES_UP) ? (y >> 1) : y);
-                    const int sx = (RES == RES_DOWN) ? 2 * x + (d & 1) : ((RES == RES_UP) ? (x >> 1) : x);
-                    load8(src_ptr(chunk, n, sy, sx), v);
+                for (int j = 0; j < 8; ++j) o[j] += pro_apply<PRO, FAST>(v[j], ab[j]);
+            }
+            if (ND == 4) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] += pro_apply<PRO, FAST>(v[j], ab[j]);
-                }
-                if (ND == 4) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] *= 0.25f;
-                }
+                for (int j = 0; j < 8; ++j) o[j] *= 0.25f;
             }
         }
-        store_frag(reinterpret_cast<T*>(abuf + hq * PITCH) + oct * 8, o);
+        store_frag(reinterpret_cast<T*>(abuf + lo), o);
     };
 
     // ---- prologue: chunk 0 of A, step 0 of B ------------------------------------------------------
@@ -193,34 +212,39 @@ __global__ __launch_bounds__(512, 2) void conv_fused_kernel(const ConvArgs a) {
         if (DEFER) item_load(0, i, raw, valid);
         item_finish(0, i, smem, raw, valid);
     }
-    Frag8<T> bcur[KK];
+    Frag8<T> b0[KK], b1[KK];
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) bcur[kk] = load_frag(wp + kk * 512);
+    for (int kk = 0; kk < KK; ++kk) {
+        b0[kk] = load_frag(wp + kk * 512);
+        b1[kk] = load_frag(wp + wstride + kk * 512);
+    }
 
-    f32x16 acc[8];
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
-    const int lane_off = G::hp0(r) * PITCH + h * (8 * (int)sizeof(T));
+    const int lane_off = G::off0(r) + h * (8 * (int)sizeof(T));
     __syncthreads();
 
     // ---- main loop ------------------------------------------------------------------------------------
     int step = 0;
     for (int chunk = 0; chunk < nchunk; ++chunk) {
-        const char* abuf = smem + (chunk & 1) * ABUF;
-        char* anext = smem + ((chunk + 1) & 1) * ABUF;
+        const char* abuf = smem + (chunk & 1) * G::ABUF;
+        char* anext = smem + ((chunk + 1) & 1) * G::ABUF;
         const bool stage_next = (chunk + 1 < nchunk);
 #pragma unroll 1
         for (int tap = 0; tap < G::TAPS; ++tap, ++step) {
             // (1) weights: each fragment is refilled in place for the NEXT step right after its last use below
-            //     (clamped: the last step re-reads itself), so B needs KK fragments, one step of prefetch distance
+            //     (clamped: the last step re-reads itself), so B needs 2*KK fragments with one step of prefetch distance
             const T* pnext = wp + (size_t)((step + 1 < nsteps) ? step + 1 : step) * (KK * 512);
             // (2) issue this step's share of the next chunk's activation loads
             float raw[IPS][8];
             bool valid[IPS];
-            const bool do_stage = stage_next && (tap * IPS < NITEMS);
+            const bool do_stage = stage_next && (tap * IPS < NITEMS) && !(a.dbg & 1);
             if (do_stage) {
                 if (AB_REGS && tap == 0) load_ab(chunk + 1, n_base, abr);
                 if (DEFER) {
@@ -228,43 +252,49 @@ __global__ __launch_bounds__(512, 2) void conv_fused_kernel(const ConvArgs a) {
                     for (int q = 0; q < IPS; ++q) item_load(chunk + 1, tap * IPS + q, raw[q], valid[q]);
                 }
             }
-            // (3) multiply: 8 pixel tiles x KK k-steps against this wave's 32 output channels.  The 8 A fragments of
-            //     a k-step are read from LDS as one group (latency paid once per group, not per MFMA); with bf16
-            //     operands the next k-step's group is issued before this k-step's 8 back-to-back MFMAs.
-            const int tap_off = ((tap / KS) * G::HW_ + (tap % KS)) * PITCH;
+            // (3) multiply: 4 pixel tiles x 2 channel tiles x KK k-steps.  The 4 A fragments of a k-step are read from LDS
+            //     as one group; with bf16 operands the next k-step's group is issued before this k-step's 8 MFMAs.
+            const int tap_off = (tap / KS) * G::RS + (tap % KS) * PITCH;
             const char* abase = abuf + lane_off + tap_off;
-            auto read_a = [&](int kk, Frag8<T> (&af)[8]) {
+            auto read_a = [&](int kk, Frag8<T> (&af)[4]) {
 #pragma unroll
-                for (int mt = 0; mt < 8; ++mt)
-                    af[mt] = load_frag(reinterpret_cast<const T*>(abase + G::hp0(mt * 32) * PITCH) + kk * 16);
+                for (int mt = 0; mt < 4; ++mt)
+                    af[mt] = load_frag(reinterpret_cast<const T*>(abase + G::off0(mt * 32)) + kk * 16);
             };
-            if (PIPE_A) {
-                Frag8<T> a0[8], a1[8];
+            auto mma8 = [&](int kk, const Frag8<T> (&af)[4]) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    mma16(acc[mt][0], af[mt], b0[kk]);
+                    mma16(acc[mt][1], af[mt], b1[kk]);
+                }
+                if (!(a.dbg & 2)) {
+                    b0[kk] = load_frag(pnext + kk * 512);
+                    b1[kk] = load_frag(pnext + wstride + kk * 512);
+                }
+            };
+            if (a.dbg & 8) {
+                // ablation: no LDS reads, no MFMAs
+            } else if (PIPE_A) {
+                Frag8<T> a0[4], a1[4];
                 read_a(0, a0);
 #pragma unroll
                 for (int kk = 0; kk < KK; kk += 2) {
                     read_a(kk + 1, a1);
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int mt = 0; mt < 8; ++mt) mma16(acc[mt], a0[mt], bcur[kk]);
-                    bcur[kk] = load_frag(pnext + kk * 512);
+                    mma8(kk, a0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (kk + 2 < KK) read_a(kk + 2, a0);
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int mt = 0; mt < 8; ++mt) mma16(acc[mt], a1[mt], bcur[kk + 1]);
-                    bcur[kk + 1] = load_frag(pnext + (kk + 1) * 512);
+                    mma8(kk + 1, a1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk) {
-                    Frag8<T> af[8];
+                    Frag8<T> af[4];
                     read_a(kk, af);
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int mt = 0; mt < 8; ++mt) mma16(acc[mt], af[mt], bcur[kk]);
-                    bcur[kk] = load_frag(pnext + kk * 512);
+                    mma8(kk, af);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -279,50 +309,101 @@ __global__ __launch_bounds__(512, 2) void conv_fused_kernel(const ConvArgs a) {
     }
 
     // ---- epilogue -------------------------------------------------------------------------------------
-    const int cl = wave * 32 + r;  // channel within this 256-wide block
     const int HWo = H * G::W;
+    if (a.dbg & 4) {  // ablation: keep the accumulators live, store (almost) nothing
+        float t = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t += acc[mt][nt][i];
+        if (t == 1234.5678f) reinterpret_cast<float*>(a.out)[0] = t;
+        return;
+    }
     if (OUTMODE == OUT_NHWC) {
-        const int co = nblk * 256 + cl;
-        const float bias = a.bias ? a.bias[co] : 0.f;
+        // Transpose each 32-pixel x 64-channel accumulator slab through this wave's private LDS scratch (the A buffers
+        // are dead after the last barrier) so that global traffic is row-contiguous: a lane owns one channel QUAD of one
+        // pixel (16 B fp32 / 8 B bf16 per access), 16 lanes cover a pixel's 64 channels, 4 pixels per wave instruction.
+        constexpr int EP_PITCH = 64 * 4 + 16;
+        constexpr int MT_PER_IMG = 4 / G::IMGS;
+        static_assert(4 * 32 * EP_PITCH <= 2 * G::ABUF, "epilogue scratch must fit in the A buffers");
+        char* ep = smem + wave * (32 * EP_PITCH);
+        const int c4 = lane & 15, prow = lane >> 4;
+        const int co0 = nblk * 256 + wave * 64 + c4 * 4;
+        T* out = reinterpret_cast<T*>(a.out);
+        const T* resid = reinterpret_cast<const T*>(a.resid);
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + co0);
+        float ssum[G::IMGS], ssq[G::IMGS];
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
+        for (int im = 0; im < G::IMGS; ++im) ssum[im] = ssq[im] = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int p = mt * 32 + acc_row(i, h);
+        for (int mt = 0; mt < 4; ++mt) {
+            const int im = mt / MT_PER_IMG;
+            const int n = n_base + im;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    *reinterpret_cast<float*>(ep + acc_row(i, h) * EP_PITCH + (nt * 32 + r) * 4) = acc[mt][nt][i];
+            f32x4 add = bias4;
+            if (a.temb && n < a.B) add += *reinterpret_cast<const f32x4*>(a.temb + (size_t)n * a.temb_stride + co0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int pl = j * 4 + prow;
+                f32x4 v = *reinterpret_cast<const f32x4*>(ep + pl * EP_PITCH + c4 * 16);
+                const int p = mt * 32 + pl;
                 const int x = p & (G::W - 1);
                 const int y = row0 + ((p >> LOGW) & (G::TH - 1));
-                const int n = n_base + (p >> (LOGW + G::LOGTH));
                 if (n < a.B) {
-                    const size_t gp = ((size_t)n * H + y) * G::W + x;
-                    float v = acc[mt][i] + bias;
-                    if (a.temb) v += a.temb[(size_t)n * a.temb_stride + co];
-                    if (a.resid) v += a.resid[gp * a.Cout + co];
-                    a.out[gp * a.Cout + co] = v * a.scale;
+                    const size_t go = (((size_t)n * H + y) * G::W + x) * a.Cout + co0;
+                    v += add;
+                    if (resid) v += load4(resid + go);
+                    v *= a.scale;
+                    const f32x4 vr = store4(out + go, v);  // the values as the consumer will read them
+                    ssum[im] += (vr[0] + vr[1]) + (vr[2] + vr[3]);
+                    ssq[im] += (vr[0] * vr[0] + vr[1] * vr[1]) + (vr[2] * vr[2] + vr[3] * vr[3]);
                 }
             }
         }
+        if (a.stats) {
+#pragma unroll
+            for (int im = 0; im < G::IMGS; ++im) {
+                float sv = ssum[im], qv = ssq[im];
+                sv += __shfl_xor(sv, 16); qv += __shfl_xor(qv, 16);
+                sv += __shfl_xor(sv, 32); qv += __shfl_xor(qv, 32);
+                const int n = n_base + im;
+                if (prow == 0 && n < a.B)
+                    a.stats[((size_t)n * G::TPI + slot) * (a.Cout >> 2) + (co0 >> 2)] = make_float2(sv, qv);
+            }
+        }
     } else {  // OUT_QKV: plane nblk of {q, k, v^T} in the compute dtype
-        const float bias = a.bias ? a.bias[nblk * 256 + cl] : 0.f;
         T* qk = reinterpret_cast<T*>(nblk == 0 ? a.q_out : a.k_out);
         T* vt = reinterpret_cast<T*>(a.vt_out);
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
+        for (int nt = 0; nt < 2; ++nt) {
+            const int cl = wave * 64 + nt * 32 + r;
+            const float bias = a.bias ? a.bias[nblk * 256 + cl] : 0.f;
 #pragma unroll
-            for (int i4 = 0; i4 < 16; i4 += 4) {
-                const int p = mt * 32 + acc_row(i4, h);  // 4 consecutive pixels p..p+3 (same row)
-                const int x = p & (G::W - 1);
-                const int y = row0 + ((p >> LOGW) & (G::TH - 1));
-                const int n = n_base + (p >> (LOGW + G::LOGTH));
-                if (n < a.B) {
-                    const int pix = y * G::W + x;
-                    if (nblk < 2) {
+            for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
-                        for (int d = 0; d < 4; ++d)
-                            qk[((size_t)n * HWo + pix + d) * 256 + cl] = (T)(acc[mt][i4 + d] + bias);
-                    } else {
-                        T* dst = vt + ((size_t)n * 256 + cl) * HWo + pix;
+                for (int i4 = 0; i4 < 16; i4 += 4) {
+                    const int p = mt * 32 + acc_row(i4, h);  // 4 consecutive pixels p..p+3 (same row)
+                    const int x = p & (G::W - 1);
+                    const int y = row0 + ((p >> LOGW) & (G::TH - 1));
+                    const int n = n_base + (p >> (LOGW + G::LOGTH));
+                    if (n < a.B) {
+                        const int pix = y * G::W + x;
+                        if (nblk < 2) {
 #pragma unroll
-                        for (int d = 0; d < 4; ++d) dst[d] = (T)(acc[mt][i4 + d] + bias);
+                            for (int d = 0; d < 4; ++d)
+                                qk[((size_t)n * HWo + pix + d) * 256 + cl] = (T)(acc[mt][nt][i4 + d] + bias);
+                        } else {
+                            T* dst = vt + ((size_t)n * 256 + cl) * HWo + pix;
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) dst[d] = (T)(acc[mt][nt][i4 + d] + bias);
+                        }
                     }
                 }
             }
@@ -363,7 +444,7 @@ template <typename T, int KS, int PRO, int RES, int LOGW, int OUTMODE>
 int launch_one(const ConvArgs& a, hipStream_t stream) {
     using G = Geom<KS, LOGW>;
     const int tiles = (G::IMGS > 1) ? (a.B + G::IMGS - 1) / G::IMGS : a.B * G::TPI;
-    const size_t lds = 2 * (size_t)G::HALO_PIX * PITCH;
+    const size_t lds = 2 * (size_t)G::ABUF;
     auto kern = conv_fused_kernel<T, KS, PRO, RES, LOGW, OUTMODE>;
     static bool attr_done = false;  // raise the dynamic-LDS cap once per instantiation (never inside stream capture)
     if (!attr_done) {
@@ -373,7 +454,7 @@ int launch_one(const ConvArgs& a, hipStream_t stream) {
     }
     if (g_prepare_only) return 0;
     dim3 grid(tiles, a.Cout / 256);
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, stream, a);
     return (int)hipGetLastError();
 }
 
@@ -421,6 +502,8 @@ int launch_conv_fused(int dtype, int ks, int pro, int res, int outmode, const Co
     return dtype ? launch_t<__bf16>(ks, pro, res, outmode, a, stream) : launch_t<float>(ks, pro, res, outmode, a, stream);
 }
 
+int conv_stat_slots(int W) { return W == 32 ? Geom<3, 5>::TPI : (W == 16 ? Geom<3, 4>::TPI : Geom<3, 3>::TPI); }
+
 int conv_prepare_all(int dtype) {
     g_prepare_only = true;
     int rc = 0;
@@ -431,15 +514,11 @@ int conv_prepare_all(int dtype) {
     for (int wi = 0; wi < 3 && !rc; ++wi) {
         a.W = a.H = ws[wi];
         for (int res = 0; res < 3 && !rc; ++res) {
-            if (dtype) {
-                rc = launch_t<__bf16>(3, PRO_GN_SILU, res, OUT_NHWC, a, nullptr);
-                if (!rc) rc = launch_t<__bf16>(1, PRO_NONE, res, OUT_NHWC, a, nullptr);
-            } else {
-                rc = launch_t<float>(3, PRO_GN_SILU, res, OUT_NHWC, a, nullptr);
-                if (!rc) rc = launch_t<float>(1, PRO_NONE, res, OUT_NHWC, a, nullptr);
-            }
+            rc = dtype ? launch_t<__bf16>(3, PRO_GN_SILU, res, OUT_NHWC, a, nullptr) : launch_t<float>(3, PRO_GN_SILU, res, OUT_NHWC, a, nullptr);
+            if (!rc) rc = dtype ? launch_t<__bf16>(1, PRO_NONE, res, OUT_NHWC, a, nullptr) : launch_t<float>(1, PRO_NONE, res, OUT_NHWC, a, nullptr);
         }
-        if (!rc && a.W <= 16) rc = dtype ? launch_t<__bf16>(1, PRO_GN, RES_NONE, OUT_QKV, a, nullptr) : launch_t<float>(1, PRO_GN, RES_NONE, OUT_QKV, a, nullptr);
+        if (!rc && a.W <= 16)
+            rc = dtype ? launch_t<__bf16>(1, PRO_GN, RES_NONE, OUT_QKV, a, nullptr) : launch_t<float>(1, PRO_GN, RES_NONE, OUT_QKV, a, nullptr);
     }
     g_prepare_only = false;
     return rc;

@@ -75,11 +75,21 @@ struct Arena {
     }
 };
 
+// An NHWC activation plus the GroupNorm partial statistics its producing conv left behind (st == nullptr: none, the
+// consumer falls back to a full statistics pass over the tensor).
+struct Act {
+    void* p = nullptr;  // compute dtype (fp32 / bf16)
+    float2* st = nullptr;
+    int slots = 0;
+};
+
 struct Workspace {
     float *coef, *emb0, *emb1, *emb, *temb;
     float2 *ab0, *ab1, *ab2;
-    std::vector<float*> skip;  // encoder outputs
-    float *xa, *xb, *h, *sbuf, *xattn, *aout;
+    std::vector<Act> skip;  // encoder outputs
+    Act xa, xb, h, xattn;
+    void *sbuf, *aout;
+    void *cvt1, *cvt2;  // fg_edm_run_block: caller's fp32 tensors converted to the activation dtype
     void *q, *k, *vt;
     // sampler state
     float *x, *x_pred, *eps;
@@ -330,14 +340,23 @@ size_t plan_workspace(const fg_edm* h, int B, Arena& A, Workspace& w) {
     w.ab0 = A.get<float2>((size_t)B * max_c);
     w.ab1 = A.get<float2>((size_t)B * max_c);
     w.ab2 = A.get<float2>((size_t)B * max_c);
+    const size_t st_elems = (size_t)B * 8 * 64;  // [B][<= 8 slots][256/4 quads]
+    auto act = [&](size_t elems) {
+        Act a;
+        a.p = A.take(elems * tsz);
+        a.st = A.get<float2>(st_elems);
+        return a;
+    };
     w.skip.clear();
-    for (const Block& b : h->enc) w.skip.push_back(A.get<float>((size_t)B * b.res_out * b.res_out * b.cout));
-    w.xa = A.get<float>((size_t)B * max_act);
-    w.xb = A.get<float>((size_t)B * max_act);
-    w.h = A.get<float>((size_t)B * max_act);
-    w.sbuf = A.get<float>((size_t)B * max_act);
-    w.xattn = A.get<float>((size_t)B * max_attn_hw * 256);
-    w.aout = A.get<float>((size_t)B * max_attn_hw * 256);
+    for (const Block& b : h->enc) w.skip.push_back(act((size_t)B * b.res_out * b.res_out * b.cout));
+    w.xa = act((size_t)B * max_act);
+    w.xb = act((size_t)B * max_act);
+    w.h = act((size_t)B * max_act);
+    w.sbuf = A.take((size_t)B * max_act * tsz);
+    w.cvt1 = A.take((size_t)B * max_act * 4 * tsz);  // run_block inputs: up to 512 channels at the input resolution
+    w.cvt2 = A.take((size_t)B * max_act * 4 * tsz);
+    w.xattn = act((size_t)B * max_attn_hw * 256);
+    w.aout = A.take((size_t)B * max_attn_hw * 256 * tsz);
     w.q = A.take((size_t)B * max_attn_hw * 256 * tsz);
     w.k = A.take((size_t)B * max_attn_hw * 256 * tsz);
     w.vt = A.take((size_t)B * max_attn_hw * 256 * tsz);
@@ -377,52 +396,68 @@ int conv_launch(fg_edm* h, int ks, int pro, int res, int outmode, const ConvArgs
 const float kSkipScale = (float)std::sqrt(0.5);  // block_kwargs.skip_scale, EDM/network.py:385
 const float kBlockEps = 1e-6f;                   // block_kwargs.eps :386, aux_norm :483
 
-// One UNetBlock (EDM/network.py:274-299) as 3-8 kernel launches.
-int run_block(fg_edm* h, const Block& b, const float* x1, int c1, const float* x2, int c2, const float* temb,
-              float* out, int B, Workspace& w, hipStream_t s) {
+// GroupNorm coefficients of the virtual concat [x1 | x2]: from the producers' partial statistics when every source
+// has them, else one full pass over the tensor(s).
+int norm_coeffs(int dtype, const Act& x1, int c1, const Act& x2, int c2, const float* gamma, const float* beta, float2* ab,
+                int B, int hw, hipStream_t s) {
+    if (x1.st && (!c2 || x2.st))
+        HIP_TRY(launch_gn_finalize(x1.st, c1, x1.slots, c2 ? x2.st : nullptr, c2, c2 ? x2.slots : 0, gamma, beta, kBlockEps, ab, B, hw, s));
+    else
+        HIP_TRY(launch_gn_coeffs(dtype, x1.p, c1, c2 ? x2.p : nullptr, c2, gamma, beta, kBlockEps, ab, B, hw, s));
+    return FG_OK;
+}
+
+// One UNetBlock (EDM/network.py:274-299) as 5-10 kernel launches.  `out.st` receives the block output's statistics.
+int run_block(fg_edm* h, const Block& b, const Act& x1, int c1, const Act& x2, int c2, const float* temb, Act& out, int B,
+              Workspace& w, hipStream_t s) {
     if (c1 + c2 != b.cin) return fail(FG_EINVAL, "%s: got %d+%d input channels, expected %d", b.key.c_str(), c1, c2, b.cin);
-    const int hw_in = b.res_in * b.res_in;
+    const int hw_in = b.res_in * b.res_in, hw = b.res_out * b.res_out;
     const int res_mode = b.down ? RES_DOWN : (b.up ? RES_UP : RES_NONE);
+    const int slots = conv_stat_slots(b.res_out);
+    int rc;
     // h = conv0(silu(norm0(x))) + affine(emb)
-    HIP_TRY(launch_gn_coeffs(x1, c1, x2, c2, h->P(b.norm0_w), h->P(b.norm0_b), kBlockEps, w.ab0, B, hw_in, s));
+    if ((rc = norm_coeffs(h->dtype, x1, c1, x2, c2, h->P(b.norm0_w), h->P(b.norm0_b), w.ab0, B, hw_in, s))) return rc;
     ConvArgs a{};
-    a.src1 = x1; a.src2 = x2; a.C1 = c1; a.C2 = c2;
+    a.src1 = x1.p; a.src2 = c2 ? x2.p : nullptr; a.C1 = c1; a.C2 = c2;
     a.Hs = a.Ws = b.res_in; a.H = a.W = b.res_out; a.B = B;
     a.ab = w.ab0; a.wpack = b.p_conv0; a.bias = h->P(b.conv0_b);
     a.temb = temb + b.temb_off; a.temb_stride = h->temb_total;
-    a.resid = nullptr; a.scale = 1.0f; a.out = w.h; a.Cout = b.cout;
+    a.resid = nullptr; a.scale = 1.0f; a.out = w.h.p; a.Cout = b.cout; a.stats = w.h.st;
     HIP_TRY(conv_launch(h, 3, PRO_GN_SILU, res_mode, OUT_NHWC, a, s));
+    w.h.slots = slots;
     // skip path
-    const float* resid = x1;
+    const void* resid = x1.p;
     if (b.has_skip) {
         ConvArgs k{};
-        k.src1 = x1; k.src2 = x2; k.C1 = c1; k.C2 = c2;
+        k.src1 = x1.p; k.src2 = c2 ? x2.p : nullptr; k.C1 = c1; k.C2 = c2;
         k.Hs = k.Ws = b.res_in; k.H = k.W = b.res_out; k.B = B;
         k.wpack = b.p_skip; k.bias = h->P(b.skip_b); k.scale = 1.0f; k.out = w.sbuf; k.Cout = b.cout;
         HIP_TRY(conv_launch(h, 1, PRO_NONE, res_mode, OUT_NHWC, k, s));
         resid = w.sbuf;
     }
     // x = (conv1(silu(norm1(h))) + skip) * sqrt(.5)
-    const int hw = b.res_out * b.res_out;
-    HIP_TRY(launch_gn_coeffs(w.h, b.cout, nullptr, 0, h->P(b.norm1_w), h->P(b.norm1_b), kBlockEps, w.ab1, B, hw, s));
-    float* x_mid = b.attn ? w.xattn : out;
+    HIP_TRY(launch_gn_finalize(w.h.st, b.cout, slots, nullptr, 0, 0, h->P(b.norm1_w), h->P(b.norm1_b), kBlockEps, w.ab1, B, hw, s));
+    Act& x_mid = b.attn ? w.xattn : out;
     ConvArgs d{};
-    d.src1 = w.h; d.C1 = b.cout; d.Hs = d.Ws = d.H = d.W = b.res_out; d.B = B;
+    d.src1 = w.h.p; d.C1 = b.cout; d.Hs = d.Ws = d.H = d.W = b.res_out; d.B = B;
     d.ab = w.ab1; d.wpack = b.p_conv1; d.bias = h->P(b.conv1_b);
-    d.resid = resid; d.scale = kSkipScale; d.out = x_mid; d.Cout = b.cout;
+    d.resid = resid; d.scale = kSkipScale; d.out = x_mid.p; d.Cout = b.cout; d.stats = x_mid.st;
     HIP_TRY(conv_launch(h, 3, PRO_GN_SILU, RES_NONE, OUT_NHWC, d, s));
+    x_mid.slots = slots;
     if (b.attn) {
-        HIP_TRY(launch_gn_coeffs(x_mid, b.cout, nullptr, 0, h->P(b.norm2_w), h->P(b.norm2_b), kBlockEps, w.ab2, B, hw, s));
+        HIP_TRY(launch_gn_finalize(x_mid.st, b.cout, slots, nullptr, 0, 0, h->P(b.norm2_w), h->P(b.norm2_b), kBlockEps, w.ab2, B, hw, s));
         ConvArgs q{};
-        q.src1 = x_mid; q.C1 = b.cout; q.Hs = q.Ws = q.H = q.W = b.res_out; q.B = B;
+        q.src1 = x_mid.p; q.C1 = b.cout; q.Hs = q.Ws = q.H = q.W = b.res_out; q.B = B;
         q.ab = w.ab2; q.wpack = b.p_qkv; q.bias = b.qkv_bias; q.scale = 1.0f; q.Cout = 3 * b.cout;
         q.q_out = w.q; q.k_out = w.k; q.vt_out = w.vt;
         HIP_TRY(conv_launch(h, 1, PRO_GN, RES_NONE, OUT_QKV, q, s));
         HIP_TRY(launch_attention(h->dtype, w.q, w.k, w.vt, w.aout, B, hw, s));
         ConvArgs p{};
         p.src1 = w.aout; p.C1 = b.cout; p.Hs = p.Ws = p.H = p.W = b.res_out; p.B = B;
-        p.wpack = b.p_proj; p.bias = h->P(b.proj_b); p.resid = x_mid; p.scale = kSkipScale; p.out = out; p.Cout = b.cout;
+        p.wpack = b.p_proj; p.bias = h->P(b.proj_b); p.resid = x_mid.p; p.scale = kSkipScale; p.out = out.p; p.Cout = b.cout;
+        p.stats = out.st;
         HIP_TRY(conv_launch(h, 1, PRO_NONE, RES_NONE, OUT_NHWC, p, s));
+        out.slots = slots;
     }
     return FG_OK;
 }
@@ -447,35 +482,36 @@ int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, cons
     int rc = run_mapping(h, labels, B, w, s);
     if (rc) return rc;
     // encoder
-    const float* x = nullptr;
+    const Act none;
+    const Act* x = nullptr;
     for (size_t i = 0; i < h->enc.size(); ++i) {
         const Block& b = h->enc[i];
         if (b.kind == K_STEM) {
-            HIP_TRY(launch_conv_in(x_t, w.coef, h->P(b.w), h->P(b.b), w.skip[i], B, b.res_out, b.cin, b.cout, s));
+            HIP_TRY(launch_conv_in(h->dtype, x_t, w.coef, h->P(b.w), h->P(b.b), w.skip[i].p, B, b.res_out, b.cin, b.cout, s));
+            w.skip[i].st = nullptr;  // the stem leaves no statistics: block0's norm0 takes the full-pass fallback
         } else {
-            rc = run_block(h, b, x, b.cin, nullptr, 0, w.temb, w.skip[i], B, w, s);
+            rc = run_block(h, b, *x, b.cin, none, 0, w.temb, w.skip[i], B, w, s);
             if (rc) return rc;
         }
-        x = w.skip[i];
+        x = &w.skip[i];
     }
     // decoder (skip stack popped from the back; concat is virtual)
     int sp = (int)h->enc.size();
-    float* pong[2] = {w.xa, w.xb};
+    Act* pong[2] = {&w.xa, &w.xb};
     int cur = 0;
     const float2* aux_ab = nullptr;
     for (const Block& b : h->dec) {
         if (b.kind == K_BLOCK) {
-            const float* x2 = nullptr;
-            if (b.skip_c) x2 = w.skip[--sp];
-            rc = run_block(h, b, x, b.cin - b.skip_c, x2, b.skip_c, w.temb, pong[cur], B, w, s);
+            const Act& x2 = b.skip_c ? w.skip[--sp] : none;
+            rc = run_block(h, b, *x, b.cin - b.skip_c, x2, b.skip_c, w.temb, *pong[cur], B, w, s);
             if (rc) return rc;
             x = pong[cur];
             cur ^= 1;
         } else if (b.kind == K_AUX_NORM) {
-            HIP_TRY(launch_gn_coeffs(x, b.cin, nullptr, 0, h->P(b.w), h->P(b.b), kBlockEps, w.ab0, B, b.res_in * b.res_in, s));
+            if ((rc = norm_coeffs(h->dtype, *x, b.cin, none, 0, h->P(b.w), h->P(b.b), w.ab0, B, b.res_in * b.res_in, s))) return rc;
             aux_ab = w.ab0;
         } else if (b.kind == K_AUX_CONV) {
-            HIP_TRY(launch_aux_out(h->dtype, x, aux_ab, h->P(b.w), h->P(b.b), x_t, w.coef, out, B, b.res_out, b.cin, b.cout, s));
+            HIP_TRY(launch_aux_out(h->dtype, x->p, aux_ab, h->P(b.w), h->P(b.b), x_t, w.coef, out, B, b.res_out, b.cin, b.cout, s));
         }
     }
     return FG_OK;
@@ -789,6 +825,45 @@ int fg_edm_profile_end(fg_edm* h, int64_t* launches, double* total_ms, double* t
     return FG_OK;
 }
 
+// Debug/ablation micro-benchmark of one fused 3x3 conv (bf16 or fp32): allocates its own buffers, times `iters`
+// launches with HIP events.  Not part of the product path; used by scripts/conv_ablate.py only.
+int fg_debug_conv_bench(int dtype, int batch, int cin, int res, int ks, int with_resid, int dbg, int iters, float* ms_out) {
+    const size_t npix = (size_t)batch * res * res;
+    float *x = nullptr, *out = nullptr, *resid = nullptr, *bias = nullptr;
+    float2* ab = nullptr;
+    void* wp = nullptr;
+    HIP_TRY(hipMalloc((void**)&x, npix * cin * 4));
+    HIP_TRY(hipMalloc((void**)&out, npix * 256 * 4));
+    HIP_TRY(hipMalloc((void**)&resid, npix * 256 * 4));
+    HIP_TRY(hipMalloc((void**)&bias, 256 * 4));
+    HIP_TRY(hipMalloc((void**)&ab, (size_t)batch * cin * 8));
+    HIP_TRY(hipMalloc(&wp, (size_t)256 * cin * ks * ks * 4));
+    HIP_TRY(hipMemset(x, 0x3c, npix * cin * 4));       // ~0.0115 per float: finite, non-zero
+    HIP_TRY(hipMemset(resid, 0x3c, npix * 256 * 4));
+    HIP_TRY(hipMemset(bias, 0, 256 * 4));
+    HIP_TRY(hipMemset(ab, 0x3c, (size_t)batch * cin * 8));
+    HIP_TRY(hipMemset(wp, 0x3c, (size_t)256 * cin * ks * ks * (dtype ? 2 : 4)));
+    if (conv_prepare_all(dtype) != 0) return fail(FG_EHIP, "prepare failed");
+    ConvArgs a{};
+    a.src1 = x; a.C1 = cin; a.Hs = a.Ws = a.H = a.W = res; a.B = batch;
+    a.ab = ab; a.wpack = wp; a.bias = bias; a.resid = with_resid ? resid : nullptr; a.scale = 1.f; a.out = out; a.Cout = 256;
+    a.dbg = dbg;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) HIP_TRY(launch_conv_fused(dtype, ks, ks == 3 ? PRO_GN_SILU : PRO_NONE, RES_NONE, OUT_NHWC, a, nullptr));
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) HIP_TRY(launch_conv_fused(dtype, ks, ks == 3 ? PRO_GN_SILU : PRO_NONE, RES_NONE, OUT_NHWC, a, nullptr));
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (ms_out) *ms_out = ms / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(x); (void)hipFree(out); (void)hipFree(resid); (void)hipFree(bias); (void)hipFree(ab); (void)hipFree(wp);
+    return FG_OK;
+}
+
 int fg_edm_num_blocks(const fg_edm* h) { return h ? (int)h->blocks.size() : 0; }
 
 int fg_edm_block_info(const fg_edm* h, int index, const char** key, int* cin, int* cout, int* res_in, int* res_out,
@@ -810,17 +885,31 @@ int fg_edm_run_block(fg_edm* h, int index, const float* x1, int c1, const float*
     if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
     if (index < 0 || index >= (int)h->blocks.size()) return fail(FG_EINVAL, "block index out of range");
     Workspace w;
-    int rc = setup_ws(h, batch, workspace, workspace_bytes, w);
-    if (rc) return rc;
+    int rc0 = setup_ws(h, batch, workspace, workspace_bytes, w);
+    if (rc0) return rc0;
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(launch_linear(emb, h->aff_w, h->aff_b, w.temb, batch, h->emb_ch, h->temb_total, 0, s));
-    return run_block(h, *h->blocks[index], x1, c1, c2 ? x2 : nullptr, c2, w.temb, out, batch, w, s);
+    // caller tensors are fp32 and carry no partial statistics: convert to the activation dtype; norm0 takes the
+    // full-pass fallback
+    const Block& b = *h->blocks[index];
+    const size_t npix_in = (size_t)batch * b.res_in * b.res_in, npix_out = (size_t)batch * b.res_out * b.res_out;
+    Act a1, a2;
+    HIP_TRY(launch_to_act(h->dtype, x1, w.cvt1, (int64_t)npix_in * c1, s));
+    a1.p = w.cvt1;
+    if (c2) {
+        HIP_TRY(launch_to_act(h->dtype, x2, w.cvt2, (int64_t)npix_in * c2, s));
+        a2.p = w.cvt2;
+    }
+    int rc = run_block(h, b, a1, c1, a2, c2, w.temb, w.xa, batch, w, s);
+    if (rc) return rc;
+    HIP_TRY(launch_from_act(h->dtype, w.xa.p, out, (int64_t)npix_out * b.cout, s));
+    return FG_OK;
 }
 
 int fg_op_gn_coeffs(const float* x1, int c1, const float* x2, int c2, const float* gamma, const float* beta, float eps,
                     float* ab_out, int batch, int hw, void* stream) {
     if (!x1 || !gamma || !beta || !ab_out) return fail(FG_EINVAL, "null argument");
-    HIP_TRY(launch_gn_coeffs(x1, c1, c2 ? x2 : nullptr, c2, gamma, beta, eps, (float2*)ab_out, batch, hw, (hipStream_t)stream));
+    HIP_TRY(launch_gn_coeffs(0, x1, c1, c2 ? x2 : nullptr, c2, gamma, beta, eps, (float2*)ab_out, batch, hw, (hipStream_t)stream));
     return FG_OK;
 }
 int fg_op_latents(const float* noise, double t_init, float* out, int64_t total, void* stream) {

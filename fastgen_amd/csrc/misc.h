@@ -3,17 +3,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-int launch_gn_coeffs(const float* x1, int c1, const float* x2, int c2, const float* gamma, const float* beta, float eps,
-                     float2* ab, int batch, int hw, hipStream_t s);
+// dtype (0 fp32 / 1 bf16) is the storage type of activation tensors passed as void*
+int launch_gn_coeffs(int dtype, const void* x1, int c1, const void* x2, int c2, const float* gamma, const float* beta,
+                     float eps, float2* ab, int batch, int hw, hipStream_t s);
+int launch_gn_finalize(const float2* st1, int c1, int s1, const float2* st2, int c2, int s2, const float* gamma,
+                       const float* beta, float eps, float2* ab, int batch, int hw, hipStream_t s);
 int launch_precond_coef(const double* t, int t_stride, double sigma_data, double sigma_shift, double clamp_min,
                         float* coef, int B, hipStream_t s);
 int launch_mapping_in(const float* c_noise, const float* freqs, const float* labels, int label_dim, const float* wl,
                       const float* bl, float* out, int B, int N, hipStream_t s);
 int launch_linear(const float* x, const float* w, const float* bias, float* y, int B, int I, int O, int act_silu,
                   hipStream_t s);
-int launch_conv_in(const float* x, const float* c_in, const float* w, const float* bias, float* out, int B, int res,
-                   int cin, int cout, hipStream_t s);
-int launch_aux_out(int fast, const float* x, const float2* ab, const float* w, const float* bias, const float* x_t,
+int launch_conv_in(int dtype, const float* x, const float* c_in, const float* w, const float* bias, void* out, int B,
+                   int res, int cin, int cout, hipStream_t s);
+int launch_aux_out(int dtype, const void* x, const float2* ab, const float* w, const float* bias, const float* x_t,
                    const float* coef, float* out, int B, int res, int C, int cout, hipStream_t s);
 int launch_latents(const float* noise, double tv, const double* tp, int ti, float* out, int64_t total, hipStream_t s);
 int launch_forward_process(const float* x0, const float* eps, double tv, const double* tp, int ti, float* out,
@@ -21,8 +24,10 @@ int launch_forward_process(const float* x0, const float* eps, double tv, const d
 int launch_x0_to_eps(const float* xt, const float* x0, double tv, const double* tp, int ti, double clamp_min, float* out,
                      int64_t total, hipStream_t s);
 int launch_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, const uint64_t* seed_dev, hipStream_t s);
+int launch_to_act(int dtype, const float* in, void* out, int64_t total, hipStream_t s);
+int launch_from_act(int dtype, const void* in, float* out, int64_t total, hipStream_t s);
 int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, hipStream_t s);
 
 // Single-head self-attention over T tokens, head dim 256 (AttentionOp + value product, EDM/network.py:160-168, 295-296).
-// q,k: [B][T][256], vt: [B][256][T] in the compute dtype (dtype 0 fp32 / 1 bf16); out [B][T][256] fp32.
-int launch_attention(int dtype, const void* q, const void* k, const void* vt, float* out, int B, int T, hipStream_t s);
+// q,k: [B][T][256], vt: [B][256][T], out [B][T][256], all in the compute dtype (dtype 0 fp32 / 1 bf16).
+int launch_attention(int dtype, const void* q, const void* k, const void* vt, void* out, int B, int T, hipStream_t s);

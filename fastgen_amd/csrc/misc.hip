@@ -11,7 +11,8 @@ namespace {
 //   a = rstd * gamma,  b = beta - mean * a      (GroupNorm.forward :141-149; groups = min(32, C/4), biased variance)
 // x is the virtual concat [x1 (C1) | x2 (C2)], NHWC.  One workgroup per image; a thread owns one channel quad.
 // HBM-bound: reads the tensor once with 16-byte loads.
-__global__ __launch_bounds__(512) void gn_coeffs_kernel(const float* __restrict__ x1, int C1, const float* __restrict__ x2,
+template <typename AT>
+__global__ __launch_bounds__(512) void gn_coeffs_kernel(const AT* __restrict__ x1, int C1, const AT* __restrict__ x2,
                                                         int C2, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, float2* __restrict__ ab,
                                                         int hw) {
@@ -28,11 +29,11 @@ __global__ __launch_bounds__(512) void gn_coeffs_kernel(const float* __restrict_
     if (t < Q * lanes) {
         const int q = t % Q, pl = t / Q;
         const int c = q * 4;
-        const float* base = (c < C1) ? x1 + (size_t)n * hw * C1 + c : x2 + (size_t)n * hw * C2 + (c - C1);
+        const AT* base = (c < C1) ? x1 + (size_t)n * hw * C1 + c : x2 + (size_t)n * hw * C2 + (c - C1);
         const int stride = (c < C1) ? C1 : C2;
         // fp32 partials over <= hw/lanes pixels, four independent chains per thread; combined in fp64 below
         for (int p = pl; p < hw; p += lanes) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * stride);
+            const f32x4 v = load4(base + (size_t)p * stride);
             s += (v[0] + v[1]) + (v[2] + v[3]);
             ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
         }
@@ -61,6 +62,42 @@ __global__ __launch_bounds__(512) void gn_coeffs_kernel(const float* __restrict_
         const int g = c / cpg;
         const float a = s_rstd[g] * gamma[c];
         ab[(size_t)n * C + c] = make_float2(a, fmaf(-a, s_mean[g], beta[c]));
+    }
+}
+
+// GroupNorm coefficients from the partial statistics the conv epilogues leave behind (conv.hip): no pass over the
+// tensor.  st[b][slot][quad] = {sum, sum of squares} over a pixel tile of channels 4*quad..4*quad+3; the normalised
+// tensor is the virtual concat of up to two producers.  One workgroup per image, one thread per channel; combined in
+// fp64 in a fixed order (deterministic).
+__global__ void gn_finalize_kernel(const float2* __restrict__ st1, int C1, int S1, const float2* __restrict__ st2, int C2,
+                                   int S2, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float2* __restrict__ ab, int hw) {
+    const int C = C1 + C2;
+    const int groups = min(32, C / 4);
+    const int cpg = C / groups;
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        double s = 0.0, q = 0.0;
+        for (int quad = g * cpg / 4; quad < (g + 1) * cpg / 4; ++quad) {
+            const bool first = quad * 4 < C1;
+            const float2* st = first ? st1 : st2;
+            const int S = first ? S1 : S2;
+            const int Q = (first ? C1 : C2) >> 2;
+            const int ql = first ? quad : quad - (C1 >> 2);
+            for (int sl = 0; sl < S; ++sl) {
+                const float2 v = st[((size_t)n * S + sl) * Q + ql];
+                s += v.x;
+                q += v.y;
+            }
+        }
+        const double cnt = (double)cpg * hw;
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float m = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float a = rstd * gamma[c];
+        ab[(size_t)n * C + c] = make_float2(a, fmaf(-a, m, beta[c]));
     }
 }
 
@@ -149,9 +186,10 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 // ---------------------------------------------------------------------------------------------------
 // Stem: out[n,y,x,co] = conv3x3(c_in[n] * x_t)[co] + bias   (precond_input :771-773 folded into enc '{res}x{res}_conv',
 // :426).  x_t is NCHW fp32, out NHWC fp32.  One workgroup per image row; memory-bound on the output write.
+template <typename AT>
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ c_in,
                                                       const float* __restrict__ w, const float* __restrict__ bias,
-                                                      float* __restrict__ out, int res, int cin, int cout) {
+                                                      AT* __restrict__ out, int res, int cin, int cout) {
     extern __shared__ float sw[];  // [cin*9][cout]
     const int n = blockIdx.x / res, y = blockIdx.x % res;
     const int K = cin * 9;
@@ -180,11 +218,11 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
                     for (int j = 0; j < 16; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
                 }
             }
-        float* o = out + (((size_t)n * res + y) * res + px) * cout + cg * 16;
+        AT* o = out + (((size_t)n * res + y) * res + px) * cout + cg * 16;
 #pragma unroll
         for (int j = 0; j < 16; j += 4)
-            *reinterpret_cast<f32x4*>(o + j) = f32x4{acc[j] + bias[cg * 16 + j], acc[j + 1] + bias[cg * 16 + j + 1],
-                                                     acc[j + 2] + bias[cg * 16 + j + 2], acc[j + 3] + bias[cg * 16 + j + 3]};
+            store4(o + j, f32x4{acc[j] + bias[cg * 16 + j], acc[j + 1] + bias[cg * 16 + j + 1],
+                                acc[j + 2] + bias[cg * 16 + j + 2], acc[j + 3] + bias[cg * 16 + j + 3]});
     }
 }
 
@@ -192,8 +230,8 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
 // Output head: F = aux_conv(silu(aux_norm(x)))  (:553-557) and D = c_skip * x_t + c_out * F  (precond_output :798-805)
 // x NHWC [B,res,res,C] fp32, ab = aux_norm coefficients, w OIHW [cout(<=4)][C][3][3]; x_t / out NCHW.
 // One workgroup per image row: thread = (pixel, 1/8 channel slice); the slices meet in a wave shuffle.
-template <bool FAST>
-__global__ __launch_bounds__(256) void aux_out_kernel(const float* __restrict__ x, const float2* __restrict__ ab,
+template <bool FAST, typename AT>
+__global__ __launch_bounds__(256) void aux_out_kernel(const AT* __restrict__ x, const float2* __restrict__ ab,
                                                       const float* __restrict__ w, const float* __restrict__ bias,
                                                       const float* __restrict__ x_t, const float* __restrict__ coef,
                                                       float* __restrict__ out, int B, int res, int C, int cout) {
@@ -215,9 +253,9 @@ __global__ __launch_bounds__(256) void aux_out_kernel(const float* __restrict__ 
             for (int tap = 0; tap < 9; ++tap) {
                 const int yy = y + tap / 3 - 1, xx = px + tap % 3 - 1;
                 if (yy < 0 || yy >= res || xx < 0 || xx >= res) continue;
-                const float* xp = x + (((size_t)n * res + yy) * res + xx) * C + cs * slice;
+                const AT* xp = x + (((size_t)n * res + yy) * res + xx) * C + cs * slice;
                 for (int c = 0; c < slice; c += 4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(xp + c);
+                    const f32x4 v = load4(xp + c);
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         const float2 k = sab[cs * slice + c + d];
@@ -324,6 +362,12 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restr
     }
 }
 
+template <typename A, typename B>
+__global__ void convert_kernel(const A* __restrict__ in, B* __restrict__ out, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (B)(float)in[i];
+}
+
 inline int ew_grid(int64_t total) {
     int64_t g = (total + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -333,8 +377,8 @@ inline int ew_grid(int64_t total) {
 
 #define RET_LAST() return (int)hipGetLastError()
 
-int launch_gn_coeffs(const float* x1, int c1, const float* x2, int c2, const float* gamma, const float* beta, float eps,
-                     float2* ab, int batch, int hw, hipStream_t s) {
+int launch_gn_coeffs(int dtype, const void* x1, int c1, const void* x2, int c2, const float* gamma, const float* beta,
+                     float eps, float2* ab, int batch, int hw, hipStream_t s) {
     const int C = c1 + c2;
     if (C % 4 || (c1 % 4) || C < 16 || C > 2048) return (int)hipErrorInvalidValue;
     const int groups = C / 4 < 32 ? C / 4 : 32;
@@ -342,7 +386,21 @@ int launch_gn_coeffs(const float* x1, int c1, const float* x2, int c2, const flo
     const int Q = C / 4;
     if (Q > 512) return (int)hipErrorInvalidValue;
     const int threads = (512 / Q) * Q;
-    hipLaunchKernelGGL(gn_coeffs_kernel, dim3(batch), dim3(threads), 0, s, x1, c1, x2, c2, gamma, beta, eps, ab, hw);
+    if (dtype)
+        hipLaunchKernelGGL(gn_coeffs_kernel<__bf16>, dim3(batch), dim3(threads), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, gamma, beta, eps, ab, hw);
+    else
+        hipLaunchKernelGGL(gn_coeffs_kernel<float>, dim3(batch), dim3(threads), 0, s, (const float*)x1, c1, (const float*)x2, c2, gamma, beta, eps, ab, hw);
+    RET_LAST();
+}
+
+int launch_gn_finalize(const float2* st1, int c1, int s1, const float2* st2, int c2, int s2, const float* gamma,
+                       const float* beta, float eps, float2* ab, int batch, int hw, hipStream_t s) {
+    const int C = c1 + c2;
+    if (C % 4 || (c1 % 4) || C < 16) return (int)hipErrorInvalidValue;
+    const int groups = C / 4 < 32 ? C / 4 : 32;
+    if (C % groups || (C / groups) % 4) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(C < 512 ? C : 512), 0, s, st1, c1, s1, st2, c2, s2, gamma, beta,
+                       eps, ab, hw);
     RET_LAST();
 }
 
@@ -370,24 +428,27 @@ int launch_linear(const float* x, const float* w, const float* bias, float* y, i
     RET_LAST();
 }
 
-int launch_conv_in(const float* x, const float* c_in, const float* w, const float* bias, float* out, int B, int res,
-                   int cin, int cout, hipStream_t s) {
+int launch_conv_in(int dtype, const float* x, const float* c_in, const float* w, const float* bias, void* out, int B,
+                   int res, int cin, int cout, hipStream_t s) {
     if (cout % 16) return (int)hipErrorInvalidValue;
     const size_t lds = (size_t)cin * 9 * cout * sizeof(float);
     if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(conv_in_kernel, dim3(B * res), dim3(256), lds, s, x, c_in, w, bias, out, res, cin, cout);
+    if (dtype)
+        hipLaunchKernelGGL(conv_in_kernel<__bf16>, dim3(B * res), dim3(256), lds, s, x, c_in, w, bias, (__bf16*)out, res, cin, cout);
+    else
+        hipLaunchKernelGGL(conv_in_kernel<float>, dim3(B * res), dim3(256), lds, s, x, c_in, w, bias, (float*)out, res, cin, cout);
     RET_LAST();
 }
 
-int launch_aux_out(int fast, const float* x, const float2* ab, const float* w, const float* bias, const float* x_t,
+int launch_aux_out(int dtype, const void* x, const float2* ab, const float* w, const float* bias, const float* x_t,
                    const float* coef, float* out, int B, int res, int C, int cout, hipStream_t s) {
     if (cout > 4 || C % 32) return (int)hipErrorInvalidValue;
     const size_t lds = (size_t)9 * cout * C * sizeof(float) + (size_t)C * sizeof(float2);
     if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
-    if (fast)
-        hipLaunchKernelGGL(aux_out_kernel<true>, dim3(B * res), dim3(256), lds, s, x, ab, w, bias, x_t, coef, out, B, res, C, cout);
+    if (dtype)
+        hipLaunchKernelGGL((aux_out_kernel<true, __bf16>), dim3(B * res), dim3(256), lds, s, (const __bf16*)x, ab, w, bias, x_t, coef, out, B, res, C, cout);
     else
-        hipLaunchKernelGGL(aux_out_kernel<false>, dim3(B * res), dim3(256), lds, s, x, ab, w, bias, x_t, coef, out, B, res, C, cout);
+        hipLaunchKernelGGL((aux_out_kernel<false, float>), dim3(B * res), dim3(256), lds, s, (const float*)x, ab, w, bias, x_t, coef, out, B, res, C, cout);
     RET_LAST();
 }
 
@@ -407,6 +468,20 @@ int launch_x0_to_eps(const float* xt, const float* x0, double tv, const double* 
 }
 int launch_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, const uint64_t* seed_dev, hipStream_t s) {
     hipLaunchKernelGGL(randn_kernel, dim3(ew_grid((total + 3) / 4)), dim3(256), 0, s, out, total, seed, offset, seed_dev);
+    RET_LAST();
+}
+int launch_to_act(int dtype, const float* in, void* out, int64_t total, hipStream_t s) {
+    if (dtype)
+        hipLaunchKernelGGL((convert_kernel<float, __bf16>), dim3(ew_grid(total)), dim3(256), 0, s, in, (__bf16*)out, total);
+    else
+        hipLaunchKernelGGL((convert_kernel<float, float>), dim3(ew_grid(total)), dim3(256), 0, s, in, (float*)out, total);
+    RET_LAST();
+}
+int launch_from_act(int dtype, const void* in, float* out, int64_t total, hipStream_t s) {
+    if (dtype)
+        hipLaunchKernelGGL((convert_kernel<__bf16, float>), dim3(ew_grid(total)), dim3(256), 0, s, (const __bf16*)in, out, total);
+    else
+        hipLaunchKernelGGL((convert_kernel<float, float>), dim3(ew_grid(total)), dim3(256), 0, s, (const float*)in, out, total);
     RET_LAST();
 }
 int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, hipStream_t s) {
