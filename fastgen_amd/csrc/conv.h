@@ -40,6 +40,7 @@ enum { OUT_NHWC = 0, OUT_QKV = 1 };
 int launch_conv_fused(int dtype, int ks, int pro, int res, int outmode, const ConvArgs& a, hipStream_t stream);
 // partial-statistics slots per image for an output of width W (= pixel tiles per image, 1 when a tile spans images)
 int conv_stat_slots(int W);
+int launch_conv_debug(int dtype, const ConvArgs& a, hipStream_t stream);  // ablation build, honours a.dbg
 // set the dynamic-LDS attribute of every instantiation of this dtype (call once, outside stream capture)
 int conv_prepare_all(int dtype);
 // elements of packed weight storage for a conv with these dims
