@@ -1,0 +1,141 @@
+// Output head of the EDM U-Net on the matrix cores:
+//     F = aux_conv(silu(aux_norm(x)))                      reference fastgen/networks/EDM/network.py:553-557
+//     D = c_skip * x_t + c_out * F                          precond_output, :798-805
+// aux_conv is a 3x3 convolution to img_channels (3) outputs: as a GEMM its N is tiny, so instead of the 256-wide conv
+// kernel this one pads N to a single 32-column MFMA tile and splits the 128-pixel tile over the four waves along M.
+// The activation halo is normalised + SiLU'd once per 64-channel chunk into LDS (same image layout as conv.hip) and
+// read by all nine taps; the kernel is bound by reading x once (1.5x with the halo rows).
+#include "common.h"
+#include "misc.h"
+
+namespace {
+
+constexpr int APITCH = 144;
+constexpr int HWID = 34, HROWS = 6;  // halo of a 4 x 32 pixel tile
+
+template <typename T>
+__global__ __launch_bounds__(256) void aux_head_kernel(const T* __restrict__ x, const float2* __restrict__ ab,
+                                                       const T* __restrict__ wpack, const float* __restrict__ bias,
+                                                       const float* __restrict__ x_t, const float* __restrict__ coef,
+                                                       float* __restrict__ out, int B, int C, int cout) {
+    constexpr int KC = DT<T>::KC, KK = KC / 16, OPP = KC / 8;
+    constexpr bool FAST = DT<T>::FAST;
+    constexpr int LOG_OPP = (OPP == 8) ? 3 : 2;
+    constexpr int PSTRIDE = 256 / OPP;
+    constexpr int HALO_PIX = HROWS * HWID;
+    constexpr int NITEMS = (HALO_PIX * OPP + 255) / 256;
+    __shared__ __attribute__((aligned(16))) char smem[HALO_PIX * APITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n = blockIdx.x >> 3, row0 = (blockIdx.x & 7) * 4;
+    const int oct = tid & (OPP - 1), hq0 = tid >> LOG_OPP;
+    const int nchunk = C / KC;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        // ---- stage: silu(a*x+b) of the 6 x 34 halo, this chunk's KC channels --------------------------------
+        float2 abr[8];
+        {
+            const float2* p = ab + (size_t)n * C + chunk * KC + oct * 8;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(p + j);
+                abr[j] = make_float2(q[0], q[1]);
+                abr[j + 1] = make_float2(q[2], q[3]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NITEMS; ++i) {
+            const int hq = hq0 + i * PSTRIDE;
+            if (hq < HALO_PIX) {
+                const int hx = hq % HWID, hy = hq / HWID;
+                const int y = row0 + hy - 1, xx = hx - 1;
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = 0.f;
+                if (y >= 0 && y < 32 && xx >= 0 && xx < 32) {
+                    const T* p = x + (((size_t)n * 32 + y) * 32 + xx) * C + chunk * KC + oct * 8;
+                    const f32x4 lo = load4(p), hi = load4(p + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = silu_f<FAST>(fmaf(lo[j], abr[j].x, abr[j].y));
+                        o[j + 4] = silu_f<FAST>(fmaf(hi[j], abr[j + 4].x, abr[j + 4].y));
+                    }
+                }
+                store_frag(reinterpret_cast<T*>(smem + hq * APITCH) + oct * 8, o);
+            }
+        }
+        __syncthreads();
+        // ---- multiply: wave w = image row row0 + w of the tile, 9 taps x KK k-steps, N padded to 32 ----------------
+        const T* wp = wpack + (size_t)chunk * 9 * KK * 512 + lane * 8;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const char* abase = smem + ((wave + tap / 3) * HWID + r + tap % 3) * APITCH + h * (8 * (int)sizeof(T));
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const Frag8<T> af = load_frag(reinterpret_cast<const T*>(abase) + kk * 16);
+                const Frag8<T> bf = load_frag(wp + (tap * KK + kk) * 512);
+                mma16(acc, af, bf);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: lanes r < cout hold output channel r for 16 pixels of the row ---------------------------------
+    if (r < cout) {
+        const float c_skip = coef[2 * B + n], c_out = coef[3 * B + n];
+        const float bv = bias[r];
+        const int y = row0 + wave;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const size_t o = (((size_t)n * cout + r) * 32 + y) * 32 + acc_row(i, h);
+            out[o] = c_skip * x_t[o] + c_out * (acc[i] + bv);
+        }
+    }
+}
+
+// packed[chunk][tap][kk][lane][j] = W[co = lane & 31][ci = chunk*KC + kk*16 + 8*(lane>>5) + j][tap], zero for co >= cout
+template <typename T>
+__global__ void pack_aux_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int C, int cout) {
+    constexpr int KC = DT<T>::KC, KK = KC / 16;
+    const int total = C * 9 * 32;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        int t = idx;
+        const int j = t % 8; t /= 8;
+        const int lane = t % 64; t /= 64;
+        const int kk = t % KK; t /= KK;
+        const int tap = t % 9; t /= 9;
+        const int chunk = t;
+        const int co = lane & 31;
+        const int ci = chunk * KC + kk * 16 + 8 * (lane >> 5) + j;
+        out[idx] = (co < cout) ? (T)w[((size_t)co * C + ci) * 9 + tap] : (T)0.f;
+    }
+}
+
+}  // namespace
+
+size_t aux_pack_elems(int C) { return (size_t)C * 9 * 32; }
+
+int launch_pack_aux_weights(int dtype, const float* w, void* out, int C, int cout, hipStream_t s) {
+    const int grid = (int)((aux_pack_elems(C) + 255) / 256);
+    if (dtype)
+        hipLaunchKernelGGL(pack_aux_weights_kernel<__bf16>, dim3(grid), dim3(256), 0, s, w, (__bf16*)out, C, cout);
+    else
+        hipLaunchKernelGGL(pack_aux_weights_kernel<float>, dim3(grid), dim3(256), 0, s, w, (float*)out, C, cout);
+    return (int)hipGetLastError();
+}
+
+// supported: res == 32, C a multiple of the chunk size, cout <= 32
+int aux_head_supported(int dtype, int res, int C, int cout) { return res == 32 && C % (dtype ? 64 : 32) == 0 && cout <= 32; }
+
+int launch_aux_head(int dtype, const void* x, const float2* ab, const void* wpack, const float* bias, const float* x_t,
+                    const float* coef, float* out, int B, int C, int cout, hipStream_t s) {
+    if (dtype)
+        hipLaunchKernelGGL(aux_head_kernel<__bf16>, dim3(B * 8), dim3(256), 0, s, (const __bf16*)x, ab, (const __bf16*)wpack, bias, x_t, coef, out, B, C, cout);
+    else
+        hipLaunchKernelGGL(aux_head_kernel<float>, dim3(B * 8), dim3(256), 0, s, (const float*)x, ab, (const float*)wpack, bias, x_t, coef, out, B, C, cout);
+    return (int)hipGetLastError();
+}

@@ -95,6 +95,15 @@ __device__ __forceinline__ f32x4 store4(__bf16* p, f32x4 v) {
     return f32x4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
 }
 
+// raw (un-widened) 4-element activation vectors: lets a load stay in flight without a dependent conversion
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { typedef f32x4 type; };
+template <> struct Raw4<__bf16> { typedef bf16x4 type; };
+__device__ __forceinline__ f32x4 raw_load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ bf16x4 raw_load4(const __bf16* p) { return *reinterpret_cast<const bf16x4*>(p); }
+__device__ __forceinline__ f32x4 widen4(f32x4 v) { return v; }
+__device__ __forceinline__ f32x4 widen4(bf16x4 q) { return f32x4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]}; }
+
 // SiLU = x * sigmoid(x) (torch.nn.functional.silu, used at EDM/network.py:276,283,520-521,556).
 template <bool FAST>
 __device__ __forceinline__ float silu_f(float x) {

@@ -345,10 +345,32 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         float ssum[G::IMGS], ssq[G::IMGS];
 #pragma unroll
         for (int im = 0; im < G::IMGS; ++im) ssum[im] = ssq[im] = 0.f;
+        // global element offset of this lane's quad for pixel row pl of pixel tile mt (or -1 past the batch)
+        auto goff = [&](int mt, int j, bool& ok) -> size_t {
+            const int p = mt * 32 + j * 4 + prow;
+            const int x = p & (G::W - 1);
+            const int y = row0 + ((p >> LOGW) & (G::TH - 1));
+            const int n = n_base + mt / MT_PER_IMG;
+            ok = n < a.B;
+            return (((size_t)n * H + y) * G::W + x) * a.Cout + co0;
+        };
+        typedef typename Raw4<T>::type R4;
+        R4 rcur[8], rnext[8];  // residual quads: the loads for tile mt+1 are in flight while tile mt is processed
+        auto issue_resid = [&](int mt, R4 (&rr)[8]) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bool ok;
+                const size_t go = goff(mt, j, ok);
+                rr[j] = R4{};
+                if (ok) rr[j] = raw_load4(resid + go);
+            }
+        };
+        if (resid) issue_resid(0, rcur);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int im = mt / MT_PER_IMG;
             const int n = n_base + im;
+            if (resid && mt + 1 < 4) issue_resid(mt + 1, rnext);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -360,19 +382,19 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
             for (int j = 0; j < 8; ++j) {
                 const int pl = j * 4 + prow;
                 f32x4 v = *reinterpret_cast<const f32x4*>(ep + pl * EP_PITCH + c4 * 16);
-                const int p = mt * 32 + pl;
-                const int x = p & (G::W - 1);
-                const int y = row0 + ((p >> LOGW) & (G::TH - 1));
-                if (n < a.B) {
-                    const size_t go = (((size_t)n * H + y) * G::W + x) * a.Cout + co0;
+                bool ok;
+                const size_t go = goff(mt, j, ok);
+                if (ok) {
                     v += add;
-                    if (resid) v += load4(resid + go);
+                    if (resid) v += widen4(rcur[j]);
                     v *= a.scale;
                     const f32x4 vr = store4(out + go, v);  // the values as the consumer will read them
                     ssum[im] += (vr[0] + vr[1]) + (vr[2] + vr[3]);
                     ssq[im] += (vr[0] * vr[0] + vr[1] * vr[1]) + (vr[2] * vr[2] + vr[3] * vr[3]);
                 }
             }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rcur[j] = rnext[j];
         }
         if (a.stats) {
 #pragma unroll

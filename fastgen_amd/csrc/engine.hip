@@ -57,6 +57,7 @@ struct Block {
     // packed weights (owned device memory, compute dtype)
     void *p_conv0 = nullptr, *p_conv1 = nullptr, *p_skip = nullptr, *p_qkv = nullptr, *p_proj = nullptr;
     float* qkv_bias = nullptr;  // [3C] permuted to q|k|v
+    void* p_aux = nullptr;      // K_AUX_CONV: weights packed for the MFMA output head
 };
 
 struct Arena {
@@ -511,7 +512,10 @@ int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, cons
             if ((rc = norm_coeffs(h->dtype, *x, b.cin, none, 0, h->P(b.w), h->P(b.b), w.ab0, B, b.res_in * b.res_in, s))) return rc;
             aux_ab = w.ab0;
         } else if (b.kind == K_AUX_CONV) {
-            HIP_TRY(launch_aux_out(h->dtype, x->p, aux_ab, h->P(b.w), h->P(b.b), x_t, w.coef, out, B, b.res_out, b.cin, b.cout, s));
+            if (b.p_aux)
+                HIP_TRY(launch_aux_head(h->dtype, x->p, aux_ab, b.p_aux, h->P(b.b), x_t, w.coef, out, B, b.cin, b.cout, s));
+            else
+                HIP_TRY(launch_aux_out(h->dtype, x->p, aux_ab, h->P(b.w), h->P(b.b), x_t, w.coef, out, B, b.res_out, b.cin, b.cout, s));
         }
     }
     return FG_OK;
@@ -582,6 +586,9 @@ int ensure_device_state(fg_edm* h) {
             if ((rc = dev_alloc(h, (void**)&b->qkv_bias, sizeof(float) * 3 * b->cout))) return rc;
         }
     }
+    for (Block& b : h->dec)
+        if (b.kind == K_AUX_CONV && aux_head_supported(h->dtype, b.res_out, b.cin, b.cout))
+            if ((rc = dev_alloc(h, &b.p_aux, aux_pack_elems(b.cin) * tsz))) return rc;
     if ((rc = dev_alloc(h, (void**)&h->aff_w, sizeof(float) * (size_t)h->temb_total * h->emb_ch))) return rc;
     if ((rc = dev_alloc(h, (void**)&h->aff_b, sizeof(float) * (size_t)h->temb_total))) return rc;
     // PositionalEmbedding(endpoint=True) frequencies in fp32, EDM/network.py:314-316
@@ -688,6 +695,8 @@ int fg_edm_pack_weights(fg_edm* h, void* stream) {
                                sizeof(float) * (size_t)b->cout * h->emb_ch, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(h->aff_b + b->temb_off, h->P(b->aff_b), sizeof(float) * b->cout, hipMemcpyDeviceToDevice, s));
     }
+    for (Block& b : h->dec)
+        if (b.kind == K_AUX_CONV && b.p_aux) HIP_TRY(launch_pack_aux_weights(h->dtype, h->P(b.w), b.p_aux, b.cin, b.cout, s));
     drop_graph(h);
     h->packed = true;
     return FG_OK;

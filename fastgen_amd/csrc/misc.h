@@ -31,3 +31,10 @@ int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, hipSt
 // Single-head self-attention over T tokens, head dim 256 (AttentionOp + value product, EDM/network.py:160-168, 295-296).
 // q,k: [B][T][256], vt: [B][256][T], out [B][T][256], all in the compute dtype (dtype 0 fp32 / 1 bf16).
 int launch_attention(int dtype, const void* q, const void* k, const void* vt, void* out, int B, int T, hipStream_t s);
+
+// MFMA output head (aux.hip): aux_conv(silu(aux_norm(x))) + EDM output preconditioning, res == 32.
+size_t aux_pack_elems(int C);
+int launch_pack_aux_weights(int dtype, const float* w, void* out, int C, int cout, hipStream_t s);
+int aux_head_supported(int dtype, int res, int C, int cout);
+int launch_aux_head(int dtype, const void* x, const float2* ab, const void* wpack, const float* bias, const float* x_t,
+                    const float* coef, float* out, int B, int C, int cout, hipStream_t s);
