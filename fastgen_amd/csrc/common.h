@@ -78,6 +78,16 @@ __device__ __forceinline__ void store_frag(float* p, const float (&x)[8]) {
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{x[4], x[5], x[6], x[7]};
 }
 
+// a loaded 8-element fragment widened to fp32
+__device__ __forceinline__ void widen8(const Frag8<__bf16>& f, float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)f.v[j];
+}
+__device__ __forceinline__ void widen8(const Frag8<float>& f, float (&v)[8]) {
+    v[0] = f.lo[0]; v[1] = f.lo[1]; v[2] = f.lo[2]; v[3] = f.lo[3];
+    v[4] = f.hi[0]; v[5] = f.hi[1]; v[6] = f.hi[2]; v[7] = f.hi[3];
+}
+
 // 4 consecutive activation elements <-> fp32
 __device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x4 load4(const __bf16* p) {

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
     constexpr int PSTRIDE = NTHR / OPP;                               // halo pixels covered per staging item
     constexpr int NITEMS = (G::HALO_PIX * OPP + NTHR - 1) / NTHR;     // staging items per thread and chunk
     constexpr int IPS = (NITEMS + G::TAPS - 1) / G::TAPS;             // items staged per (chunk, tap) step
-    constexpr bool DEFER = (RES != RES_DOWN) && (KS == 3);            // split load / transform+write around the MFMAs
+    constexpr bool DEFER = (RES != RES_DOWN) && (OUTMODE != OUT_QKV);  // split load / transform+write around the MFMAs
     constexpr bool AB_REGS = (PRO != PRO_NONE) && (G::IMGS == 1);     // per-chunk GN coefficients live in registers
     constexpr bool PIPE_A = (sizeof(T) == 2);                         // two A-fragment register sets (bf16 only)
 
@@ -151,19 +151,18 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
     for (int j = 0; j < 8; ++j) abr[j] = make_float2(1.f, 0.f);
 
     // phase 1 of an item: issue the global loads (3x3, RES_NONE / RES_UP only)
-    auto item_load = [&](int chunk, int i, float (&raw)[8], bool& valid) {
+    auto item_load = [&](int chunk, int i, Frag8<ST>& raw, bool& valid) {
         int n, y, x, lo;
         valid = decode(hq0 + i * PSTRIDE, n, y, x, lo);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) raw[j] = 0.f;
+        raw = Frag8<ST>{};
         if (valid) {
             const int sy = (RES == RES_UP) ? (y >> 1) : y;
             const int sx = (RES == RES_UP) ? (x >> 1) : x;
-            load8(src_ptr(chunk, n, sy, sx), raw);
+            raw = load_frag(src_ptr(chunk, n, sy, sx));
         }
     };
     // phase 2: transform and park in LDS
-    auto item_finish = [&](int chunk, int i, char* abuf, float (&raw)[8], bool valid) {
+    auto item_finish = [&](int chunk, int i, char* abuf, const Frag8<ST>& rawp, bool valid) {
         const int hq = hq0 + i * PSTRIDE;
         if (hq >= G::HALO_PIX) return;
         int n, y, x, lo;
@@ -173,6 +172,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         for (int j = 0; j < 8; ++j) o[j] = 0.f;
         if (DEFER) {
             if (valid) {
+                float raw[8];
+                widen8(rawp, raw);
                 if (PRO != PRO_NONE && !AB_REGS) {
                     float2 ab[8];
                     load_ab(chunk, n, ab);
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
     if (AB_REGS) load_ab(0, n_base, abr);
 #pragma unroll
     for (int i = 0; i < NITEMS; ++i) {
-        float raw[8];
+        Frag8<ST> raw = {};
         bool valid = false;
         if (DEFER) item_load(0, i, raw, valid);
         item_finish(0, i, smem, raw, valid);
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
             //     (clamped: the last step re-reads itself), so B needs 2*KK fragments with one step of prefetch distance
             const T* pnext = wp + (size_t)((DBG && (dbg & 16)) ? 0 : ((step + 1 < nsteps) ? step + 1 : step)) * (KK * 512);
             // (2) issue this step's share of the next chunk's activation loads
-            float raw[IPS][8];
+            Frag8<ST> raw[IPS];
             bool valid[IPS];
             const bool do_stage = stage_next && (tap * IPS < NITEMS) && !(DBG && (dbg & 1));
             if (do_stage) {
