@@ -51,6 +51,10 @@ struct Geom {
     }
 };
 
+// Output-channel tiles per wave.  The 8x8 layers have only B/2 pixel tiles: splitting N over two workgroups (128
+// channels each) doubles the grid so that two workgroups are resident per CU there as well.
+__host__ __device__ constexpr int conv_nt(int ks, int logw, int outmode) { return (logw == 3 && ks == 3 && outmode == OUT_NHWC) ? 1 : 2; }
+
 template <int PRO, bool FAST>
 __device__ __forceinline__ float pro_apply(float x, float2 ab) {
     if (PRO == PRO_NONE) return x;
@@ -91,6 +95,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
     constexpr bool DEFER = (RES != RES_DOWN) && (OUTMODE != OUT_QKV);  // split load / transform+write around the MFMAs
     constexpr bool AB_REGS = (PRO != PRO_NONE) && (G::IMGS == 1);     // per-chunk GN coefficients live in registers
     constexpr bool PIPE_A = (sizeof(T) == 2);                         // two A-fragment register sets (bf16 only)
+    constexpr int NT = conv_nt(KS, LOGW, OUTMODE);                    // 32-channel tiles per wave: 2, or 1 (N split over 2 workgroups)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
 
     // this wave's packed weights: [cout/32][step][kk][lane][8], two consecutive 32-channel groups
     const size_t wstride = (size_t)nsteps * (KK * 512);
-    const T* wp = reinterpret_cast<const T*>(a.wpack) + (size_t)(nblk * 8 + wave * 2) * wstride + lane * 8;
+    const T* wp = reinterpret_cast<const T*>(a.wpack) + (size_t)(nblk * (4 * NT) + wave * NT) * wstride + lane * 8;
 
     const ST* src1 = reinterpret_cast<const ST*>(a.src1);
     const ST* src2 = reinterpret_cast<const ST*>(a.src2);
@@ -220,18 +225,17 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         if (DEFER) item_load(0, i, raw, valid);
         item_finish(0, i, smem, raw, valid);
     }
-    Frag8<T> b0[KK], b1[KK];
+    Frag8<T> bfr[NT][KK];
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-        b0[kk] = load_frag(wp + kk * 512);
-        b1[kk] = load_frag(wp + wstride + kk * 512);
-    }
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) bfr[nt][kk] = load_frag(wp + nt * wstride + kk * 512);
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][NT];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
@@ -271,13 +275,12 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
             };
             auto mma8 = [&](int kk, const Frag8<T> (&af)[4]) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    mma16(acc[mt][0], af[mt], b0[kk]);
-                    mma16(acc[mt][1], af[mt], b1[kk]);
-                }
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) mma16(acc[mt][nt], af[mt], bfr[nt][kk]);
                 if (!DBG || !(dbg & 2)) {
-                    b0[kk] = load_frag(pnext + kk * 512);
-                    b1[kk] = load_frag(pnext + wstride + kk * 512);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bfr[nt][kk] = load_frag(pnext + nt * wstride + kk * 512);
                 }
             };
             if (DBG && (dbg & 8)) {
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) t += acc[mt][nt][i];
         if (t == 1234.5678f) reinterpret_cast<float*>(a.out)[0] = t;
@@ -333,12 +336,15 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         // Transpose each 32-pixel x 64-channel accumulator slab through this wave's private LDS scratch (the A buffers
         // are dead after the last barrier) so that global traffic is row-contiguous: a lane owns one channel QUAD of one
         // pixel (16 B fp32 / 8 B bf16 per access), 16 lanes cover a pixel's 64 channels, 4 pixels per wave instruction.
-        constexpr int EP_PITCH = 64 * 4 + 16;
+        constexpr int QPW = 8 * NT;              // channel quads per pixel row of this wave's slab
+        constexpr int RP = 64 / QPW;             // pixel rows per wave instruction
+        constexpr int NP = 32 / RP;              // passes per 32-pixel tile
+        constexpr int EP_PITCH = 32 * NT * 4 + 16;
         constexpr int MT_PER_IMG = 4 / G::IMGS;
         static_assert(4 * 32 * EP_PITCH <= 2 * G::ABUF, "epilogue scratch must fit in the A buffers");
         char* ep = smem + wave * (32 * EP_PITCH);
-        const int c4 = lane & 15, prow = lane >> 4;
-        const int co0 = nblk * 256 + wave * 64 + c4 * 4;
+        const int c4 = lane % QPW, prow = lane / QPW;
+        const int co0 = nblk * (128 * NT) + wave * (32 * NT) + c4 * 4;
         T* out = reinterpret_cast<T*>(a.out);
         const T* resid = reinterpret_cast<const T*>(a.resid);
         f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         for (int im = 0; im < G::IMGS; ++im) ssum[im] = ssq[im] = 0.f;
         // global element offset of this lane's quad for pixel row pl of pixel tile mt (or -1 past the batch)
         auto goff = [&](int mt, int j, bool& ok) -> size_t {
-            const int p = mt * 32 + j * 4 + prow;
+            const int p = mt * 32 + j * RP + prow;
             const int x = p & (G::W - 1);
             const int y = row0 + ((p >> LOGW) & (G::TH - 1));
             const int n = n_base + mt / MT_PER_IMG;
@@ -356,10 +362,10 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
             return (((size_t)n * H + y) * G::W + x) * a.Cout + co0;
         };
         typedef typename Raw4<T>::type R4;
-        R4 rcur[8], rnext[8];  // residual quads: the loads for tile mt+1 are in flight while tile mt is processed
-        auto issue_resid = [&](int mt, R4 (&rr)[8]) {
+        R4 rcur[NP], rnext[NP];  // residual quads: the loads for tile mt+1 are in flight while tile mt is processed
+        auto issue_resid = [&](int mt, R4 (&rr)[NP]) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NP; ++j) {
                 bool ok;
                 const size_t go = goff(mt, j, ok);
                 rr[j] = R4{};
@@ -373,15 +379,15 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
             const int n = n_base + im;
             if (resid && mt + 1 < 4) issue_resid(mt + 1, rnext);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                     *reinterpret_cast<float*>(ep + acc_row(i, h) * EP_PITCH + (nt * 32 + r) * 4) = acc[mt][nt][i];
             f32x4 add = bias4;
             if (a.temb && n < a.B) add += *reinterpret_cast<const f32x4*>(a.temb + (size_t)n * a.temb_stride + co0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int pl = j * 4 + prow;
+            for (int j = 0; j < NP; ++j) {
+                const int pl = j * RP + prow;
                 f32x4 v = *reinterpret_cast<const f32x4*>(ep + pl * EP_PITCH + c4 * 16);
                 bool ok;
                 const size_t go = goff(mt, j, ok);
@@ -395,24 +401,28 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) rcur[j] = rnext[j];
+            for (int j = 0; j < NP; ++j) rcur[j] = rnext[j];
         }
         if (a.stats) {
 #pragma unroll
             for (int im = 0; im < G::IMGS; ++im) {
                 float sv = ssum[im], qv = ssq[im];
-                sv += __shfl_xor(sv, 16); qv += __shfl_xor(qv, 16);
-                sv += __shfl_xor(sv, 32); qv += __shfl_xor(qv, 32);
+#pragma unroll
+                for (int sh = QPW; sh < 64; sh <<= 1) {
+                    sv += __shfl_xor(sv, sh);
+                    qv += __shfl_xor(qv, sh);
+                }
                 const int n = n_base + im;
                 if (prow == 0 && n < a.B)
                     a.stats[((size_t)n * G::TPI + slot) * (a.Cout >> 2) + (co0 >> 2)] = make_float2(sv, qv);
             }
         }
     } else {  // OUT_QKV: plane nblk of {q, k, v^T} in the compute dtype
+        static_assert(OUTMODE != OUT_QKV || NT == 2, "qkv epilogue assumes 64 channels per wave");
         T* qk = reinterpret_cast<T*>(nblk == 0 ? a.q_out : a.k_out);
         T* vt = reinterpret_cast<T*>(a.vt_out);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             const int cl = wave * 64 + nt * 32 + r;
             const float bias = a.bias ? a.bias[nblk * 256 + cl] : 0.f;
 #pragma unroll
@@ -483,7 +493,7 @@ int launch_one(const ConvArgs& a, hipStream_t stream) {
         attr_done = true;
     }
     if (g_prepare_only) return 0;
-    dim3 grid(tiles, a.Cout / 256);
+    dim3 grid(tiles, a.Cout / (128 * conv_nt(KS, LOGW, OUTMODE)));
     hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, stream, a);
     return (int)hipGetLastError();
 }
