@@ -134,6 +134,148 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
     }
 }
 
+// ---- bf16, T = 256: K and V^T tiles staged through LDS -----------------------------------------------------------
+// The direct-from-global form above reads every K / V fragment as 64 scattered 16-byte (8-byte) pieces and every wave
+// of an image re-reads them.  Here one workgroup = 4 waves = 128 queries of one image; 64-key tiles of K ([key][dim],
+// 528-byte pitch: conflict-free ds_read_b128) and of V^T ([dim][key], 136-byte pitch: conflict-free ds_read_b64) are
+// copied with coalesced 16-byte loads into a double-buffered LDS ring shared by the four waves.  Q stays in registers
+// (64 VGPRs), S^T in 128 accumulators, then P as 64 VGPRs of bf16 fragments next to the 128 accumulators of O.
+constexpr int KPITCH = 528, VPITCH = 136;
+constexpr int ATT_BUF = 256 * VPITCH;  // >= 64 * KPITCH
+
+__global__ __launch_bounds__(256, 2) void attention_lds_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
+                                                               const __bf16* vt, __bf16* __restrict__ out,
+                                                               int B) {
+    constexpr int Tn = 256, D = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n = blockIdx.x >> 1;
+    const int q0 = (blockIdx.x & 1) * 128 + wave * 32;
+
+    auto stage_k = [&](int kt64, char* buf) {  // 64 keys x 256 dims: 2048 16-byte chunks, 8 per thread (two batches)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+#pragma unroll
+            for (int i = b2 * 4; i < b2 * 4 + 4; ++i) {
+                const int idx = tid + 256 * i, row = idx >> 5, c = idx & 31;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(k + ((size_t)n * Tn + kt64 * 64 + row) * D + c * 8);
+                *reinterpret_cast<bf16x8*>(buf + row * KPITCH + c * 16) = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto stage_v = [&](int kt64, char* buf) {  // 256 dims x 64 keys: 2048 chunks, written as 2 x 8 bytes (pitch % 16 = 8)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+#pragma unroll
+            for (int i = b2 * 4; i < b2 * 4 + 4; ++i) {
+                const int idx = tid + 256 * i, row = idx >> 3, c = idx & 7;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(vt + ((size_t)n * D + row) * Tn + kt64 * 64 + c * 8);
+                bf16x4* dst = reinterpret_cast<bf16x4*>(buf + row * VPITCH + c * 16);
+                dst[0] = bf16x4{v[0], v[1], v[2], v[3]};
+                dst[1] = bf16x4{v[4], v[5], v[6], v[7]};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // Q fragments of this wave's 32 queries (B operand of S^T = K Q^T): 16 KB per wave, re-read from L1/L2 per key tile
+    const __bf16* qrow = q + ((size_t)n * Tn + q0 + r) * D + 8 * h;
+    f32x16 st[8];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[kt][i] = 0.f;
+
+    stage_k(0, smem);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        char* cur = smem + (t & 1) * ATT_BUF;
+        if (t + 1 < 4) stage_k(t + 1, smem + ((t + 1) & 1) * ATT_BUF);
+#pragma unroll 4
+        for (int kk = 0; kk < 16; ++kk) {
+            const Frag8<__bf16> qf = load_frag(qrow + kk * 16);
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const Frag8<__bf16> kf = load_frag(reinterpret_cast<const __bf16*>(cur + (sub * 32 + r) * KPITCH + h * 16) + kk * 16);
+                mma16(st[t * 2 + sub], kf, qf);
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- softmax over keys (registers + the partner half-wave), as in attention_kernel ----------------------------
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m = fmaxf(m, st[kt][i]);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float e = __builtin_amdgcn_exp2f(1.44269504088896341f * 0.0625f * (st[kt][i] - m));
+            st[kt][i] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 32);
+    const float inv = __builtin_amdgcn_rcpf(sum);
+    Frag8<__bf16> pf[8][2];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[kt][s2].v[j] = (__bf16)(st[kt][8 * s2 + j] * inv);
+        __builtin_amdgcn_sched_barrier(0);  // convert tile by tile: products of all tiles at once would double the footprint
+    }
+
+    __builtin_amdgcn_sched_barrier(0);  // keep the softmax / P conversion (peak register use) clear of what follows
+    // ---- O = P V over 64-key tiles of V^T, four 32-wide dim tiles at a time (two sweeps over the V^T tiles) --------------
+    __bf16* obase = out + ((size_t)n * Tn + q0) * D + r;
+#pragma unroll 1
+    for (int dg = 0; dg < 2; ++dg) {
+        f32x16 o[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
+        asm volatile("" ::: "memory");  // the V^T loads do not depend on dg: stop LICM from hoisting all of them out of the loop
+        stage_v(0, smem);         // buffer 0 is free: the previous phase ended with a barrier
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const char* cur = smem + (t & 1) * ATT_BUF;
+            if (t + 1 < 4) stage_v(t + 1, smem + ((t + 1) & 1) * ATT_BUF);
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        // element j <-> key 32*sub + 16*s2 + 8*(j>>2) + 4h + (j&3) of the tile
+                        const char* p = cur + ((dg * 4 + d) * 32 + r) * VPITCH + (sub * 32 + 16 * s2 + 4 * h) * 2;
+                        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(p);
+                        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(p + 16);
+                        Frag8<__bf16> vf;
+                        vf.v = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        mma16(o[d], pf[t * 2 + sub][s2], vf);
+                    }
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) obase[(size_t)acc_row(i, h) * D + (dg * 4 + d) * 32] = (__bf16)o[d][i];
+    }
+}
+
 }  // namespace
 
 int launch_attention(int dtype, const void* q, const void* k, const void* vt, void* out, int B, int T, hipStream_t s) {
@@ -141,6 +283,18 @@ int launch_attention(int dtype, const void* q, const void* k, const void* vt, vo
     const int nt = T / 32;
     const int waves = B * nt;
     dim3 grid((waves + 3) / 4), block(256);
+    if (dtype && nt == 8) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_BUF);
+            if (e != hipSuccess) return (int)e;
+            attr_done = true;
+        }
+        if (!q) return 0;  // prepare-only call (sets the attribute outside stream capture)
+        hipLaunchKernelGGL(attention_lds_kernel, dim3(B * 2), block, 2 * ATT_BUF, s, (const __bf16*)q, (const __bf16*)k, (const __bf16*)vt, (__bf16*)out, B);
+        return (int)hipGetLastError();
+    }
+    if (!q) return 0;  // prepare-only call: nothing to set for the direct-from-global kernels
     if (dtype) {
         if (nt == 8)
             hipLaunchKernelGGL((attention_kernel<__bf16, 8>), grid, block, 0, s, (const __bf16*)q, (const __bf16*)k, (const __bf16*)vt, (__bf16*)out, B);

@@ -79,11 +79,12 @@ __device__ __forceinline__ void load8(const __bf16* p, float (&v)[8]) {
 // reference's own bf16 autocast keeps conv outputs — hence the residual stream — in bf16, EDM/network.py:285-287).
 // DBG: compile-time switch for the ablation hooks (scripts/conv_ablate.py); production instantiations use DBG = false so
 // that no runtime flag splits the MFMA basic block (a join makes the compiler's s_waitcnt placement conservative).
-template <typename T, int KS, int PRO, int RES, int LOGW, int OUTMODE, bool DBG = false>
+template <typename T, int KS, int PRO, int RES, int LOGW, int OUTMODE, int ABL = 0>
 __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
+    constexpr bool DBG = false;  // (runtime ablation flags retired: they perturbed the code they measured)
     using G = Geom<KS, LOGW>;
     using ST = T;
-    const int dbg = DBG ? a.dbg : 0;
+    constexpr int dbg = ABL;  // compile-time ablation mask: 1 no staging, 2 no weight refill, 4 no epilogue, 8 no MFMA
     constexpr int KC = DT<T>::KC;
     constexpr bool FAST = DT<T>::FAST;
     constexpr int KK = KC / 16;   // 16-deep MFMA steps per chunk
@@ -212,10 +213,6 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         store_frag(reinterpret_cast<T*>(abuf + lo), o);
     };
 
-    if (DBG && (dbg >> 8) && blockIdx.x >= 256 && blockIdx.x < 512) {  // ablation: stagger the second-resident workgroups
-        const long long t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < (long long)(dbg >> 8) * 1024) __builtin_amdgcn_s_sleep(32);
-    }
     // ---- prologue: chunk 0 of A, step 0 of B ------------------------------------------------------
     if (AB_REGS) load_ab(0, n_base, abr);
 #pragma unroll
@@ -252,11 +249,11 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         for (int tap = 0; tap < G::TAPS; ++tap, ++step) {
             // (1) weights: each fragment is refilled in place for the NEXT step right after its last use below
             //     (clamped: the last step re-reads itself), so B needs 2*KK fragments with one step of prefetch distance
-            const T* pnext = wp + (size_t)((DBG && (dbg & 16)) ? 0 : ((step + 1 < nsteps) ? step + 1 : step)) * (KK * 512);
+            const T* pnext = wp + (size_t)((step + 1 < nsteps) ? step + 1 : step) * (KK * 512);
             // (2) issue this step's share of the next chunk's activation loads
             Frag8<ST> raw[IPS];
             bool valid[IPS];
-            const bool do_stage = stage_next && (tap * IPS < NITEMS) && !(DBG && (dbg & 1));
+            const bool do_stage = stage_next && (tap * IPS < NITEMS) && !(dbg & 1);
             if (do_stage) {
                 if (AB_REGS && tap == 0) load_ab(chunk + 1, n_base, abr);
                 if (DEFER) {
@@ -278,12 +275,12 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) mma16(acc[mt][nt], af[mt], bfr[nt][kk]);
-                if (!DBG || !(dbg & 2)) {
+                if (!(dbg & 2)) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) bfr[nt][kk] = load_frag(pnext + nt * wstride + kk * 512);
                 }
             };
-            if (DBG && (dbg & 8)) {
+            if (dbg & 8) {
                 // ablation: no LDS reads, no MFMAs
             } else if (PIPE_A) {
                 Frag8<T> a0[4], a1[4];
@@ -321,7 +318,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
 
     // ---- epilogue -------------------------------------------------------------------------------------
     const int HWo = H * G::W;
-    if (DBG && (dbg & 4)) {  // ablation: keep the accumulators live, store (almost) nothing
+    if (dbg & 4) {  // ablation: keep the accumulators live, store (almost) nothing
         float t = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -480,12 +477,12 @@ __global__ void pack_conv_weights_kernel(const float* __restrict__ w, T* __restr
 
 bool g_prepare_only = false;  // conv_prepare_all(): walk the dispatch tables, set attributes, launch nothing
 
-template <typename T, int KS, int PRO, int RES, int LOGW, int OUTMODE, bool DBG = false>
+template <typename T, int KS, int PRO, int RES, int LOGW, int OUTMODE, int ABL = 0>
 int launch_one(const ConvArgs& a, hipStream_t stream) {
     using G = Geom<KS, LOGW>;
     const int tiles = (G::IMGS > 1) ? (a.B + G::IMGS - 1) / G::IMGS : a.B * G::TPI;
     const size_t lds = 2 * (size_t)G::ABUF;
-    auto kern = conv_fused_kernel<T, KS, PRO, RES, LOGW, OUTMODE, DBG>;
+    auto kern = conv_fused_kernel<T, KS, PRO, RES, LOGW, OUTMODE, ABL>;
     static bool attr_done = false;  // raise the dynamic-LDS cap once per instantiation (never inside stream capture)
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -530,12 +527,19 @@ int launch_t(int ks, int pro, int res, int outmode, const ConvArgs& a, hipStream
 
 }  // namespace
 
-// ablation build of the dominant shape (3x3, no resample, 32x32 / 16x16), scripts/conv_ablate.py only
+// compile-time ablation builds of the dominant shape (bf16, 3x3, no resample, 32x32): scripts/conv_ablate.py only
 int launch_conv_debug(int dtype, const ConvArgs& a, hipStream_t stream) {
-    if (a.W == 32) return dtype ? launch_one<__bf16, 3, PRO_GN_SILU, RES_NONE, 5, OUT_NHWC, true>(a, stream)
-                                : launch_one<float, 3, PRO_GN_SILU, RES_NONE, 5, OUT_NHWC, true>(a, stream);
-    if (a.W == 16) return dtype ? launch_one<__bf16, 3, PRO_GN_SILU, RES_NONE, 4, OUT_NHWC, true>(a, stream)
-                                : launch_one<float, 3, PRO_GN_SILU, RES_NONE, 4, OUT_NHWC, true>(a, stream);
+    if (!dtype || a.W != 32) return (int)hipErrorInvalidValue;
+    switch (a.dbg) {
+        case 0: return launch_one<__bf16, 3, PRO_GN_SILU, RES_NONE, 5, OUT_NHWC, 0>(a, stream);
+        case 1: return launch_one<__bf16, 3, PRO_GN_SILU, RES_NONE, 5, OUT_NHWC, 1>(a, stream);
+        case 2: return launch_one<__bf16, 3, PRO_GN_SILU, RES_NONE, 5, OUT_NHWC, 2>(a, stream);
+        case 3: return launch_one<__bf16, 3, PRO_GN_SILU, RES_NONE, 5, OUT_NHWC, 3>(a, stream);
+        case 4: return launch_one<__bf16, 3, PRO_GN_SILU, RES_NONE, 5, OUT_NHWC, 4>(a, stream);
+        case 5: return launch_one<__bf16, 3, PRO_GN_SILU, RES_NONE, 5, OUT_NHWC, 5>(a, stream);
+        case 6: return launch_one<__bf16, 3, PRO_GN_SILU, RES_NONE, 5, OUT_NHWC, 6>(a, stream);
+        case 7: return launch_one<__bf16, 3, PRO_GN_SILU, RES_NONE, 5, OUT_NHWC, 7>(a, stream);
+    }
     return (int)hipErrorInvalidValue;
 }
 

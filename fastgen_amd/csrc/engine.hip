@@ -598,6 +598,7 @@ int ensure_device_state(fg_edm* h) {
     if ((rc = dev_alloc(h, (void**)&h->freqs, sizeof(float) * half))) return rc;
     HIP_TRY(hipMemcpy(h->freqs, fr.data(), sizeof(float) * half, hipMemcpyHostToDevice));
     if (conv_prepare_all(h->dtype) != 0) return fail(FG_EHIP, "hipFuncSetAttribute(dynamic LDS) failed");
+    if (launch_attention(h->dtype, nullptr, nullptr, nullptr, nullptr, 1, 256, nullptr) != 0) return fail(FG_EHIP, "attention prepare failed");
     HIP_TRY(hipHostMalloc((void**)&h->slots, sizeof(fg_edm::Slot) * fg_edm::kSlots));
     for (int i = 0; i < fg_edm::kSlots; ++i) HIP_TRY(hipEventCreateWithFlags(&h->slot_ev[i], hipEventDisableTiming));
     h->device_ready = true;
