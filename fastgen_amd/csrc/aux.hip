@@ -115,6 +115,68 @@ __global__ void pack_aux_weights_kernel(const float* __restrict__ w, T* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Stem: out = conv3x3(c_in * x_t) + bias, img_channels (3) -> 128 channels (precond_input :771-773 folded into the
+// first encoder conv :426).  K = 27 is padded to two 16-deep MFMA steps; the A fragment (32 pixels x 16 k) is gathered
+// directly from the NCHW fp32 input (lanes = consecutive x: coalesced), the four 32-channel B tiles are pre-packed.
+// One wave = 32 consecutive pixels x 128 channels.  Bound by writing the NHWC output.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ c_in,
+                                                   const T* __restrict__ wpack, const float* __restrict__ bias,
+                                                   T* __restrict__ out, int B, int res, int cin) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int hw = res * res;
+    const long long p0 = ((long long)blockIdx.x * 4 + wave) * 32;  // first pixel (flattened over the batch) of this wave
+    const int n = (int)(p0 / hw);
+    if (n >= B) return;
+    const int pix = (int)(p0 % hw) + r;
+    const int y = pix / res, xx = pix % res;
+    const float ci_scale = c_in[n];
+    f32x16 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = s * 16 + 8 * h + j;  // k = ci*9 + kh*3 + kw (OIHW order)
+            const int ci = k / 9, kh = (k % 9) / 3, kw = k % 3;
+            const int yy = y + kh - 1, xs = xx + kw - 1;
+            v[j] = 0.f;
+            if (k < cin * 9 && yy >= 0 && yy < res && xs >= 0 && xs < res)
+                v[j] = ci_scale * x[(((size_t)n * cin + ci) * res + yy) * res + xs];
+        }
+        Frag8<T> af;
+        store_frag(reinterpret_cast<T*>(&af), v);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const Frag8<T> bf = load_frag(wpack + ((s * 4 + nt) * 64 + lane) * 8);
+            mma16(acc[nt], af, bf);
+        }
+    }
+    T* obase = out + ((size_t)n * hw + (p0 % hw)) * 128;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const float bv = bias[nt * 32 + r];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) obase[(size_t)acc_row(i, h) * 128 + nt * 32 + r] = (T)(acc[nt][i] + bv);
+    }
+}
+
+// packed[s][nt][lane][j] = W[co = nt*32 + (lane&31)][k = s*16 + 8*(lane>>5) + j], zero for k >= cin*9
+template <typename T>
+__global__ void pack_stem_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int cin) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 2 * 4 * 64 * 8) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63, nt = (idx >> 9) & 3, s = idx >> 11;
+    const int co = nt * 32 + (lane & 31), k = s * 16 + 8 * (lane >> 5) + j;
+    out[idx] = (k < cin * 9) ? (T)w[(size_t)co * cin * 9 + k] : (T)0.f;
+}
+
 }  // namespace
 
 size_t aux_pack_elems(int C) { return (size_t)C * 9 * 32; }
@@ -137,5 +199,26 @@ int launch_aux_head(int dtype, const void* x, const float2* ab, const void* wpac
         hipLaunchKernelGGL(aux_head_kernel<__bf16>, dim3(B * 8), dim3(256), 0, s, (const __bf16*)x, ab, (const __bf16*)wpack, bias, x_t, coef, out, B, C, cout);
     else
         hipLaunchKernelGGL(aux_head_kernel<float>, dim3(B * 8), dim3(256), 0, s, (const float*)x, ab, (const float*)wpack, bias, x_t, coef, out, B, C, cout);
+    return (int)hipGetLastError();
+}
+
+// ---- stem -------------------------------------------------------------------------------------------------------
+int stem_supported(int res, int cin, int cout) { return cout == 128 && cin * 9 <= 32 && (res * res) % 32 == 0; }
+size_t stem_pack_elems() { return 2 * 4 * 64 * 8; }
+int launch_pack_stem_weights(int dtype, const float* w, void* out, int cin, hipStream_t s) {
+    if (dtype)
+        hipLaunchKernelGGL(pack_stem_weights_kernel<__bf16>, dim3(16), dim3(256), 0, s, w, (__bf16*)out, cin);
+    else
+        hipLaunchKernelGGL(pack_stem_weights_kernel<float>, dim3(16), dim3(256), 0, s, w, (float*)out, cin);
+    return (int)hipGetLastError();
+}
+int launch_stem(int dtype, const float* x, const float* c_in, const void* wpack, const float* bias, void* out, int B,
+                int res, int cin, hipStream_t s) {
+    const long long waves = (long long)B * res * res / 32;
+    dim3 grid((unsigned)((waves + 3) / 4));
+    if (dtype)
+        hipLaunchKernelGGL(stem_kernel<__bf16>, grid, dim3(256), 0, s, x, c_in, (const __bf16*)wpack, bias, (__bf16*)out, B, res, cin);
+    else
+        hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, s, x, c_in, (const float*)wpack, bias, (float*)out, B, res, cin);
     return (int)hipGetLastError();
 }

@@ -93,7 +93,9 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
     constexpr int PSTRIDE = NTHR / OPP;                               // halo pixels covered per staging item
     constexpr int NITEMS = (G::HALO_PIX * OPP + NTHR - 1) / NTHR;     // staging items per thread and chunk
     constexpr int IPS = (NITEMS + G::TAPS - 1) / G::TAPS;             // items staged per (chunk, tap) step
-    constexpr bool DEFER = (RES != RES_DOWN) && (OUTMODE != OUT_QKV);  // split load / transform+write around the MFMAs
+    constexpr int ND = (RES == RES_DOWN) ? 4 : 1;                     // source pixels per staged pixel (2x2 mean when down-sampling)
+    // split load / transform+write around the MFMAs; with down-sampling an item holds 4 raw fragments: bf16 3x3 only
+    constexpr bool DEFER = (OUTMODE != OUT_QKV) && (RES != RES_DOWN || (KS == 3 && sizeof(T) == 2));
     constexpr bool AB_REGS = (PRO != PRO_NONE) && (G::IMGS == 1);     // per-chunk GN coefficients live in registers
     constexpr bool PIPE_A = (sizeof(T) == 2);                         // two A-fragment register sets (bf16 only)
     constexpr int NT = conv_nt(KS, LOGW, OUTMODE);                    // 32-channel tiles per wave: 2, or 1 (N split over 2 workgroups)
@@ -157,18 +159,22 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
     for (int j = 0; j < 8; ++j) abr[j] = make_float2(1.f, 0.f);
 
     // phase 1 of an item: issue the global loads (3x3, RES_NONE / RES_UP only)
-    auto item_load = [&](int chunk, int i, Frag8<ST>& raw, bool& valid) {
+    auto item_load = [&](int chunk, int i, Frag8<ST> (&raw)[ND], bool& valid) {
         int n, y, x, lo;
         valid = decode(hq0 + i * PSTRIDE, n, y, x, lo);
-        raw = Frag8<ST>{};
+#pragma unroll
+        for (int d = 0; d < ND; ++d) raw[d] = Frag8<ST>{};
         if (valid) {
-            const int sy = (RES == RES_UP) ? (y >> 1) : y;
-            const int sx = (RES == RES_UP) ? (x >> 1) : x;
-            raw = load_frag(src_ptr(chunk, n, sy, sx));
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                const int sy = (RES == RES_DOWN) ? 2 * y + (d >> 1) : ((RES == RES_UP) ? (y >> 1) : y);
+                const int sx = (RES == RES_DOWN) ? 2 * x + (d & 1) : ((RES == RES_UP) ? (x >> 1) : x);
+                raw[d] = load_frag(src_ptr(chunk, n, sy, sx));
+            }
         }
     };
     // phase 2: transform and park in LDS
-    auto item_finish = [&](int chunk, int i, char* abuf, const Frag8<ST>& rawp, bool valid) {
+    auto item_finish = [&](int chunk, int i, char* abuf, const Frag8<ST> (&rawp)[ND], bool valid) {
         const int hq = hq0 + i * PSTRIDE;
         if (hq >= G::HALO_PIX) return;
         int n, y, x, lo;
@@ -178,20 +184,23 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         for (int j = 0; j < 8; ++j) o[j] = 0.f;
         if (DEFER) {
             if (valid) {
-                float raw[8];
-                widen8(rawp, raw);
-                if (PRO != PRO_NONE && !AB_REGS) {
-                    float2 ab[8];
-                    load_ab(chunk, n, ab);
+                float2 ab[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = pro_apply<PRO, FAST>(raw[j], ab[j]);
-                } else {
+                for (int j = 0; j < 8; ++j) ab[j] = abr[j];
+                if (PRO != PRO_NONE && !AB_REGS) load_ab(chunk, n, ab);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = pro_apply<PRO, FAST>(raw[j], abr[j]);
+                for (int d = 0; d < ND; ++d) {
+                    float raw[8];
+                    widen8(rawp[d], raw);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] += pro_apply<PRO, FAST>(raw[j], ab[j]);
+                }
+                if (ND == 4) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] *= 0.25f;
                 }
             }
-        } else if (ok) {  // synchronous path: RES_DOWN (mean of the four transformed source pixels) and all 1x1 convs
-            constexpr int ND = (RES == RES_DOWN) ? 4 : 1;
+        } else if (ok) {  // synchronous path (qkv, fp32 / 1x1 down-sampling)
             float2 ab[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) ab[j] = AB_REGS ? abr[j] : make_float2(1.f, 0.f);
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
     if (AB_REGS) load_ab(0, n_base, abr);
 #pragma unroll
     for (int i = 0; i < NITEMS; ++i) {
-        Frag8<ST> raw = {};
+        Frag8<ST> raw[ND] = {};
         bool valid = false;
         if (DEFER) item_load(0, i, raw, valid);
         item_finish(0, i, smem, raw, valid);
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
             //     (clamped: the last step re-reads itself), so B needs 2*KK fragments with one step of prefetch distance
             const T* pnext = wp + (size_t)((step + 1 < nsteps) ? step + 1 : step) * (KK * 512);
             // (2) issue this step's share of the next chunk's activation loads
-            Frag8<ST> raw[IPS];
+            Frag8<ST> raw[IPS][ND];
             bool valid[IPS];
             const bool do_stage = stage_next && (tap * IPS < NITEMS) && !(dbg & 1);
             if (do_stage) {
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         if (t == 1234.5678f) reinterpret_cast<float*>(a.out)[0] = t;
         return;
     }
-    if (OUTMODE == OUT_NHWC) {
+    if (OUTMODE == OUT_NHWC || nblk < 2) {  // NHWC tensor, or the q / k plane of the qkv projection ([B][HW][256])
         // Transpose each 32-pixel x 64-channel accumulator slab through this wave's private LDS scratch (the A buffers
         // are dead after the last barrier) so that global traffic is row-contiguous: a lane owns one channel QUAD of one
         // pixel (16 B fp32 / 8 B bf16 per access), 16 lanes cover a pixel's 64 channels, 4 pixels per wave instruction.
@@ -342,8 +351,11 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         char* ep = smem + wave * (32 * EP_PITCH);
         const int c4 = lane % QPW, prow = lane / QPW;
         const int co0 = nblk * (128 * NT) + wave * (32 * NT) + c4 * 4;
-        T* out = reinterpret_cast<T*>(a.out);
-        const T* resid = reinterpret_cast<const T*>(a.resid);
+        const bool qk = (OUTMODE == OUT_QKV);
+        T* out = reinterpret_cast<T*>(qk ? (nblk == 0 ? a.q_out : a.k_out) : a.out);
+        const T* resid = qk ? nullptr : reinterpret_cast<const T*>(a.resid);
+        const int ostride = qk ? 256 : a.Cout;          // channels per pixel of the tensor written
+        const int co_out = qk ? co0 - nblk * 256 : co0;  // channel within that tensor (co0 indexes bias / temb / stats)
         f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
         if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + co0);
         float ssum[G::IMGS], ssq[G::IMGS];
@@ -356,7 +368,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
             const int y = row0 + ((p >> LOGW) & (G::TH - 1));
             const int n = n_base + mt / MT_PER_IMG;
             ok = n < a.B;
-            return (((size_t)n * H + y) * G::W + x) * a.Cout + co0;
+            return (((size_t)n * H + y) * G::W + x) * ostride + co_out;
         };
         typedef typename Raw4<T>::type R4;
         R4 rcur[NP], rnext[NP];  // residual quads: the loads for tile mt+1 are in flight while tile mt is processed
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
                 for (int i = 0; i < 16; ++i)
                     *reinterpret_cast<float*>(ep + acc_row(i, h) * EP_PITCH + (nt * 32 + r) * 4) = acc[mt][nt][i];
             f32x4 add = bias4;
-            if (a.temb && n < a.B) add += *reinterpret_cast<const f32x4*>(a.temb + (size_t)n * a.temb_stride + co0);
+            if (!qk && a.temb && n < a.B) add += *reinterpret_cast<const f32x4*>(a.temb + (size_t)n * a.temb_stride + co0);
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 const int pl = j * RP + prow;
@@ -400,7 +412,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < NP; ++j) rcur[j] = rnext[j];
         }
-        if (a.stats) {
+        if (!qk && a.stats) {
 #pragma unroll
             for (int im = 0; im < G::IMGS; ++im) {
                 float sv = ssum[im], qv = ssq[im];
@@ -414,9 +426,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
                     a.stats[((size_t)n * G::TPI + slot) * (a.Cout >> 2) + (co0 >> 2)] = make_float2(sv, qv);
             }
         }
-    } else {  // OUT_QKV: plane nblk of {q, k, v^T} in the compute dtype
+    } else {  // the v^T plane of the qkv projection: [B][256][HW], four consecutive pixels per 8/16-byte store
         static_assert(OUTMODE != OUT_QKV || NT == 2, "qkv epilogue assumes 64 channels per wave");
-        T* qk = reinterpret_cast<T*>(nblk == 0 ? a.q_out : a.k_out);
         T* vt = reinterpret_cast<T*>(a.vt_out);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -430,18 +441,10 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
                     const int x = p & (G::W - 1);
                     const int y = row0 + ((p >> LOGW) & (G::TH - 1));
                     const int n = n_base + (p >> (LOGW + G::LOGTH));
-                    if (n < a.B) {
-                        const int pix = y * G::W + x;
-                        if (nblk < 2) {
-#pragma unroll
-                            for (int d = 0; d < 4; ++d)
-                                qk[((size_t)n * HWo + pix + d) * 256 + cl] = (T)(acc[mt][nt][i4 + d] + bias);
-                        } else {
-                            T* dst = vt + ((size_t)n * 256 + cl) * HWo + pix;
-#pragma unroll
-                            for (int d = 0; d < 4; ++d) dst[d] = (T)(acc[mt][nt][i4 + d] + bias);
-                        }
-                    }
+                    if (n < a.B)
+                        store4(vt + ((size_t)n * 256 + cl) * HWo + y * G::W + x,
+                               f32x4{acc[mt][nt][i4] + bias, acc[mt][nt][i4 + 1] + bias, acc[mt][nt][i4 + 2] + bias,
+                                     acc[mt][nt][i4 + 3] + bias});
                 }
             }
         }
@@ -514,9 +517,10 @@ int launch_t(int ks, int pro, int res, int outmode, const ConvArgs& a, hipStream
     }
     if (ks == 3 && pro == PRO_GN_SILU) {
         if (res == RES_NONE) return launch_w<T, 3, PRO_GN_SILU, RES_NONE, OUT_NHWC>(a, s);
-        if (res == RES_DOWN) return launch_w<T, 3, PRO_GN_SILU, RES_DOWN, OUT_NHWC>(a, s);
         if (res == RES_UP) return launch_w<T, 3, PRO_GN_SILU, RES_UP, OUT_NHWC>(a, s);
     }
+    // down-sampling blocks: the operand was normalised, activated and pooled by gn_silu_pool (misc.hip)
+    if (ks == 3 && pro == PRO_NONE && res == RES_NONE) return launch_w<T, 3, PRO_NONE, RES_NONE, OUT_NHWC>(a, s);
     if (ks == 1 && pro == PRO_NONE) {
         if (res == RES_NONE) return launch_w<T, 1, PRO_NONE, RES_NONE, OUT_NHWC>(a, s);
         if (res == RES_DOWN) return launch_w<T, 1, PRO_NONE, RES_DOWN, OUT_NHWC>(a, s);
@@ -567,9 +571,11 @@ int conv_prepare_all(int dtype) {
     for (int wi = 0; wi < 3 && !rc; ++wi) {
         a.W = a.H = ws[wi];
         for (int res = 0; res < 3 && !rc; ++res) {
-            rc = dtype ? launch_t<__bf16>(3, PRO_GN_SILU, res, OUT_NHWC, a, nullptr) : launch_t<float>(3, PRO_GN_SILU, res, OUT_NHWC, a, nullptr);
+            if (res != RES_DOWN)
+                rc = dtype ? launch_t<__bf16>(3, PRO_GN_SILU, res, OUT_NHWC, a, nullptr) : launch_t<float>(3, PRO_GN_SILU, res, OUT_NHWC, a, nullptr);
             if (!rc) rc = dtype ? launch_t<__bf16>(1, PRO_NONE, res, OUT_NHWC, a, nullptr) : launch_t<float>(1, PRO_NONE, res, OUT_NHWC, a, nullptr);
         }
+        if (!rc) rc = dtype ? launch_t<__bf16>(3, PRO_NONE, RES_NONE, OUT_NHWC, a, nullptr) : launch_t<float>(3, PRO_NONE, RES_NONE, OUT_NHWC, a, nullptr);
         if (!rc && a.W <= 16)
             rc = dtype ? launch_t<__bf16>(1, PRO_GN, RES_NONE, OUT_QKV, a, nullptr) : launch_t<float>(1, PRO_GN, RES_NONE, OUT_QKV, a, nullptr);
     }

@@ -58,6 +58,7 @@ struct Block {
     void *p_conv0 = nullptr, *p_conv1 = nullptr, *p_skip = nullptr, *p_qkv = nullptr, *p_proj = nullptr;
     float* qkv_bias = nullptr;  // [3C] permuted to q|k|v
     void* p_aux = nullptr;      // K_AUX_CONV: weights packed for the MFMA output head
+    void* p_stem = nullptr;     // K_STEM: weights packed for the MFMA stem
 };
 
 struct Arena {
@@ -89,7 +90,7 @@ struct Workspace {
     float2 *ab0, *ab1, *ab2;
     std::vector<Act> skip;  // encoder outputs
     Act xa, xb, h, xattn;
-    void *sbuf, *aout;
+    void *sbuf, *aout, *pool;
     void *cvt1, *cvt2;  // fg_edm_run_block: caller's fp32 tensors converted to the activation dtype
     void *q, *k, *vt;
     // sampler state
@@ -354,6 +355,7 @@ size_t plan_workspace(const fg_edm* h, int B, Arena& A, Workspace& w) {
     w.xb = act((size_t)B * max_act);
     w.h = act((size_t)B * max_act);
     w.sbuf = A.take((size_t)B * max_act * tsz);
+    w.pool = A.take((size_t)B * max_act * tsz);
     w.cvt1 = A.take((size_t)B * max_act * 4 * tsz);  // run_block inputs: up to 512 channels at the input resolution
     w.cvt2 = A.take((size_t)B * max_act * 4 * tsz);
     w.xattn = act((size_t)B * max_attn_hw * 256);
@@ -424,7 +426,14 @@ int run_block(fg_edm* h, const Block& b, const Act& x1, int c1, const Act& x2, i
     a.ab = w.ab0; a.wpack = b.p_conv0; a.bias = h->P(b.conv0_b);
     a.temb = temb + b.temb_off; a.temb_stride = h->temb_total;
     a.resid = nullptr; a.scale = 1.0f; a.out = w.h.p; a.Cout = b.cout; a.stats = w.h.st;
-    HIP_TRY(conv_launch(h, 3, PRO_GN_SILU, res_mode, OUT_NHWC, a, s));
+    if (b.down && !c2) {
+        // pooled silu(norm0(x)) written once by a small pass (4x less transform work than pooling inside the conv)
+        HIP_TRY(launch_gn_silu_pool(h->dtype, x1.p, w.ab0, w.pool, B, b.res_out, b.res_out, c1, s));
+        a.src1 = w.pool; a.Hs = a.Ws = b.res_out; a.ab = nullptr;
+        HIP_TRY(conv_launch(h, 3, PRO_NONE, RES_NONE, OUT_NHWC, a, s));
+    } else {
+        HIP_TRY(conv_launch(h, 3, PRO_GN_SILU, res_mode, OUT_NHWC, a, s));
+    }
     w.h.slots = slots;
     // skip path
     const void* resid = x1.p;
@@ -488,7 +497,10 @@ int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, cons
     for (size_t i = 0; i < h->enc.size(); ++i) {
         const Block& b = h->enc[i];
         if (b.kind == K_STEM) {
-            HIP_TRY(launch_conv_in(h->dtype, x_t, w.coef, h->P(b.w), h->P(b.b), w.skip[i].p, B, b.res_out, b.cin, b.cout, s));
+            if (b.p_stem)
+                HIP_TRY(launch_stem(h->dtype, x_t, w.coef, b.p_stem, h->P(b.b), w.skip[i].p, B, b.res_out, b.cin, s));
+            else
+                HIP_TRY(launch_conv_in(h->dtype, x_t, w.coef, h->P(b.w), h->P(b.b), w.skip[i].p, B, b.res_out, b.cin, b.cout, s));
             w.skip[i].st = nullptr;  // the stem leaves no statistics: block0's norm0 takes the full-pass fallback
         } else {
             rc = run_block(h, b, *x, b.cin, none, 0, w.temb, w.skip[i], B, w, s);
@@ -586,6 +598,9 @@ int ensure_device_state(fg_edm* h) {
             if ((rc = dev_alloc(h, (void**)&b->qkv_bias, sizeof(float) * 3 * b->cout))) return rc;
         }
     }
+    for (Block& b : h->enc)
+        if (b.kind == K_STEM && stem_supported(b.res_out, b.cin, b.cout))
+            if ((rc = dev_alloc(h, &b.p_stem, stem_pack_elems() * tsz))) return rc;
     for (Block& b : h->dec)
         if (b.kind == K_AUX_CONV && aux_head_supported(h->dtype, b.res_out, b.cin, b.cout))
             if ((rc = dev_alloc(h, &b.p_aux, aux_pack_elems(b.cin) * tsz))) return rc;
@@ -696,6 +711,8 @@ int fg_edm_pack_weights(fg_edm* h, void* stream) {
                                sizeof(float) * (size_t)b->cout * h->emb_ch, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(h->aff_b + b->temb_off, h->P(b->aff_b), sizeof(float) * b->cout, hipMemcpyDeviceToDevice, s));
     }
+    for (Block& b : h->enc)
+        if (b.kind == K_STEM && b.p_stem) HIP_TRY(launch_pack_stem_weights(h->dtype, h->P(b.w), b.p_stem, b.cin, s));
     for (Block& b : h->dec)
         if (b.kind == K_AUX_CONV && b.p_aux) HIP_TRY(launch_pack_aux_weights(h->dtype, h->P(b.w), b.p_aux, b.cin, b.cout, s));
     drop_graph(h);

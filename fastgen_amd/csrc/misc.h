@@ -24,6 +24,8 @@ int launch_forward_process(const float* x0, const float* eps, double tv, const d
 int launch_x0_to_eps(const float* xt, const float* x0, double tv, const double* tp, int ti, double clamp_min, float* out,
                      int64_t total, hipStream_t s);
 int launch_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, const uint64_t* seed_dev, hipStream_t s);
+// out[B,H,W,C] = mean over 2x2 of silu(a*x+b), x [B,2H,2W,C]
+int launch_gn_silu_pool(int dtype, const void* x, const float2* ab, void* out, int B, int H, int W, int C, hipStream_t s);
 int launch_to_act(int dtype, const float* in, void* out, int64_t total, hipStream_t s);
 int launch_from_act(int dtype, const void* in, float* out, int64_t total, hipStream_t s);
 int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, hipStream_t s);
@@ -38,3 +40,10 @@ int launch_pack_aux_weights(int dtype, const float* w, void* out, int C, int cou
 int aux_head_supported(int dtype, int res, int C, int cout);
 int launch_aux_head(int dtype, const void* x, const float2* ab, const void* wpack, const float* bias, const float* x_t,
                     const float* coef, float* out, int B, int C, int cout, hipStream_t s);
+
+// MFMA stem conv (aux.hip): conv3x3(c_in * x_t) + bias, img_channels -> 128, NCHW fp32 in, NHWC activations out.
+int stem_supported(int res, int cin, int cout);
+size_t stem_pack_elems();
+int launch_pack_stem_weights(int dtype, const float* w, void* out, int cin, hipStream_t s);
+int launch_stem(int dtype, const float* x, const float* c_in, const void* wpack, const float* bias, void* out, int B,
+                int res, int cin, hipStream_t s);

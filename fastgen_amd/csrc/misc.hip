@@ -362,6 +362,44 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restr
     }
 }
 
+// Down-sampling blocks: conv0 consumes mean_2x2(silu(gn(x))) (Conv2d.forward :118-123 applied to silu(norm0(x)), :276).
+// Doing that inside the conv's operand staging costs 4x the transform work per staged pixel; this pass writes the pooled
+// tensor once (HBM-bound: reads x, writes a quarter of it) and the conv then runs without prologue.
+// x [B, 2H, 2W, C] -> out [B, H, W, C]; a thread owns 8 channels of one output pixel.
+template <typename AT, bool FAST>
+__global__ void gn_silu_pool_kernel(const AT* __restrict__ x, const float2* __restrict__ ab, AT* __restrict__ out, int B,
+                                    int H, int W, int C) {
+    const int oc = C >> 3;
+    const int64_t total = (int64_t)B * H * W * oc;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(i % oc);
+        int64_t t = i / oc;
+        const int xx = (int)(t % W); t /= W;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        float2 k[8];
+        const float2* kp = ab + (size_t)n * C + o * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) k[j] = kp[j];
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const AT* p = x + ((((size_t)n * 2 * H + 2 * y + (d >> 1)) * 2 * W) + 2 * xx + (d & 1)) * C + o * 8;
+            const f32x4 lo = load4(p), hi = load4(p + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[j] += silu_f<FAST>(fmaf(lo[j], k[j].x, k[j].y));
+                acc[j + 4] += silu_f<FAST>(fmaf(hi[j], k[j + 4].x, k[j + 4].y));
+            }
+        }
+        AT* q = out + (size_t)i * 8;
+        store4(q, f32x4{0.25f * acc[0], 0.25f * acc[1], 0.25f * acc[2], 0.25f * acc[3]});
+        store4(q + 4, f32x4{0.25f * acc[4], 0.25f * acc[5], 0.25f * acc[6], 0.25f * acc[7]});
+    }
+}
+
 template <typename A, typename B>
 __global__ void convert_kernel(const A* __restrict__ in, B* __restrict__ out, int64_t total) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
@@ -468,6 +506,15 @@ int launch_x0_to_eps(const float* xt, const float* x0, double tv, const double* 
 }
 int launch_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, const uint64_t* seed_dev, hipStream_t s) {
     hipLaunchKernelGGL(randn_kernel, dim3(ew_grid((total + 3) / 4)), dim3(256), 0, s, out, total, seed, offset, seed_dev);
+    RET_LAST();
+}
+int launch_gn_silu_pool(int dtype, const void* x, const float2* ab, void* out, int B, int H, int W, int C, hipStream_t s) {
+    if (C % 8) return (int)hipErrorInvalidValue;
+    const int64_t total = (int64_t)B * H * W * (C / 8);
+    if (dtype)
+        hipLaunchKernelGGL((gn_silu_pool_kernel<__bf16, true>), dim3(ew_grid(total)), dim3(256), 0, s, (const __bf16*)x, ab, (__bf16*)out, B, H, W, C);
+    else
+        hipLaunchKernelGGL((gn_silu_pool_kernel<float, false>), dim3(ew_grid(total)), dim3(256), 0, s, (const float*)x, ab, (float*)out, B, H, W, C);
     RET_LAST();
 }
 int launch_to_act(int dtype, const float* in, void* out, int64_t total, hipStream_t s) {
