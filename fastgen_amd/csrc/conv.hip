@@ -30,24 +30,29 @@ constexpr int NTHR = 256;
 
 template <int KS, int LOGW>
 struct Geom {
-    static constexpr int W = 1 << LOGW;
-    static constexpr int LOGTH = (LOGW == 5) ? 2 : 3;
-    static constexpr int TH = 1 << LOGTH;           // tile rows per image
-    static constexpr int IMGS = 128 / (TH * W);     // images per tile (2 at 8x8, else 1)
-    static constexpr int TPI = (IMGS > 1) ? 1 : W / TH;  // tiles (= statistics slots) per image
+    static constexpr int W = 1 << LOGW;              // image width (= height)
+    // Pixel tile of 128 outputs: 8 rows x 16 columns at 32x32 and 16x16 (halo 10 x 18 = 1.41x the tile; the former 4 x 32
+    // strip had 1.59x), two whole images at 8x8.
+    static constexpr int LOGTW = (LOGW == 5) ? 4 : LOGW;
+    static constexpr int TW = 1 << LOGTW;            // tile columns
+    static constexpr int LOGTH = 3;
+    static constexpr int TH = 1 << LOGTH;            // tile rows per image
+    static constexpr int IMGS = 128 / (TH * TW);     // images per tile (2 at 8x8, else 1)
+    static constexpr int TCOLS = W / TW;             // tiles across the image width
+    static constexpr int TPI = (IMGS > 1) ? 1 : (W / TH) * TCOLS;  // tiles (= statistics slots) per image
     static constexpr int PAD = KS / 2;
-    static constexpr int HW_ = W + 2 * PAD;
+    static constexpr int HW_ = TW + 2 * PAD;
     static constexpr int HH_ = TH + 2 * PAD;
     static constexpr int HALO_PIX = IMGS * HH_ * HW_;
     static constexpr int TAPS = KS * KS;
-    // LDS row stride.  A 32-pixel MFMA row tile spans 1 / 2 / 4 halo rows at W = 32 / 16 / 8; the row stride in 16-byte
-    // slots must be 0 (W=16) or 8 (W=8) mod 16 for the 16-lane ds_read_b128 groups to hit 16 distinct slots.
-    static constexpr int ROWPAD = (LOGW == 5) ? 0 : 16 * ((((LOGW == 4) ? 0 : 8) - (HW_ * 9) % 16 + 32) % 16);
+    // LDS row stride.  A 32-pixel MFMA row tile spans 2 / 4 halo rows at tile width 16 / 8; the row stride in 16-byte slots
+    // must be 0 (width 16) or 8 (width 8) mod 16 for the 16-lane ds_read_b128 groups to hit 16 distinct slots.
+    static constexpr int ROWPAD = 16 * ((((LOGTW == 4) ? 0 : 8) - (HW_ * 9) % 16 + 32) % 16);
     static constexpr int RS = HW_ * PITCH + ROWPAD;
     static constexpr int ABUF = IMGS * HH_ * RS;
     // LDS byte offset (tap 0,0) of tile pixel p in [0,128); additive in (p & ~31) and (p & 31)
     static __host__ __device__ constexpr int off0(int p) {
-        return (((p >> (LOGW + LOGTH)) * HH_) + ((p >> LOGW) & (TH - 1))) * RS + (p & (W - 1)) * PITCH;
+        return (((p >> (LOGTW + LOGTH)) * HH_) + ((p >> LOGTW) & (TH - 1))) * RS + (p & (TW - 1)) * PITCH;
     }
 };
 
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
 
     const int n_base = (G::IMGS > 1) ? tile * G::IMGS : tile / G::TPI;
     const int slot = (G::IMGS > 1) ? 0 : tile % G::TPI;
-    const int row0 = slot * G::TH;
+    const int row0 = (slot / G::TCOLS) * G::TH, col0 = (slot % G::TCOLS) * G::TW;
 
     // this wave's packed weights: [cout/32][step][kk][lane][8], two consecutive 32-channel groups
     const size_t wstride = (size_t)nsteps * (KK * 512);
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         const int hy = t % G::HH_;
         const int img = t / G::HH_;
         y = row0 + hy - G::PAD;
-        x = hx - G::PAD;
+        x = col0 + hx - G::PAD;
         n = n_base + img;
         lds_off = (img * G::HH_ + hy) * G::RS + hx * PITCH + oct * (8 * (int)sizeof(T));
         return (hq < G::HALO_PIX) && (y >= 0) && (y < H) && (x >= 0) && (x < G::W) && (n < a.B);
@@ -364,8 +369,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         // global element offset of this lane's quad for pixel row pl of pixel tile mt (or -1 past the batch)
         auto goff = [&](int mt, int j, bool& ok) -> size_t {
             const int p = mt * 32 + j * RP + prow;
-            const int x = p & (G::W - 1);
-            const int y = row0 + ((p >> LOGW) & (G::TH - 1));
+            const int x = col0 + (p & (G::TW - 1));
+            const int y = row0 + ((p >> G::LOGTW) & (G::TH - 1));
             const int n = n_base + mt / MT_PER_IMG;
             ok = n < a.B;
             return (((size_t)n * H + y) * G::W + x) * ostride + co_out;
@@ -438,9 +443,9 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int i4 = 0; i4 < 16; i4 += 4) {
                     const int p = mt * 32 + acc_row(i4, h);  // 4 consecutive pixels p..p+3 (same row)
-                    const int x = p & (G::W - 1);
-                    const int y = row0 + ((p >> LOGW) & (G::TH - 1));
-                    const int n = n_base + (p >> (LOGW + G::LOGTH));
+                    const int x = col0 + (p & (G::TW - 1));
+                    const int y = row0 + ((p >> G::LOGTW) & (G::TH - 1));
+                    const int n = n_base + (p >> (G::LOGTW + G::LOGTH));
                     if (n < a.B)
                         store4(vt + ((size_t)n * 256 + cl) * HWo + y * G::W + x,
                                f32x4{acc[mt][nt][i4] + bias, acc[mt][nt][i4 + 1] + bias, acc[mt][nt][i4 + 2] + bias,
