@@ -229,12 +229,28 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
 
     // ---- prologue: chunk 0 of A, step 0 of B ------------------------------------------------------
     if (AB_REGS) load_ab(0, n_base, abr);
+    if (DEFER && ND == 1) {
+        // all loads of chunk 0 first, branch-free (out-of-image pixels read a clamped address and are zeroed by `valid`),
+        // then the transforms: one global-load latency per workgroup instead of one per item
+        Frag8<ST> raw0[NITEMS][ND];
+        bool valid0[NITEMS];
 #pragma unroll
-    for (int i = 0; i < NITEMS; ++i) {
-        Frag8<ST> raw[ND] = {};
-        bool valid = false;
-        if (DEFER) item_load(0, i, raw, valid);
-        item_finish(0, i, smem, raw, valid);
+        for (int i = 0; i < NITEMS; ++i) {
+            int n, y, x, lo;
+            valid0[i] = decode(min(hq0 + i * PSTRIDE, G::HALO_PIX - 1), n, y, x, lo);
+            const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), G::W - 1), nc = min(n, a.B - 1);
+            raw0[i][0] = load_frag(src_ptr(0, nc, (RES == RES_UP) ? (yc >> 1) : yc, (RES == RES_UP) ? (xc >> 1) : xc));
+        }
+#pragma unroll
+        for (int i = 0; i < NITEMS; ++i) item_finish(0, i, smem, raw0[i], valid0[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NITEMS; ++i) {
+            Frag8<ST> raw[ND] = {};
+            bool valid = false;
+            if (DEFER) item_load(0, i, raw, valid);
+            item_finish(0, i, smem, raw, valid);
+        }
     }
     Frag8<T> bfr[NT][KK];
 #pragma unroll
