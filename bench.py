@@ -180,8 +180,14 @@ def main():
         _lib.check(L.fg_edm_profile_end(h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)))
         ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         peak = PEAK_TFLOPS[args.dtype]
+        # HBM bytes per launch of that kernel come from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file);
+        # they cannot be collected from inside this process, so the committed profile of the same command is quoted
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_traffic_dominant_kernel.json")
+        if args.dtype == "bf16" and B == 512 and os.path.exists(tfile):
+            traffic = int(json.load(open(tfile))["hbm_bytes_per_launch"])
         roof = {"bound": "mfma", "kernel": "conv_fused_kernel<T,3,PRO_GN_SILU,RES_NONE,32x32>",
-                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2),
                 "avg_launch_gflop": round(fl.value / max(n.value, 1) / 1e9, 2),
                 "whole_step": {"achieved": round(value / world * GFLOP_PER_IMAGE_FWD * args.sample_steps / 1e3, 2),
