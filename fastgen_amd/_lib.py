@@ -10,6 +10,9 @@ LIB_PATH = os.path.join(_HERE, "libfastgen_amd.so")
 FG_MAX_LEVELS = 8
 FG_DTYPE_F32, FG_DTYPE_BF16 = 0, 1
 FG_SAMPLE_SDE, FG_SAMPLE_ODE = 0, 1
+FG_LOOP_X0, FG_LOOP_MEANFLOW = 0, 1
+FG_SCHEDULE_EDM, FG_SCHEDULE_RF = 0, 1
+FG_DROP_PRECOND_INPUT, FG_DROP_PRECOND_OUTPUT = 1, 2
 
 
 class fg_edm_config(ctypes.Structure):
@@ -18,7 +21,8 @@ class fg_edm_config(ctypes.Structure):
         ("model_channels", c_int), ("num_levels", c_int), ("channel_mult", c_int * FG_MAX_LEVELS),
         ("channel_mult_emb", c_int), ("num_blocks", c_int), ("num_attn_resolutions", c_int),
         ("attn_resolutions", c_int * FG_MAX_LEVELS), ("channel_mult_noise", c_int), ("sigma_data", c_double),
-        ("sigma_shift", c_double), ("compute_dtype", c_int),
+        ("sigma_shift", c_double), ("compute_dtype", c_int), ("r_timestep", c_int), ("drop_precond", c_int),
+        ("schedule", c_int),
     ]
 
 
@@ -33,10 +37,12 @@ SIGNATURES = {
     "fg_edm_bind_param": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
     "fg_edm_pack_weights": (c_int, [c_void_p, c_void_p]),
     "fg_edm_workspace_bytes": (c_size_t, [c_void_p, c_int]),
-    "fg_edm_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
-    "fg_sampler_run": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double), c_int, c_int, c_void_p, c_uint64,
+    "fg_edm_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                               c_size_t, c_void_p]),
+    "fg_sampler_run": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double), c_int, c_int, c_int, c_void_p, c_uint64,
                                c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "fg_edm_t_list": (c_int, [c_int, POINTER(c_double)]),
+    "fg_rf_t_list": (c_int, [c_int, POINTER(c_double)]),
     "fg_edm_profile_begin": (c_int, [c_void_p]),
     "fg_edm_profile_end": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
     "fg_edm_num_blocks": (c_int, [c_void_p]),
@@ -46,8 +52,8 @@ SIGNATURES = {
                                  c_size_t, c_void_p]),
     "fg_op_gn_coeffs": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]),
     "fg_op_latents": (c_int, [c_void_p, c_double, c_void_p, c_int64, c_void_p]),
-    "fg_op_forward_process": (c_int, [c_void_p, c_void_p, c_double, c_void_p, c_int64, c_void_p]),
-    "fg_op_x0_to_eps": (c_int, [c_void_p, c_void_p, c_double, c_void_p, c_int64, c_void_p]),
+    "fg_op_forward_process": (c_int, [c_void_p, c_void_p, c_double, c_int, c_void_p, c_int64, c_void_p]),
+    "fg_op_x0_to_eps": (c_int, [c_void_p, c_void_p, c_double, c_int, c_void_p, c_int64, c_void_p]),
     "fg_op_randn": (c_int, [c_void_p, c_int64, c_uint64, c_uint64, c_void_p]),
 }
 

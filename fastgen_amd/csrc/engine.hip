@@ -100,12 +100,12 @@ struct Workspace {
 };
 
 struct GraphKey {
-    int B = 0, steps = 0, type = 0;
+    int B = 0, steps = 0, type = 0, loop = 0;
     uint64_t zero_mask = 0;
     const void *noise = nullptr, *labels = nullptr, *eps = nullptr, *out = nullptr, *ws = nullptr;
     bool device_rng = false;
     bool operator==(const GraphKey& o) const {
-        return B == o.B && steps == o.steps && type == o.type && zero_mask == o.zero_mask && noise == o.noise &&
+        return B == o.B && steps == o.steps && type == o.type && loop == o.loop && zero_mask == o.zero_mask && noise == o.noise &&
                labels == o.labels && eps == o.eps && out == o.out && ws == o.ws && device_rng == o.device_rng;
     }
 };
@@ -115,7 +115,7 @@ struct GraphKey {
 struct fg_edm {
     fg_edm_config cfg;
     int dtype = 0;
-    int emb_ch = 0, noise_ch = 0;
+    int emb_ch = 0, noise_ch = 0, cond_ch = 0;  // cond_ch = noise_ch * (1 + r_timestep), EDM/network.py:376
     std::vector<Param> params;
     std::vector<Block> enc, dec;  // dec includes aux_norm / aux_conv entries
     std::vector<Block*> blocks;   // UNetBlocks only, encoder then decoder order
@@ -175,7 +175,7 @@ namespace {
 // Module order of SongUNet (standard encoder / decoder), reference EDM/network.py:417-486; state-dict names as there.
 void build_layout(fg_edm* h) {
     const fg_edm_config& c = h->cfg;
-    const int E = h->emb_ch, N = h->noise_ch;
+    const int E = h->emb_ch, N = h->cond_ch;
     if (c.label_dim) {
         h->add("model.map_label.weight", {N, c.label_dim});
         h->add("model.map_label.bias", {N});
@@ -297,7 +297,7 @@ void build_layout(fg_edm* h) {
             h->dec.push_back(a);
         }
     }
-    h->add("model.logvar_linear.weight", {1, N});
+    h->add("model.logvar_linear.weight", {1, h->noise_ch});  // Linear(noise_channels, 1), EDM/network.py:487
     h->add("model.logvar_linear.bias", {1});
     for (auto& b : h->enc)
         if (b.kind == K_BLOCK) h->blocks.push_back(&b);
@@ -334,8 +334,8 @@ size_t plan_workspace(const fg_edm* h, int B, Arena& A, Workspace& w) {
         max_c = std::max(max_c, std::max(b->cin, b->cout));
         if (b->attn) max_attn_hw = std::max(max_attn_hw, b->res_out * b->res_out);
     }
-    w.coef = A.get<float>(4 * (size_t)B);
-    w.emb0 = A.get<float>((size_t)B * h->noise_ch);
+    w.coef = A.get<float>(5 * (size_t)B);
+    w.emb0 = A.get<float>((size_t)B * h->cond_ch);
     w.emb1 = A.get<float>((size_t)B * h->emb_ch);
     w.emb = A.get<float>((size_t)B * h->emb_ch);
     w.temb = A.get<float>((size_t)B * h->temb_total);
@@ -474,21 +474,24 @@ int run_block(fg_edm* h, const Block& b, const Act& x1, int c1, const Act& x2, i
 
 int run_mapping(fg_edm* h, const float* labels, int B, Workspace& w, hipStream_t s) {
     const fg_edm_config& c = h->cfg;
-    HIP_TRY(launch_mapping_in(w.coef + B, h->freqs, labels, c.label_dim, h->P(h->find("model.map_label.weight")),
-                              h->P(h->find("model.map_label.bias")), w.emb0, B, h->noise_ch, s));
+    HIP_TRY(launch_mapping_in(w.coef + B, w.coef + 4 * (size_t)B, h->freqs, labels, c.label_dim,
+                              h->P(h->find("model.map_label.weight")), h->P(h->find("model.map_label.bias")), w.emb0, B,
+                              h->cond_ch, h->noise_ch, s));
     HIP_TRY(launch_linear(w.emb0, h->P(h->find("model.map_layer0.weight")), h->P(h->find("model.map_layer0.bias")), w.emb1,
-                          B, h->noise_ch, h->emb_ch, 1, s));
+                          B, h->cond_ch, h->emb_ch, 1, s));
     HIP_TRY(launch_linear(w.emb1, h->P(h->find("model.map_layer1.weight")), h->P(h->find("model.map_layer1.bias")), w.emb, B,
                           h->emb_ch, h->emb_ch, 1, s));
     HIP_TRY(launch_linear(w.emb, h->aff_w, h->aff_b, w.temb, B, h->emb_ch, h->temb_total, 0, s));
     return FG_OK;
 }
 
-// EDMPrecond.forward (eval, fwd_pred_type = x0): EDM/network.py:881-974 + SongUNet.forward :489-574.
-int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, const float* labels, float* out, int B,
-                Workspace& w, hipStream_t s) {
+// EDMPrecond.forward (eval, fwd_pred_type = net_pred_type): EDM/network.py:881-974 + SongUNet.forward :489-574.
+// r (target time of r_timestep networks) is required iff cfg.r_timestep.
+int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, const double* r, int r_stride,
+                const float* labels, float* out, int B, Workspace& w, hipStream_t s) {
     const fg_edm_config& c = h->cfg;
-    HIP_TRY(launch_precond_coef(t, t_stride, c.sigma_data, c.sigma_shift, 1e-6, w.coef, B, s));
+    HIP_TRY(launch_precond_coef(t, t_stride, c.r_timestep ? r : nullptr, r_stride, c.sigma_data, c.sigma_shift, 1e-6,
+                                c.drop_precond, w.coef, B, s));
     int rc = run_mapping(h, labels, B, w, s);
     if (rc) return rc;
     // encoder
@@ -534,31 +537,53 @@ int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, cons
 }
 
 int enqueue_sampler(fg_edm* h, const float* noise, const float* labels, const double* t_list, int steps, int type,
-                    const float* eps, float* out, int B, Workspace& w, hipStream_t s) {
+                    int loop, const float* eps, float* out, int B, Workspace& w, hipStream_t s) {
     const fg_edm_config& c = h->cfg;
+    const int sched = c.schedule;
     const int64_t total = (int64_t)B * c.img_channels * c.img_resolution * c.img_resolution;
     HIP_TRY(launch_latents(noise, 0.0, w.tl, 0, w.x, total, s));  // latents = noise * sigma(t_0), noise_schedule.py:72-88
+    auto sde_noise = [&](int i, const float** e) -> int {
+        if (eps) {
+            *e = eps + (size_t)i * total;
+        } else {
+            HIP_TRY(launch_randn(w.eps, total, 0, (uint64_t)i, w.seed, s));
+            *e = w.eps;
+        }
+        return FG_OK;
+    };
+    if (loop == FG_LOOP_MEANFLOW) {
+        // MeanFlowModel._student_sample_loop (consistency_model/mean_flow.py:336-381): the network output is the
+        // average velocity u(x, t, r); 'sde' jumps to r = 0 and re-noises, 'ode' integrates t_cur -> t_next.
+        for (int i = 0; i < steps; ++i) {
+            const double* r = (type == FG_SAMPLE_SDE) ? w.tl + steps : w.tl + i + 1;  // t_list[steps] == 0
+            int rc = run_forward(h, w.x, w.tl + i, 0, r, 0, labels, w.x_pred, B, w, s);
+            if (rc) return rc;
+            const bool renoise = type == FG_SAMPLE_SDE && t_list[i + 1] > 0;
+            float* dst = (i == steps - 1 && !renoise) ? out : w.x;
+            HIP_TRY(launch_meanflow_update(w.x, w.x_pred, w.tl, i, type == FG_SAMPLE_SDE ? -1 : i + 1, dst, total, s));
+            if (renoise) {
+                const float* e = nullptr;
+                if ((rc = sde_noise(i, &e))) return rc;
+                HIP_TRY(launch_forward_process(w.x, e, 0.0, w.tl, i + 1, sched, w.x, total, s));
+            }
+        }
+        return FG_OK;
+    }
+    // FastGenModel._student_sample_loop (methods/model.py:315-372): x0 prediction, then re-noise to t_next
     for (int i = 0; i < steps; ++i) {
         float* pred = (i == steps - 1) ? out : w.x_pred;
-        int rc = run_forward(h, w.x, w.tl + i, 0, labels, pred, B, w, s);
+        int rc = run_forward(h, w.x, w.tl + i, 0, w.tl + steps, 0, labels, pred, B, w, s);
         if (rc) return rc;
         if (t_list[i + 1] > 0) {  // methods/model.py:356 — decided on the host, baked into the graph
             const float* e = nullptr;
             if (type == FG_SAMPLE_SDE) {
-                if (eps) {
-                    e = eps + (size_t)i * total;
-                } else {
-                    HIP_TRY(launch_randn(w.eps, total, 0, (uint64_t)i, w.seed, s));
-                    e = w.eps;
-                }
+                if ((rc = sde_noise(i, &e))) return rc;
             } else {
-                HIP_TRY(launch_x0_to_eps(w.x, pred, 0.0, w.tl, i, 1e-6, w.eps, total, s));
+                HIP_TRY(launch_x0_to_eps(w.x, pred, 0.0, w.tl, i, sched, 1e-6, w.eps, total, s));
                 e = w.eps;
             }
-            HIP_TRY(launch_forward_process(pred, e, 0.0, w.tl, i + 1, w.x, total, s));
-            if (i == steps - 1) {
-                // t_list[-1] must be 0 (model.py:410), so the last step never re-noises; unreachable by contract
-            }
+            // t_list[-1] must be 0 (model.py:410), so the last step never re-noises
+            HIP_TRY(launch_forward_process(pred, e, 0.0, w.tl, i + 1, sched, w.x, total, s));
         }
     }
     return FG_OK;
@@ -634,6 +659,9 @@ int fg_edm_create(const fg_edm_config* cfg, fg_edm** out) {
         cfg->num_attn_resolutions > FG_MAX_LEVELS)
         return fail(FG_EINVAL, "bad num_levels / num_attn_resolutions");
     if (cfg->compute_dtype != FG_DTYPE_F32 && cfg->compute_dtype != FG_DTYPE_BF16) return fail(FG_EINVAL, "bad compute_dtype");
+    if ((cfg->drop_precond & ~3) || (cfg->schedule != FG_SCHEDULE_EDM && cfg->schedule != FG_SCHEDULE_RF) ||
+        (cfg->r_timestep & ~1))
+        return fail(FG_EINVAL, "bad r_timestep / drop_precond / schedule");
     if (cfg->model_channels <= 0 || cfg->model_channels % 16 || cfg->channel_mult_noise < 1 || cfg->channel_mult_emb < 1)
         return fail(FG_EINVAL, "bad channel configuration");
     fg_edm* h = new fg_edm();
@@ -641,6 +669,7 @@ int fg_edm_create(const fg_edm_config* cfg, fg_edm** out) {
     h->dtype = cfg->compute_dtype;
     h->emb_ch = cfg->model_channels * cfg->channel_mult_emb;
     h->noise_ch = cfg->model_channels * cfg->channel_mult_noise;
+    h->cond_ch = h->noise_ch * (cfg->r_timestep ? 2 : 1);
     build_layout(h);
     int rc = check_supported(h);
     if (rc) {
@@ -728,16 +757,18 @@ size_t fg_edm_workspace_bytes(const fg_edm* h, int batch) {
     return plan_workspace(h, batch, A, w);
 }
 
-int fg_edm_forward(fg_edm* h, const float* x_t, const double* t, const float* class_labels, float* out, float* emb_out,
-                   int batch, void* workspace, size_t workspace_bytes, void* stream) {
+int fg_edm_forward(fg_edm* h, const float* x_t, const double* t, const double* r, const float* class_labels, float* out,
+                   float* emb_out, int batch, void* workspace, size_t workspace_bytes, void* stream) {
     if (!h || !x_t || !t || !out) return fail(FG_EINVAL, "null argument");
+    if (r && !h->cfg.r_timestep) return fail(FG_EINVAL, "r_noise_labels provided, but r_timestep is not set");  // EDM/network.py:510
+    if (!r && h->cfg.r_timestep) return fail(FG_EINVAL, "this network was built with r_timestep: r is required");
     if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
     if (out == x_t) return fail(FG_EINVAL, "out must not alias x_t");
     Workspace w;
     int rc = setup_ws(h, batch, workspace, workspace_bytes, w);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    rc = run_forward(h, x_t, t, 1, class_labels, out, batch, w, s);
+    rc = run_forward(h, x_t, t, 1, r, 1, class_labels, out, batch, w, s);
     if (rc) return rc;
     if (emb_out) HIP_TRY(hipMemcpyAsync(emb_out, w.emb, sizeof(float) * (size_t)batch * h->emb_ch, hipMemcpyDeviceToDevice, s));
     return FG_OK;
@@ -768,17 +799,34 @@ int fg_edm_t_list(int sample_steps, double* out_host) {
     return FG_OK;
 }
 
+int fg_rf_t_list(int sample_steps, double* out_host) {
+    if (sample_steps < 1 || sample_steps > 64 || !out_host) return fail(FG_EINVAL, "bad sample_steps");
+    // BaseNoiseSchedule.get_t_list (noise_schedule.py:259-272): linspace(max_t, 0, n+1) in fp64, ATen's symmetric form
+    const double max_t = 0.999;
+    const int n = sample_steps + 1;
+    const double step = (0.0 - max_t) / (double)(n - 1);
+    for (int i = 0; i < n; ++i) {
+        const double v = (i < n / 2) ? max_t + step * (double)i : 0.0 - step * (double)(n - 1 - i);
+        out_host[i] = v > max_t ? max_t : v;
+    }
+    return FG_OK;
+}
+
 int fg_sampler_run(fg_edm* h, const float* noise, const float* class_labels, const double* t_list, int steps,
-                   int sample_type, const float* eps, uint64_t seed, float* out, int batch, void* workspace,
+                   int sample_type, int loop_kind, const float* eps, uint64_t seed, float* out, int batch, void* workspace,
                    size_t workspace_bytes, int use_graph, void* stream) {
     if (!h || !noise || !t_list || !out) return fail(FG_EINVAL, "null argument");
     if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
     if (steps < 1 || steps > 64) return fail(FG_EINVAL, "steps must be in [1, 64]");
     if (sample_type != FG_SAMPLE_SDE && sample_type != FG_SAMPLE_ODE) return fail(FG_EINVAL, "bad sample_type");
     if (t_list[steps] != 0.0) return fail(FG_EINVAL, "t_list[-1] must be zero");  // methods/model.py:410
+    if (loop_kind != FG_LOOP_X0 && loop_kind != FG_LOOP_MEANFLOW) return fail(FG_EINVAL, "bad loop_kind");
+    if ((loop_kind == FG_LOOP_MEANFLOW) != (h->cfg.r_timestep != 0))
+        return fail(FG_EINVAL, "FG_LOOP_MEANFLOW needs an r_timestep network and FG_LOOP_X0 a network without one");
+    const double t_lo = h->cfg.schedule == FG_SCHEDULE_RF ? 0.0 : 0.002, t_hi = h->cfg.schedule == FG_SCHEDULE_RF ? 0.999 : 80.0;
     for (int i = 0; i < steps; ++i)
-        if (!(t_list[i] >= 0.002 * (1 - 1e-12) && t_list[i] <= 80.0 * (1 + 1e-12)))  // is_t_valid, noise_schedule.py:409-423
-            return fail(FG_EINVAL, "t_list[%d] = %g outside [0.002, 80]", i, t_list[i]);
+        if (!(t_list[i] >= t_lo * (1 - 1e-12) && t_list[i] <= t_hi * (1 + 1e-12)))  // is_t_valid, noise_schedule.py:409-423
+            return fail(FG_EINVAL, "t_list[%d] = %g outside [%g, %g]", i, t_list[i], t_lo, t_hi);
     Workspace w;
     int rc = setup_ws(h, batch, workspace, workspace_bytes, w);
     if (rc) return rc;
@@ -796,10 +844,11 @@ int fg_sampler_run(fg_edm* h, const float* noise, const float* class_labels, con
         HIP_TRY(hipEventRecord(h->slot_ev[si], s));
         h->slot_used[si] = true;
     }
-    if (!use_graph || h->prof_on) return enqueue_sampler(h, noise, class_labels, t_list, steps, sample_type, eps, out, batch, w, s);
+    if (!use_graph || h->prof_on)
+        return enqueue_sampler(h, noise, class_labels, t_list, steps, sample_type, loop_kind, eps, out, batch, w, s);
 
     GraphKey key;
-    key.B = batch; key.steps = steps; key.type = sample_type;
+    key.B = batch; key.steps = steps; key.type = sample_type; key.loop = loop_kind;
     for (int i = 1; i <= steps; ++i)
         if (t_list[i] > 0) key.zero_mask |= (1ull << i);
     key.noise = noise; key.labels = class_labels; key.eps = eps; key.out = out; key.ws = workspace;
@@ -809,7 +858,7 @@ int fg_sampler_run(fg_edm* h, const float* noise, const float* class_labels, con
         if (!h->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
         hipStream_t cs = h->cap_stream;  // capture records, it does not execute: the graph is launched on `s` below
         HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-        rc = enqueue_sampler(h, noise, class_labels, t_list, steps, sample_type, eps, out, batch, w, cs);
+        rc = enqueue_sampler(h, noise, class_labels, t_list, steps, sample_type, loop_kind, eps, out, batch, w, cs);
         hipGraph_t g = nullptr;
         hipError_t e = hipStreamEndCapture(cs, &g);
         if (rc) {
@@ -944,12 +993,13 @@ int fg_op_latents(const float* noise, double t_init, float* out, int64_t total, 
     HIP_TRY(launch_latents(noise, t_init, nullptr, 0, out, total, (hipStream_t)stream));
     return FG_OK;
 }
-int fg_op_forward_process(const float* x0, const float* eps, double t, float* out, int64_t total, void* stream) {
-    HIP_TRY(launch_forward_process(x0, eps, t, nullptr, 0, out, total, (hipStream_t)stream));
+int fg_op_forward_process(const float* x0, const float* eps, double t, int schedule, float* out, int64_t total,
+                          void* stream) {
+    HIP_TRY(launch_forward_process(x0, eps, t, nullptr, 0, schedule, out, total, (hipStream_t)stream));
     return FG_OK;
 }
-int fg_op_x0_to_eps(const float* xt, const float* x0, double t, float* out, int64_t total, void* stream) {
-    HIP_TRY(launch_x0_to_eps(xt, x0, t, nullptr, 0, 1e-6, out, total, (hipStream_t)stream));
+int fg_op_x0_to_eps(const float* xt, const float* x0, double t, int schedule, float* out, int64_t total, void* stream) {
+    HIP_TRY(launch_x0_to_eps(xt, x0, t, nullptr, 0, schedule, 1e-6, out, total, (hipStream_t)stream));
     return FG_OK;
 }
 int fg_op_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, void* stream) {

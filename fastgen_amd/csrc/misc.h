@@ -8,10 +8,10 @@ int launch_gn_coeffs(int dtype, const void* x1, int c1, const void* x2, int c2, 
                      float eps, float2* ab, int batch, int hw, hipStream_t s);
 int launch_gn_finalize(const float2* st1, int c1, int s1, const float2* st2, int c2, int s2, const float* gamma,
                        const float* beta, float eps, float2* ab, int batch, int hw, hipStream_t s);
-int launch_precond_coef(const double* t, int t_stride, double sigma_data, double sigma_shift, double clamp_min,
-                        float* coef, int B, hipStream_t s);
-int launch_mapping_in(const float* c_noise, const float* freqs, const float* labels, int label_dim, const float* wl,
-                      const float* bl, float* out, int B, int N, hipStream_t s);
+int launch_precond_coef(const double* t, int t_stride, const double* r, int r_stride, double sigma_data,
+                        double sigma_shift, double clamp_min, int drop, float* coef, int B, hipStream_t s);
+int launch_mapping_in(const float* c_noise, const float* r_noise, const float* freqs, const float* labels, int label_dim,
+                      const float* wl, const float* bl, float* out, int B, int N, int noise_ch, hipStream_t s);
 int launch_linear(const float* x, const float* w, const float* bias, float* y, int B, int I, int O, int act_silu,
                   hipStream_t s);
 int launch_conv_in(int dtype, const float* x, const float* c_in, const float* w, const float* bias, void* out, int B,
@@ -19,10 +19,12 @@ int launch_conv_in(int dtype, const float* x, const float* c_in, const float* w,
 int launch_aux_out(int dtype, const void* x, const float2* ab, const float* w, const float* bias, const float* x_t,
                    const float* coef, float* out, int B, int res, int C, int cout, hipStream_t s);
 int launch_latents(const float* noise, double tv, const double* tp, int ti, float* out, int64_t total, hipStream_t s);
-int launch_forward_process(const float* x0, const float* eps, double tv, const double* tp, int ti, float* out,
+int launch_forward_process(const float* x0, const float* eps, double tv, const double* tp, int ti, int sched, float* out,
                            int64_t total, hipStream_t s);
-int launch_x0_to_eps(const float* xt, const float* x0, double tv, const double* tp, int ti, double clamp_min, float* out,
-                     int64_t total, hipStream_t s);
+int launch_x0_to_eps(const float* xt, const float* x0, double tv, const double* tp, int ti, int sched, double clamp_min,
+                     float* out, int64_t total, hipStream_t s);
+int launch_meanflow_update(const float* x, const float* u, const double* tp, int ia, int ib, float* out, int64_t total,
+                           hipStream_t s);
 int launch_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, const uint64_t* seed_dev, hipStream_t s);
 // out[B,H,W,C] = mean over 2x2 of silu(a*x+b), x [B,2H,2W,C]
 int launch_gn_silu_pool(int dtype, const void* x, const float2* ab, void* out, int B, int H, int W, int C, hipStream_t s);

@@ -103,32 +103,52 @@ __global__ void gn_finalize_kernel(const float2* __restrict__ st1, int C1, int S
 
 // ---------------------------------------------------------------------------------------------------
 // EDM preconditioning coefficients in fp64 (precond_input :755-778, precond_output :781-805), cast to fp32 exactly
-// where the reference casts (`.to(x_t.dtype)`).  coef[4][B] = c_in, c_noise, c_skip, c_out.
-__global__ void precond_coef_kernel(const double* __restrict__ t, int t_stride, double sigma_data, double sigma_shift,
-                                    double clamp_min, float* __restrict__ coef, int B) {
+// where the reference casts (`.to(x_t.dtype)`).  coef[5][B] = c_in, c_noise, c_skip, c_out, r_noise.
+// drop bit 0 (drop_precond 'input'/'both', :929-934): x and the noise labels pass through unchanged (t, r cast to fp32);
+// drop bit 1 ('output'/'both', :959-960): the network output is returned as is (c_skip = 0, c_out = 1).
+__global__ void precond_coef_kernel(const double* __restrict__ t, int t_stride, const double* __restrict__ r, int r_stride,
+                                    double sigma_data, double sigma_shift, double clamp_min, int drop,
+                                    float* __restrict__ coef, int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const double tv = t[(size_t)b * t_stride];
+    const double rv = r ? r[(size_t)b * r_stride] : 0.0;
     const double sd2 = sigma_data * sigma_data;
-    coef[b] = (float)(1.0 / sqrt(sd2 + tv * tv));
-    coef[B + b] = (float)(log(fmax(tv, clamp_min)) / 4.0);
-    const double ts = tv - sigma_shift;
-    coef[2 * B + b] = (float)(sd2 / (ts * ts + sd2));
-    coef[3 * B + b] = (float)(ts * sigma_data / sqrt(ts * ts + sd2));
+    if (drop & 1) {
+        coef[b] = 1.0f;
+        coef[B + b] = (float)tv;
+        coef[4 * B + b] = (float)rv;
+    } else {
+        coef[b] = (float)(1.0 / sqrt(sd2 + tv * tv));
+        coef[B + b] = (float)(log(fmax(tv, clamp_min)) / 4.0);
+        coef[4 * B + b] = (float)(log(fmax(rv, clamp_min)) / 4.0);
+    }
+    if (drop & 2) {
+        coef[2 * B + b] = 0.0f;
+        coef[3 * B + b] = 1.0f;
+    } else {
+        const double ts = tv - sigma_shift;
+        coef[2 * B + b] = (float)(sd2 / (ts * ts + sd2));
+        coef[3 * B + b] = (float)(ts * sigma_data / sqrt(ts * ts + sd2));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Mapping-network input: positional embedding of c_noise (sin|cos after the flip at :503) + map_label(labels*sqrt(L))
 // (:306-319, :501-517).  out [B][N].
-__global__ void mapping_in_kernel(const float* __restrict__ c_noise, const float* __restrict__ freqs,
-                                  const float* __restrict__ labels, int label_dim, const float* __restrict__ wl,
-                                  const float* __restrict__ bl, float* __restrict__ out, int B, int N) {
+// With r_timestep (:401-408, 505-509) a second embedding of the r labels is concatenated: N = noise_ch * 2.
+__global__ void mapping_in_kernel(const float* __restrict__ c_noise, const float* __restrict__ r_noise,
+                                  const float* __restrict__ freqs, const float* __restrict__ labels, int label_dim,
+                                  const float* __restrict__ wl, const float* __restrict__ bl, float* __restrict__ out, int B,
+                                  int N, int noise_ch) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * N) return;
     const int b = idx / N, j = idx % N;
-    const int half = N / 2;
-    const float ang = c_noise[b] * freqs[j % half];
-    float v = (j < half) ? sinf(ang) : cosf(ang);
+    const int half = noise_ch / 2;
+    const int jj = j % noise_ch;
+    const float lab = (j < noise_ch) ? c_noise[b] : r_noise[b];
+    const float ang = lab * freqs[jj % half];
+    float v = (jj < half) ? sinf(ang) : cosf(ang);
     if (label_dim > 0) {
         float acc = 0.f;
         const float sc = sqrtf((float)label_dim);
@@ -293,18 +313,34 @@ __global__ void latents_kernel(const float* __restrict__ noise, double tv, const
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = (float)((double)noise[i] * t);
 }
-__global__ void forward_process_kernel(const float* __restrict__ x0, const float* __restrict__ eps, double tv,
-                                       const double* tp, int ti, float* __restrict__ out, int64_t total) {
+// sched 0: EDM (alpha = 1, sigma = t; noise_schedule.py:773-777); sched 1: rectified flow (alpha = 1 - t, sigma = t; :1337-1341)
+__device__ __forceinline__ double alpha_of(double t, int sched) { return sched ? 1.0 - t : 1.0; }
+
+__global__ void forward_process_kernel(const float* x0, const float* __restrict__ eps, double tv, const double* tp,
+                                       int ti, int sched, float* out, int64_t total) {  // out may alias x0
+#pragma clang fp contract(off)  // torch evaluates mul, mul, add with separate roundings: no fused multiply-add
     const double t = pick_t(tv, tp, ti);
+    const double al = alpha_of(t, sched);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = (float)((double)x0[i] * 1.0 + (double)eps[i] * t);  // alpha(t) = 1, sigma(t) = t (EDM, :773-777)
+        out[i] = (float)((double)x0[i] * al + (double)eps[i] * t);
 }
 __global__ void x0_to_eps_kernel(const float* __restrict__ xt, const float* __restrict__ x0, double tv, const double* tp,
-                                 int ti, double clamp_min, float* __restrict__ out, int64_t total) {
-    double t = pick_t(tv, tp, ti);
-    t = (t >= 0.0) ? fmax(t, clamp_min) : fmin(t, -clamp_min);  // non_zero_clamp, noise_schedule.py:123-129
+                                 int ti, int sched, double clamp_min, float* __restrict__ out, int64_t total) {
+#pragma clang fp contract(off)
+    const double t0 = pick_t(tv, tp, ti);
+    const double al = alpha_of(t0, sched);
+    const double t = (t0 >= 0.0) ? fmax(t0, clamp_min) : fmin(t0, -clamp_min);  // non_zero_clamp, noise_schedule.py:123-129
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = (float)(((double)xt[i] - (double)x0[i] * 1.0) / t);
+        out[i] = (float)(((double)xt[i] - (double)x0[i] * al) / t);
+}
+// MeanFlow update x <- x - delta_t * u with delta_t = fp32(t_a - t_b) (mean_flow.py:366-376; t_b = nullptr index < 0: 0).
+// Two fp32 roundings (product, then difference) as torch evaluates it: no fused multiply-add.
+__global__ void meanflow_update_kernel(const float* x, const float* __restrict__ u, const double* tp, int ia, int ib,
+                                       float* out, int64_t total) {  // out may alias x
+#pragma clang fp contract(off)
+    const float dt = (float)(ib >= 0 ? tp[ia] - tp[ib] : tp[ia]);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = x[i] - dt * u[i];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -442,17 +478,17 @@ int launch_gn_finalize(const float2* st1, int c1, int s1, const float2* st2, int
     RET_LAST();
 }
 
-int launch_precond_coef(const double* t, int t_stride, double sigma_data, double sigma_shift, double clamp_min,
-                        float* coef, int B, hipStream_t s) {
-    hipLaunchKernelGGL(precond_coef_kernel, dim3((B + 127) / 128), dim3(128), 0, s, t, t_stride, sigma_data, sigma_shift,
-                       clamp_min, coef, B);
+int launch_precond_coef(const double* t, int t_stride, const double* r, int r_stride, double sigma_data,
+                        double sigma_shift, double clamp_min, int drop, float* coef, int B, hipStream_t s) {
+    hipLaunchKernelGGL(precond_coef_kernel, dim3((B + 127) / 128), dim3(128), 0, s, t, t_stride, r, r_stride, sigma_data,
+                       sigma_shift, clamp_min, drop, coef, B);
     RET_LAST();
 }
 
-int launch_mapping_in(const float* c_noise, const float* freqs, const float* labels, int label_dim, const float* wl,
-                      const float* bl, float* out, int B, int N, hipStream_t s) {
-    hipLaunchKernelGGL(mapping_in_kernel, dim3((B * N + 255) / 256), dim3(256), 0, s, c_noise, freqs, labels, label_dim, wl,
-                       bl, out, B, N);
+int launch_mapping_in(const float* c_noise, const float* r_noise, const float* freqs, const float* labels, int label_dim,
+                      const float* wl, const float* bl, float* out, int B, int N, int noise_ch, hipStream_t s) {
+    hipLaunchKernelGGL(mapping_in_kernel, dim3((B * N + 255) / 256), dim3(256), 0, s, c_noise, r_noise, freqs, labels,
+                       label_dim, wl, bl, out, B, N, noise_ch);
     RET_LAST();
 }
 
@@ -494,14 +530,19 @@ int launch_latents(const float* noise, double tv, const double* tp, int ti, floa
     hipLaunchKernelGGL(latents_kernel, dim3(ew_grid(total)), dim3(256), 0, s, noise, tv, tp, ti, out, total);
     RET_LAST();
 }
-int launch_forward_process(const float* x0, const float* eps, double tv, const double* tp, int ti, float* out,
+int launch_forward_process(const float* x0, const float* eps, double tv, const double* tp, int ti, int sched, float* out,
                            int64_t total, hipStream_t s) {
-    hipLaunchKernelGGL(forward_process_kernel, dim3(ew_grid(total)), dim3(256), 0, s, x0, eps, tv, tp, ti, out, total);
+    hipLaunchKernelGGL(forward_process_kernel, dim3(ew_grid(total)), dim3(256), 0, s, x0, eps, tv, tp, ti, sched, out, total);
     RET_LAST();
 }
-int launch_x0_to_eps(const float* xt, const float* x0, double tv, const double* tp, int ti, double clamp_min, float* out,
-                     int64_t total, hipStream_t s) {
-    hipLaunchKernelGGL(x0_to_eps_kernel, dim3(ew_grid(total)), dim3(256), 0, s, xt, x0, tv, tp, ti, clamp_min, out, total);
+int launch_x0_to_eps(const float* xt, const float* x0, double tv, const double* tp, int ti, int sched, double clamp_min,
+                     float* out, int64_t total, hipStream_t s) {
+    hipLaunchKernelGGL(x0_to_eps_kernel, dim3(ew_grid(total)), dim3(256), 0, s, xt, x0, tv, tp, ti, sched, clamp_min, out, total);
+    RET_LAST();
+}
+int launch_meanflow_update(const float* x, const float* u, const double* tp, int ia, int ib, float* out, int64_t total,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(meanflow_update_kernel, dim3(ew_grid(total)), dim3(256), 0, s, x, u, tp, ia, ib, out, total);
     RET_LAST();
 }
 int launch_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, const uint64_t* seed_dev, hipStream_t s) {

@@ -35,6 +35,9 @@ class FastGenModel:
     """Only the sampling classmethods of the reference class; they are what `scripts/inference/*`, `scripts/fid/*` and
     the wandb callback call."""
 
+    # which fg_sampler_run loop restates this class's _student_sample_loop (see EDMPrecond.fused_loop)
+    _fused_loop = "x0"
+
     @classmethod
     def _student_sample_loop(cls, net, x: torch.Tensor, t_list: torch.Tensor, condition: Any = None,
                              student_sample_type: str = "sde", **kwargs) -> torch.Tensor:
@@ -75,12 +78,14 @@ class FastGenModel:
                     f"t_list length (excluding zero) != student_sample_steps: {len(t_list) - 1} != {student_sample_steps}")
                 t_list = torch.tensor(t_list, dtype=net.noise_scheduler.t_precision)
             assert t_list[-1].item() == 0, "t_list[-1] must be zero"
-            fused = isinstance(net, EDMPrecond) and data is None and not hasattr(net, "preserve_conditioning")
+            fused = (isinstance(net, EDMPrecond) and net.fused_loop() == cls._fused_loop and data is None
+                     and not hasattr(net, "preserve_conditioning"))
             if fused:
                 kw = dict(kwargs)
                 out = net.few_step_sample(noise, kw.pop("condition", None), t_list,
                                           sample_type=kw.pop("student_sample_type", "sde"), eps=kw.pop("eps", None),
-                                          seed=kw.pop("seed", None), use_graph=kw.pop("use_graph", True))
+                                          seed=kw.pop("seed", None), use_graph=kw.pop("use_graph", True),
+                                          loop=cls._fused_loop)
                 if kw:
                     raise TypeError(f"unexpected generator_fn kwargs: {sorted(kw)}")
                 return out.to(dtype=noise.dtype)

@@ -12,8 +12,12 @@ fastgen/configs/net.py:29-48).  What is kept identical to the reference:
 Parameters are ordinary fp32 `nn.Parameter`s; the library borrows their device pointers and keeps MFMA-order
 copies of the conv weights that are rebuilt whenever a parameter's storage or version changes.
 
-Not provided on this path (raises, never falls back): training backward, feature taps, `r` timestep, non-SongUNet
-model types, and any device but a HIP GPU.
+Both network flavours of the reference's EDM CIFAR-10 configs are covered: the DMD2 / consistency students
+(x0 prediction, EDM schedule, full preconditioning) and the MeanFlow student (configs/experiments/EDM/
+config_mf_cifar10.py: r_timestep=True, drop_precond='both', schedule_type='rf', net_pred_type='flow').
+
+Not provided on this path (raises, never falls back): training backward, feature taps, non-SongUNet model types,
+and any device but a HIP GPU.
 """
 from __future__ import annotations
 
@@ -77,14 +81,13 @@ class EDMPrecond(FastGenNetwork):
         super().__init__(net_pred_type=net_pred_type, schedule_type=schedule_type, **model_kwargs)
         if model_type != "SongUNet":
             raise ValueError(f"fastgen_amd implements model_type='SongUNet' only, got '{model_type}'")
-        if drop_precond is not None:
-            if drop_precond not in ["input", "output", "both"]:
-                raise ValueError(f"drop_precond must be one of 'input', 'output', 'both', or None, got {drop_precond}")
-            raise NotImplementedError("drop_precond is not implemented by the fused MI355X path")
+        if drop_precond is not None and drop_precond not in ["input", "output", "both"]:
+            raise ValueError(f"drop_precond must be one of 'input', 'output', 'both', or None, got {drop_precond}")
+        if self.noise_scheduler.schedule_id < 0:
+            raise NotImplementedError(f"schedule_type={schedule_type!r} is not implemented by the fused MI355X path")
         mk = dict(model_kwargs)
         unsupported = {
-            "embedding_type": "positional", "encoder_type": "standard", "decoder_type": "standard",
-            "r_timestep": False, "label_dropout": 0,
+            "embedding_type": "positional", "encoder_type": "standard", "decoder_type": "standard", "label_dropout": 0,
         }
         for k, want in unsupported.items():
             if mk.get(k, want) != want:
@@ -97,6 +100,7 @@ class EDMPrecond(FastGenNetwork):
         self.sigma_data = sigma_data
         self.sigma_shift = sigma_shift
         self.drop_precond = drop_precond
+        self.r_timestep = bool(mk.get("r_timestep", False))
         self.dropout = mk.get("dropout", 0.10)
         self.compute_dtype = compute_dtype or os.environ.get("FASTGEN_AMD_COMPUTE_DTYPE") or None
         if self.compute_dtype not in (None, "fp32", "bf16"):
@@ -120,6 +124,10 @@ class EDMPrecond(FastGenNetwork):
             cfg.attn_resolutions[i] = a
         cfg.channel_mult_noise = mk.get("channel_mult_noise", 1)
         cfg.sigma_data, cfg.sigma_shift = float(sigma_data), float(sigma_shift)
+        cfg.r_timestep = int(self.r_timestep)
+        cfg.drop_precond = {None: 0, "input": _lib.FG_DROP_PRECOND_INPUT, "output": _lib.FG_DROP_PRECOND_OUTPUT,
+                            "both": _lib.FG_DROP_PRECOND_INPUT | _lib.FG_DROP_PRECOND_OUTPUT}[drop_precond]
+        cfg.schedule = self.noise_scheduler.schedule_id
         self._cfg = cfg
         self._engines: Dict[int, ctypes.c_void_p] = {}
         self._bound_sig: Dict[int, Any] = {}
@@ -289,8 +297,10 @@ class EDMPrecond(FastGenNetwork):
             assert fwd_pred_type in NET_PRED_TYPES, f"{fwd_pred_type} is not supported as fwd_pred_type"
         if len(feature_indices) or return_features_early:
             raise NotImplementedError("feature taps (feature_indices) belong to the training path; not implemented")
-        if r is not None:
+        if r is not None and not self.r_timestep:
             raise ValueError("r_noise_labels provided, but r_timestep is not set")
+        if r is None and self.r_timestep:
+            raise ValueError("this network was built with r_timestep=True: forward() needs r")
         if fwd_kwargs:
             raise TypeError(f"unexpected forward kwargs: {sorted(fwd_kwargs)}")
         if self.training and self.dropout:
@@ -308,12 +318,21 @@ class EDMPrecond(FastGenNetwork):
         t64 = t64.contiguous()
         if t64.numel() != B:
             raise ValueError(f"t has {t64.numel()} entries, expected {B}")
+        r64 = None
+        if r is not None:
+            r64 = torch.atleast_1d(r.detach()).to(device=dev, dtype=torch.float64)
+            if r64.numel() == 1 and B > 1:
+                r64 = r64.expand(B)
+            r64 = r64.contiguous()
+            if r64.numel() != B:
+                raise ValueError(f"r has {r64.numel()} entries, expected {B}")
         labels = self._labels(condition, B, dev)
         dt, h = self._engine(dev)
         ws = self._workspace(dt, h, B, dev)
         out = torch.empty_like(x32)
         _lib.check(_lib.lib().fg_edm_forward(
             h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
+            ctypes.c_void_p(r64.data_ptr() if r64 is not None else None),
             ctypes.c_void_p(labels.data_ptr() if labels is not None else None), ctypes.c_void_p(out.data_ptr()), None,
             B, ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream(dev)))
         out = out.to(x_t.dtype)
@@ -325,7 +344,10 @@ class EDMPrecond(FastGenNetwork):
 
     def _logvar(self, t64: torch.Tensor) -> torch.Tensor:
         """logvar_linear(PositionalEmbedding(c_noise)) — the un-flipped [cos|sin] embedding (EDM/network.py:501,571)."""
-        c_noise = (t64.clamp(min=self.noise_scheduler.clamp_min).log() / 4).to(torch.float32)
+        if self.drop_precond in ("input", "both"):
+            c_noise = t64.to(torch.float32)
+        else:
+            c_noise = (t64.clamp(min=self.noise_scheduler.clamp_min).log() / 4).to(torch.float32)
         half = self._noise_channels // 2
         freqs = torch.arange(half, dtype=torch.float32, device=t64.device) / (half - 1)
         freqs = (1 / 10000) ** freqs
@@ -335,15 +357,31 @@ class EDMPrecond(FastGenNetwork):
         return emb @ lv.weight.to(emb.dtype).t() + lv.bias.to(emb.dtype)
 
     # ------------------------------------------------------------------------------------------------
+    def fused_loop(self) -> Optional[str]:
+        """Which student sampling loop fg_sampler_run can run for this network: 'x0' (FastGenModel._student_sample_loop,
+        needs an x0-predicting network without r), 'meanflow' (MeanFlowModel._student_sample_loop, needs a
+        flow-predicting r_timestep network), or None (callers take the generic per-step loop)."""
+        if not self.r_timestep and self.net_pred_type == "x0":
+            return "x0"
+        if self.r_timestep and self.net_pred_type == "flow":
+            return "meanflow"
+        return None
+
     def few_step_sample(self, noise: torch.Tensor, condition: Optional[torch.Tensor], t_list, sample_type: str = "sde",
                         eps: Optional[torch.Tensor] = None, seed: Optional[int] = None, use_graph: bool = True,
-                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """The whole student sampling loop (methods/model.py:374-420) as ONE library call / one hipGraph replay.
+                        out: Optional[torch.Tensor] = None, loop: Optional[str] = None) -> torch.Tensor:
+        """The whole student sampling loop (methods/model.py:374-420 or consistency_model/mean_flow.py:336-381) as ONE
+        library call / one hipGraph replay.
 
         t_list: steps+1 decreasing timesteps ending in 0.  sample_type 'sde' re-noises with `eps`
         ([steps-1,B,C,H,W], injected) or, if eps is None, with normals drawn on the device from `seed`;
-        'ode' re-uses the implied noise (x0_to_eps)."""
+        'ode' re-uses the implied noise (x0 loop) / integrates the average velocity (MeanFlow loop).
+        loop: 'x0' | 'meanflow' (default: `fused_loop()`)."""
         self._check_inference()
+        loop = loop or self.fused_loop()
+        if loop is None or loop != self.fused_loop():
+            raise NotImplementedError(
+                f"the fused sampler has no loop {loop!r} for net_pred_type={self.net_pred_type!r}, r_timestep={self.r_timestep}")
         if noise.device.type != "cuda":
             raise RuntimeError("fastgen_amd runs on a HIP GPU only (no CPU path); got a tensor on " + str(noise.device))
         if sample_type not in ("sde", "ode"):
@@ -369,6 +407,7 @@ class EDMPrecond(FastGenNetwork):
         _lib.check(_lib.lib().fg_sampler_run(
             h, ctypes.c_void_p(n32.data_ptr()), ctypes.c_void_p(labels.data_ptr() if labels is not None else None),
             tl_arr, steps, _lib.FG_SAMPLE_SDE if sample_type == "sde" else _lib.FG_SAMPLE_ODE,
+            _lib.FG_LOOP_MEANFLOW if loop == "meanflow" else _lib.FG_LOOP_X0,
             ctypes.c_void_p(eps.data_ptr() if eps is not None and eps.numel() else None), ctypes.c_uint64(seed),
             ctypes.c_void_p(out.data_ptr()), B, ctypes.c_void_p(ws.data_ptr()), ws.numel(), 1 if use_graph else 0,
             self._stream(dev)))

@@ -1,5 +1,5 @@
 """`FastGenNetwork` duck type: the nn.Module surface the reference's methods / trainer / inference scripts
-call (fastgen/networks/network.py:13-208).  Only the EDM ('edm') schedule exists on this path."""
+call (fastgen/networks/network.py:13-208).  The 'edm' and 'rf' schedules exist on this path."""
 from __future__ import annotations
 
 from abc import ABC, abstractmethod

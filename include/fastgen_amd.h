@@ -39,6 +39,15 @@ extern "C" {
 #define FG_SAMPLE_SDE 0  /* student_sample_type='sde'  (methods/model.py:358-359) */
 #define FG_SAMPLE_ODE 1  /* student_sample_type='ode'  (methods/model.py:360-361) */
 
+#define FG_LOOP_X0 0        /* FastGenModel._student_sample_loop: x0 prediction + re-noise (methods/model.py:315-372) */
+#define FG_LOOP_MEANFLOW 1  /* MeanFlowModel._student_sample_loop: x -= dt * u(x,t,r) (consistency_model/mean_flow.py:336-381) */
+
+#define FG_SCHEDULE_EDM 0   /* EDMNoiseSchedule: alpha = 1, sigma = t, t in [0.002, 80] (noise_schedule.py:729-777) */
+#define FG_SCHEDULE_RF 1    /* RFNoiseSchedule:  alpha = 1 - t, sigma = t, t in [0, 0.999] (noise_schedule.py:1306-1341) */
+
+#define FG_DROP_PRECOND_INPUT 1   /* drop_precond 'input'  (EDM/network.py:929-934); 'both' = INPUT | OUTPUT */
+#define FG_DROP_PRECOND_OUTPUT 2  /* drop_precond 'output' (EDM/network.py:959-960) */
+
 #define FG_MAX_LEVELS 8
 
 /* kwargs of EDMPrecond(model_type="SongUNet", embedding_type="positional", encoder_type=decoder_type="standard",
@@ -59,6 +68,9 @@ typedef struct fg_edm_config {
     double sigma_data;                   /* 0.5 */
     double sigma_shift;                  /* 0.0 (applied in eval mode only, EDM/network.py:956) */
     int compute_dtype;                   /* FG_DTYPE_* */
+    int r_timestep;                      /* 1: second (target-time) embedding, cond_channels doubled (EDM/network.py:376,401-408) */
+    int drop_precond;                    /* bit mask of FG_DROP_PRECOND_* (0 = full EDM preconditioning) */
+    int schedule;                        /* FG_SCHEDULE_*: the noise schedule the sampler loop re-noises with */
 } fg_edm_config;
 
 typedef struct fg_edm fg_edm; /* opaque */
@@ -87,24 +99,33 @@ int fg_edm_pack_weights(fg_edm* h, void* stream);
 /* Bytes of caller-provided scratch needed for a batch (activations, skip stack, norm statistics ...). */
 size_t fg_edm_workspace_bytes(const fg_edm* h, int batch);
 
-/* EDMPrecond.forward(x_t, t, condition=class_labels, fwd_pred_type="x0") in eval mode
- * (EDM/network.py:881-974).  x_t,out: [B,C,H,W] fp32; t: [B] fp64; class_labels: [B,label_dim] fp32 or NULL
- * (NULL = the reference's zeros([1,label_dim]) broadcast, :919-925).  All device pointers.  x_t is not modified;
- * out may not alias x_t.  emb_out (nullable): [B, model_channels*channel_mult_emb] mapping-network output. */
-int fg_edm_forward(fg_edm* h, const float* x_t, const double* t, const float* class_labels, float* out,
+/* EDMPrecond.forward(x_t, t, condition=class_labels, r=r, fwd_pred_type=net_pred_type) in eval mode
+ * (EDM/network.py:881-974).  x_t,out: [B,C,H,W] fp32; t: [B] fp64; r: [B] fp64, required iff cfg.r_timestep (else
+ * NULL, :505-510); class_labels: [B,label_dim] fp32 or NULL (NULL = the reference's zeros([1,label_dim]) broadcast,
+ * :919-925).  All device pointers.  x_t is not modified; out may not alias x_t.  emb_out (nullable):
+ * [B, model_channels*channel_mult_emb] mapping-network output. */
+int fg_edm_forward(fg_edm* h, const float* x_t, const double* t, const double* r, const float* class_labels, float* out,
                    float* emb_out, int batch, void* workspace, size_t workspace_bytes, void* stream);
 
-/* FastGenModel.generator_fn + _student_sample_loop (methods/model.py:315-420) for this network:
- *   x = noise * t_list[0]; for i: x0 = forward(x, t_i); if t_{i+1} > 0: x = x0 + t_{i+1} * eps_i; return x0.
+/* FastGenModel.generator_fn (methods/model.py:374-420) around one of the student sampling loops:
+ *   x = noise * sigma(t_list[0]);
+ *   FG_LOOP_X0 (model.py:315-372, x0-predicting network without r_timestep):
+ *     for i: x0 = forward(x, t_i); if t_{i+1} > 0: x = alpha(t_{i+1}) x0 + sigma(t_{i+1}) eps_i; return x0
+ *     ('ode': eps_i = x0_to_eps(x, x0, t_i)).
+ *   FG_LOOP_MEANFLOW (mean_flow.py:336-381, flow-predicting r_timestep network):
+ *     'sde': x -= t_i * forward(x, t_i, r=0); if t_{i+1} > 0: x = forward_process(x, eps_i, t_{i+1});
+ *     'ode': x -= (t_i - t_{i+1}) * forward(x, t_i, r=t_{i+1});   return x.
  * t_list: HOST array of steps+1 doubles, t_list[steps] must be 0 (model.py:410).  sample_type FG_SAMPLE_*.
  * eps: device [steps-1][B,C,H,W] noise to inject in 'sde' mode, or NULL to draw it on device from
  * (seed, step) with Philox4x32-10.  use_graph != 0 replays a cached hipGraph of the whole loop. */
 int fg_sampler_run(fg_edm* h, const float* noise, const float* class_labels, const double* t_list, int steps,
-                   int sample_type, const float* eps, uint64_t seed, float* out, int batch, void* workspace,
-                   size_t workspace_bytes, int use_graph, void* stream);
+                   int sample_type, int loop_kind, const float* eps, uint64_t seed, float* out, int batch,
+                   void* workspace, size_t workspace_bytes, int use_graph, void* stream);
 
 /* EDMNoiseSchedule.get_t_list(sample_steps) (noise_schedule.py:940-973) -> steps+1 doubles on the host. */
 int fg_edm_t_list(int sample_steps, double* out_host);
+/* RFNoiseSchedule.get_t_list(sample_steps) = BaseNoiseSchedule.get_t_list (noise_schedule.py:259-272). */
+int fg_rf_t_list(int sample_steps, double* out_host);
 
 /* ---- measurement hook (bench.py): time every launch of the dominant kernel — the fused 3x3 conv at 32x32 output
  * without resampling — with a hipEvent pair on the stream it is launched on.  While active the sampler runs eagerly
@@ -131,8 +152,9 @@ int fg_op_gn_coeffs(const float* x1, int c1, const float* x2, int c2, const floa
 
 /* Elementwise sampler steps in fp64 (noise_schedule.py:72-88, 425-449, 544-574); n = elements per sample. */
 int fg_op_latents(const float* noise, double t_init, float* out, int64_t total, void* stream);
-int fg_op_forward_process(const float* x0, const float* eps, double t, float* out, int64_t total, void* stream);
-int fg_op_x0_to_eps(const float* xt, const float* x0, double t, float* out, int64_t total, void* stream);
+int fg_op_forward_process(const float* x0, const float* eps, double t, int schedule, float* out, int64_t total,
+                          void* stream);
+int fg_op_x0_to_eps(const float* xt, const float* x0, double t, int schedule, float* out, int64_t total, void* stream);
 /* Standard normal draws: Philox4x32-10(key = seed, counter = (offset, index/4)) + Box-Muller. */
 int fg_op_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, void* stream);
 

@@ -47,6 +47,8 @@ class SongUNetConfig:
     sigma_data: float = 0.5
     sigma_shift: float = 0.0
     r_timestep: bool = False
+    drop_precond: Optional[str] = None  # None | "input" | "output" | "both" (EDM/network.py:818, 929-934, 959-960)
+    schedule: str = "edm"  # "edm" | "rf"  (noise_schedule.py:729-777 / 1306-1346)
 
     @property
     def emb_channels(self) -> int:
@@ -58,6 +60,9 @@ class SongUNetConfig:
 
 
 CIFAR10 = SongUNetConfig()
+# MeanFlow CIFAR-10 student: configs/methods/config_mean_flow.py:137-145 (r_timestep, label_dim 0) +
+# configs/experiments/EDM/config_mf_cifar10.py:37-46,62 (drop_precond 'both', rf schedule, flow prediction, augment_dim 6)
+CIFAR10_MEANFLOW = SongUNetConfig(label_dim=0, augment_dim=6, r_timestep=True, drop_precond="both", schedule="rf")
 
 
 @dataclass
@@ -288,9 +293,12 @@ def mapping(sd, cfg: SongUNetConfig, noise_labels: Tensor, class_labels: Optiona
     return emb
 
 
-def song_unet(sd, cfg: SongUNetConfig, x: Tensor, noise_labels: Tensor, class_labels, trace: Optional[dict] = None):
+def song_unet(sd, cfg: SongUNetConfig, x: Tensor, noise_labels: Tensor, class_labels, trace: Optional[dict] = None,
+              r_noise_labels: Optional[Tensor] = None):
     """SongUNet.forward (standard encoder/decoder), EDM/network.py:489-574."""
-    emb = mapping(sd, cfg, noise_labels, class_labels)
+    if r_noise_labels is not None and not cfg.r_timestep:
+        raise ValueError("r_noise_labels provided, but r_timestep is not set")  # :510
+    emb = mapping(sd, cfg, noise_labels, class_labels, r_noise_labels)
     if trace is not None:
         trace["emb"] = emb
     enc, dec = layout(cfg)
@@ -319,21 +327,34 @@ def song_unet(sd, cfg: SongUNetConfig, x: Tensor, noise_labels: Tensor, class_la
     return out
 
 
-def edm_precond_forward(sd, cfg: SongUNetConfig, x_t: Tensor, t: Tensor, condition: Optional[Tensor], trace=None) -> Tensor:
-    """EDMPrecond.forward with fwd_pred_type='x0' (identity conversion), eval mode, EDM/network.py:881-974;
-    precond_input :755-778 (clamp_min 1e-6 from the scheduler, :930), precond_output :781-805.
-    t is float64 on entry; coefficients are computed in float64 and cast to x_t.dtype before use."""
+def edm_precond_forward(sd, cfg: SongUNetConfig, x_t: Tensor, t: Tensor, condition: Optional[Tensor], trace=None,
+                        r: Optional[Tensor] = None) -> Tensor:
+    """EDMPrecond.forward with fwd_pred_type = net_pred_type (identity conversion), eval mode, EDM/network.py:881-974;
+    precond_input :755-778 (clamp_min 1e-6 from the scheduler, :930), precond_output :781-805; drop_precond :929-934,
+    :959-960.  t (and r) are float64 on entry; coefficients are computed in float64 and cast to x_t.dtype before use."""
     B = x_t.shape[0]
     t = t.to(torch.float64).reshape(-1)
+    if r is not None:
+        r = r.to(torch.float64).reshape(-1)
     if cfg.label_dim == 0:
         class_labels = None
     elif condition is None:
         class_labels = torch.zeros(1, cfg.label_dim, dtype=x_t.dtype)
     else:
         class_labels = condition.reshape(-1, cfg.label_dim)
-    c_in = (1.0 / (cfg.sigma_data**2 + t**2).sqrt()).to(x_t.dtype).reshape(B, 1, 1, 1)
-    c_noise = (t.clamp(min=1e-6).log() / 4).to(x_t.dtype)
-    F_x = song_unet(sd, cfg, c_in * x_t, c_noise, class_labels, trace=trace)
+    x_in, t_in, r_in = x_t, t, r
+    if cfg.drop_precond not in ("input", "both"):
+        c_in = (1.0 / (cfg.sigma_data**2 + t**2).sqrt()).to(x_t.dtype).reshape(B, 1, 1, 1)
+        x_in = c_in * x_t
+        t_in = t.clamp(min=1e-6).log() / 4
+        if r is not None:
+            r_in = r.clamp(min=1e-6).log() / 4
+    t_in = t_in.to(x_t.dtype)
+    if r_in is not None:
+        r_in = r_in.to(x_t.dtype)
+    F_x = song_unet(sd, cfg, x_in, t_in, class_labels, trace=trace, r_noise_labels=r_in)
+    if cfg.drop_precond in ("output", "both"):
+        return F_x
     ts = t - cfg.sigma_shift  # eval mode
     c_skip = (cfg.sigma_data**2 / (ts**2 + cfg.sigma_data**2)).to(x_t.dtype).reshape(B, 1, 1, 1)
     c_out = (ts * cfg.sigma_data / (ts**2 + cfg.sigma_data**2).sqrt()).to(x_t.dtype).reshape(B, 1, 1, 1)
@@ -367,17 +388,27 @@ def latents(noise: Tensor, t_init: Tensor) -> Tensor:
     return (noise.to(torch.float64) * t_init.to(torch.float64)).to(noise.dtype)
 
 
-def forward_process(x: Tensor, eps: Tensor, t: Tensor) -> Tensor:
-    """BaseNoiseSchedule.forward_process, noise_schedule.py:425-449 with alpha=1, sigma=t (:773-777)."""
+def rf_t_list(sample_steps: int, max_t=0.999) -> Tensor:
+    """RFNoiseSchedule.get_t_list = BaseNoiseSchedule.get_t_list, noise_schedule.py:259-272."""
+    return torch.linspace(max_t, 0, sample_steps + 1, dtype=torch.float64).clamp(max=max_t)
+
+
+def _alpha(tt: Tensor, schedule: str) -> Tensor:
+    """alpha(t): 1 for EDM (noise_schedule.py:773-774), 1 - t for rectified flow (:1337-1338); sigma(t) = t for both."""
+    return torch.ones_like(tt) if schedule == "edm" else 1 - tt
+
+
+def forward_process(x: Tensor, eps: Tensor, t: Tensor, schedule: str = "edm") -> Tensor:
+    """BaseNoiseSchedule.forward_process, noise_schedule.py:425-449."""
     tt = t.to(torch.float64).reshape(-1, *([1] * (x.dim() - 1)))
-    return (x.to(torch.float64) * 1.0 + eps.to(torch.float64) * tt).to(x.dtype)
+    return (x.to(torch.float64) * _alpha(tt, schedule) + eps.to(torch.float64) * tt).to(x.dtype)
 
 
-def x0_to_eps(xt: Tensor, x0: Tensor, t: Tensor, clamp_min=1e-6) -> Tensor:
+def x0_to_eps(xt: Tensor, x0: Tensor, t: Tensor, clamp_min=1e-6, schedule: str = "edm") -> Tensor:
     """BaseNoiseSchedule.x0_to_eps, noise_schedule.py:544-574; non_zero_clamp :123-129."""
     tt = t.to(torch.float64).reshape(-1, *([1] * (xt.dim() - 1)))
     s = torch.where(tt >= 0, tt.clamp(min=clamp_min), tt.clamp(max=-clamp_min))
-    return ((xt.to(torch.float64) - x0.to(torch.float64)) / s).to(xt.dtype)
+    return ((xt.to(torch.float64) - x0.to(torch.float64) * _alpha(tt, schedule)) / s).to(xt.dtype)
 
 
 def student_sample_loop(sd, cfg, x: Tensor, t_list: Tensor, condition, sample_type="sde", eps_list=None, trace=None):
@@ -395,23 +426,49 @@ def student_sample_loop(sd, cfg, x: Tensor, t_list: Tensor, condition, sample_ty
             if sample_type == "sde":
                 eps = eps_list[step]
             elif sample_type == "ode":
-                eps = x0_to_eps(x, x_pred, t_cur.expand(B))
+                eps = x0_to_eps(x, x_pred, t_cur.expand(B), schedule=cfg.schedule)
             else:
                 raise NotImplementedError(sample_type)
-            x = forward_process(x_pred, eps, t_next.expand(B))
+            x = forward_process(x_pred, eps, t_next.expand(B), cfg.schedule)
         step += 1
     return x_pred
 
 
+def meanflow_sample_loop(sd, cfg, x: Tensor, t_list: Tensor, condition, sample_type="sde", eps_list=None, trace=None):
+    """MeanFlowModel._student_sample_loop, methods/consistency_model/mean_flow.py:336-381: the network returns the
+    average velocity u(x, t, r) ('flow' prediction).  'sde' noise is injected through eps_list as above."""
+    B = x.shape[0]
+    step = 0
+    for t_cur, t_next in zip(t_list[:-1], t_list[1:]):
+        if sample_type == "sde":
+            delta_t = t_cur.reshape(1, 1, 1, 1).to(x.dtype)
+            u = edm_precond_forward(sd, cfg, x, t_cur.expand(B), condition, r=torch.zeros_like(t_next.expand(B)))
+            x = x - delta_t * u
+            if t_next > 0:
+                x = forward_process(x, eps_list[step], t_next.expand(B), cfg.schedule)
+        elif sample_type == "ode":
+            delta_t = (t_cur - t_next).reshape(1, 1, 1, 1).to(x.dtype)
+            u = edm_precond_forward(sd, cfg, x, t_cur.expand(B), condition, r=t_next.expand(B))
+            x = x - delta_t * u
+        else:
+            raise NotImplementedError(sample_type)
+        if trace is not None:
+            trace.setdefault("x", []).append(x)
+        step += 1
+    return x
+
+
 def generator_fn(sd, cfg, noise: Tensor, condition, student_sample_steps=4, t_list=None, sample_type="sde",
-                 eps_list=None, trace=None) -> Tensor:
-    """FastGenModel.generator_fn, methods/model.py:374-420 (fp32, no autocast, no `data`)."""
+                 eps_list=None, trace=None, loop="x0") -> Tensor:
+    """FastGenModel.generator_fn, methods/model.py:374-420 (fp32, no autocast, no `data`); loop selects the class's
+    _student_sample_loop: 'x0' (FastGenModel) or 'meanflow' (MeanFlowModel)."""
     with torch.inference_mode():
         if t_list is None:
-            t_list = edm_t_list(student_sample_steps)
+            t_list = edm_t_list(student_sample_steps) if cfg.schedule == "edm" else rf_t_list(student_sample_steps)
         else:
             assert len(t_list) - 1 == student_sample_steps
             t_list = torch.as_tensor(t_list, dtype=torch.float64)
         assert t_list[-1].item() == 0
         x = latents(noise, t_list[0])
-        return student_sample_loop(sd, cfg, x, t_list, condition, sample_type, eps_list, trace).to(noise.dtype)
+        fn = meanflow_sample_loop if loop == "meanflow" else student_sample_loop
+        return fn(sd, cfg, x, t_list, condition, sample_type, eps_list, trace).to(noise.dtype)

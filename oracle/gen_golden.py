@@ -9,6 +9,7 @@ Weights and inputs are not stored: they are regenerated from seeds by oracle/edm
 drift of the RNG stream is detected instead of silently comparing different problems.
 
 Usage:  python oracle/gen_golden.py            (writes tests/golden/*.pt)
+        python oracle/gen_golden.py meanflow   (only the MeanFlow / rectified-flow fixtures)
 """
 import os
 import sys
@@ -33,14 +34,15 @@ def sd_checksum(sd) -> torch.Tensor:
     return torch.stack([checksum(v) for _, v in sorted(sd.items())]).sum(0)
 
 
-def ref_net(edm_net, cfg: edm_ref.SongUNetConfig, sd):
+def ref_net(edm_net, cfg: edm_ref.SongUNetConfig, sd, **extra):
     net = edm_net.EDMPrecond(
         img_resolution=cfg.img_resolution, img_channels=cfg.img_channels, label_dim=cfg.label_dim,
         sigma_shift=cfg.sigma_shift, sigma_data=cfg.sigma_data, model_type="SongUNet", augment_dim=cfg.augment_dim,
         model_channels=cfg.model_channels, channel_mult=list(cfg.channel_mult), channel_mult_noise=cfg.channel_mult_noise,
         num_blocks=cfg.num_blocks, attn_resolutions=list(cfg.attn_resolutions),
         embedding_type="positional", encoder_type="standard", decoder_type="standard", resample_filter=[1, 1],
-        dropout=0.0, label_dropout=0, r_timestep=False, drop_precond=None,
+        dropout=0.0, label_dropout=0, r_timestep=cfg.r_timestep, drop_precond=cfg.drop_precond,
+        schedule_type=cfg.schedule, **extra,
     )
     ref_sd = net.state_dict()
     assert set(ref_sd) == set(sd), (set(ref_sd) ^ set(sd))
@@ -54,10 +56,78 @@ def seeded(shape, seed, dtype=torch.float32):
     return torch.randn(shape, generator=torch.Generator().manual_seed(seed)).to(dtype)
 
 
+def meanflow_fixtures(edm_net, ns):
+    """MeanFlow student on CIFAR-10 (configs/experiments/EDM/config_mf_cifar10.py): r_timestep network without
+    preconditioning on the rectified-flow schedule, sampled by MeanFlowModel._student_sample_loop."""
+    from fastgen.methods import MeanFlowModel
+
+    # ---- rectified-flow schedule ------------------------------------------------------------------------
+    sched = ns.RFNoiseSchedule()
+    fx = {f"t_list_{n}": sched.get_t_list(n) for n in (1, 2, 4)}
+    x = seeded((2, 3, 8, 8), 11)
+    e = seeded((2, 3, 8, 8), 12)
+    t = torch.tensor([0.7492, 0.2497], dtype=torch.float64)
+    fx["fp_out"] = sched.forward_process(x, e, t)
+    fx["lat_out"] = sched.latents(x, t_init=torch.tensor(0.999, dtype=torch.float64))
+    fx["x0eps_out"] = sched.x0_to_eps(x, e, t)
+    fx["flow_out"] = sched.x0_to_flow(x, e, t)
+    fx["max_sigma"] = torch.tensor(sched.max_sigma, dtype=torch.float64)
+    torch.save(fx, os.path.join(OUT, "schedule_rf.pt"))
+
+    # ---- full-width network: names, forward with (t, r), sampler -------------------------------------------
+    cfg = edm_ref.CIFAR10_MEANFLOW
+    sd = edm_ref.random_state_dict(cfg, seed=4321)
+    net = ref_net(edm_net, cfg, sd, net_pred_type="flow")
+    with open(os.path.join(OUT, "state_dict_keys_meanflow.txt"), "w") as f:
+        for k, v in net.state_dict().items():
+            f.write(f"{k} {' '.join(str(d) for d in v.shape)}\n")
+    B = 2
+    xin = seeded((B, 3, 32, 32), 41)
+    tt = torch.tensor([0.999, 0.4995], dtype=torch.float64)
+    rr = torch.tensor([0.0, 0.2497], dtype=torch.float64)
+    emb = {}
+    hk = net.model.map_layer1.register_forward_hook(
+        lambda m, i, o: emb.__setitem__("emb", torch.nn.functional.silu(o.detach().clone())))
+    with torch.inference_mode():
+        out = net(xin, tt, condition=None, r=rr, fwd_pred_type="flow")
+        out_x0 = net(xin, tt, condition=None, r=rr, fwd_pred_type="x0")
+    hk.remove()
+    # the other drop_precond settings on the same weights (each leaves one half of the preconditioning on)
+    variants = {}
+    for dp in (None, "input", "output"):
+        cfg_v = edm_ref.SongUNetConfig(**{**cfg.__dict__, "drop_precond": dp})
+        nv = ref_net(edm_net, cfg_v, sd, net_pred_type="flow")
+        with torch.inference_mode():
+            variants[str(dp)] = nv(xin, tt, condition=None, r=rr, fwd_pred_type="flow").clone()
+    noise = seeded((B, 3, 32, 32), 5)
+    eps_list = [seeded((B, 3, 32, 32), s) for s in (6, 7, 8)]
+    it = iter(eps_list)
+    orig_randn_like = torch.randn_like
+    try:
+        torch.randn_like = lambda x, **k: next(it).to(x.dtype)
+        out_sde = MeanFlowModel.generator_fn(net, noise, student_sample_steps=4, student_sample_type="sde")
+    finally:
+        torch.randn_like = orig_randn_like
+    out_ode = MeanFlowModel.generator_fn(net, noise, student_sample_steps=4, student_sample_type="ode")
+    out_1 = MeanFlowModel.generator_fn(net, noise, student_sample_steps=1, student_sample_type="ode")
+    out_tl = MeanFlowModel.generator_fn(net, noise, student_sample_steps=2, t_list=[0.999, 0.5, 0.0],
+                                        student_sample_type="ode")  # the config's recommended 2-step list (:15-17)
+    torch.save({"sd_checksum": sd_checksum(sd), "x_checksum": checksum(xin), "noise_checksum": checksum(noise),
+                "t": tt, "r": rr, "emb": emb["emb"], "out": out.clone(), "out_x0": out_x0.clone(),
+                "out_drop_None": variants["None"], "out_drop_input": variants["input"],
+                "out_drop_output": variants["output"], "out_sde": out_sde.clone(), "out_ode": out_ode.clone(),
+                "out_1step": out_1.clone(), "out_tlist": out_tl.clone()},
+               os.path.join(OUT, "meanflow_full_b2.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     edm_net, ns, model = _ref_import.import_reference()
     torch.manual_seed(0)
+    if sys.argv[1:] == ["meanflow"]:
+        meanflow_fixtures(edm_net, ns)
+        print("MeanFlow fixtures written to", OUT)
+        return
 
     # ---- (i)+(ii) schedule ------------------------------------------------------------------
     sched = ns.EDMNoiseSchedule()
@@ -178,6 +248,8 @@ def main():
         outs_nocond = nets(xs, ts, condition=None, fwd_pred_type="x0")
     torch.save({"sd_checksum": sd_checksum(sds), "out": outs.clone(), "out_nocond": outs_nocond.clone()},
                os.path.join(OUT, "forward_small.pt"))
+
+    meanflow_fixtures(edm_net, ns)
 
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):

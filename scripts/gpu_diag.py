@@ -61,7 +61,7 @@ def main():
             out = torch.empty(2, 3, 32, 32, device=dev)
             emb = torch.empty(2, 512, device=dev)
             xd, td, cd = x.to(dev), f["t"].to(dev), f["cond"].to(dev)
-            _lib.check(L.fg_edm_forward(h, xd.data_ptr(), td.data_ptr(), cd.data_ptr(), out.data_ptr(), emb.data_ptr(), 2,
+            _lib.check(L.fg_edm_forward(h, xd.data_ptr(), td.data_ptr(), None, cd.data_ptr(), out.data_ptr(), emb.data_ptr(), 2,
                                         ws.data_ptr(), ws.numel(), None))
             torch.cuda.synchronize()
             report("emb", emb.cpu(), f["emb"])

@@ -16,6 +16,7 @@ import pytest
 import torch
 
 from fastgen_amd import _lib
+from fastgen_amd.methods.consistency_model.mean_flow import MeanFlowModel
 from fastgen_amd.methods.model import FastGenModel
 from fastgen_amd.networks.EDM.network import EDMPrecond
 from oracle import edm_ref as R
@@ -98,14 +99,16 @@ def test_sampler_elementwise_bit_exact():
     L = _lib.lib()
     x, e = seeded((4, 3, 32, 32), 11), seeded((4, 3, 32, 32), 12)
     xd, ed, od = x.to(dev()), e.to(dev()), torch.empty(4, 3, 32, 32, device=dev())
-    for t in (79.5638, 17.498123, 0.1726, 0.002):
-        tt = torch.tensor(t, dtype=torch.float64)
-        _lib.check(L.fg_op_forward_process(xd.data_ptr(), ed.data_ptr(), t, od.data_ptr(), x.numel(), None))
-        assert torch.equal(od.cpu(), R.forward_process(x, e, tt.expand(4)))
-        _lib.check(L.fg_op_latents(xd.data_ptr(), t, od.data_ptr(), x.numel(), None))
-        assert torch.equal(od.cpu(), R.latents(x, tt))
-        _lib.check(L.fg_op_x0_to_eps(xd.data_ptr(), ed.data_ptr(), t, od.data_ptr(), x.numel(), None))
-        assert torch.equal(od.cpu(), R.x0_to_eps(x, e, tt.expand(4)))
+    for sched, sid, ts in (("edm", _lib.FG_SCHEDULE_EDM, (79.5638, 17.498123, 0.1726, 0.002)),
+                           ("rf", _lib.FG_SCHEDULE_RF, (0.999, 0.7492, 0.2497, 1e-7))):
+        for t in ts:
+            tt = torch.tensor(t, dtype=torch.float64)
+            _lib.check(L.fg_op_forward_process(xd.data_ptr(), ed.data_ptr(), t, sid, od.data_ptr(), x.numel(), None))
+            assert torch.equal(od.cpu(), R.forward_process(x, e, tt.expand(4), sched))
+            _lib.check(L.fg_op_latents(xd.data_ptr(), t, od.data_ptr(), x.numel(), None))
+            assert torch.equal(od.cpu(), R.latents(x, tt))
+            _lib.check(L.fg_op_x0_to_eps(xd.data_ptr(), ed.data_ptr(), t, sid, od.data_ptr(), x.numel(), None))
+            assert torch.equal(od.cpu(), R.x0_to_eps(x, e, tt.expand(4), schedule=sched))
 
 
 def test_randn_device_generator():
@@ -319,3 +322,89 @@ def test_reference_default_init_runs(nets):
         out = net(x, t)
     c_skip = 0.25 / (0.25 + 0.25)
     assert torch.allclose(out, c_skip * x, atol=1e-3)
+
+
+# ---- MeanFlow student (r_timestep, drop_precond, rectified flow): SURVEY 8(f) widening row ---------------------------
+
+KW_MF = {**KW, "label_dim": 0, "augment_dim": 6, "r_timestep": True, "drop_precond": "both", "schedule_type": "rf",
+         "net_pred_type": "flow"}
+
+
+@pytest.fixture(scope="module")
+def mf_sd():
+    return R.random_state_dict(R.CIFAR10_MEANFLOW, seed=4321)
+
+
+@pytest.fixture(scope="module")
+def mf_nets(mf_sd):
+    out = {}
+    for mode in ("fp32", "bf16"):
+        n = EDMPrecond(compute_dtype=mode, **KW_MF)
+        n.load_state_dict(mf_sd, strict=True)
+        out[mode] = n.to(dev()).eval()
+    return out
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_meanflow_forward_against_reference_golden(mf_nets, mf_sd, golden_dir, mode):
+    fx = load(golden_dir, "meanflow_full_b2.pt")
+    net = mf_nets[mode]
+    x = seeded((2, 3, 32, 32), 41).to(dev())
+    t, r = fx["t"].to(dev()), fx["r"].to(dev())
+    with torch.inference_mode():
+        check(net(x, t, r=r, fwd_pred_type="flow"), fx["out"], mode, "u(x, t, r)")
+        check(net(x, t, r=r), fx["out"], mode, "default fwd_pred_type = net_pred_type")
+        check(net(x, t, r=r, fwd_pred_type="x0"), fx["out_x0"], mode, "flow -> x0 conversion")
+        with pytest.raises(ValueError):
+            net(x, t)
+    # the other preconditioning settings on the same weights
+    for dp in (None, "input", "output"):
+        nv = EDMPrecond(compute_dtype=mode, **{**KW_MF, "drop_precond": dp})
+        nv.load_state_dict(mf_sd, strict=True)
+        nv = nv.to(dev()).eval()
+        with torch.inference_mode():
+            check(nv(x, t, r=r), fx[f"out_drop_{dp}"], mode, f"drop_precond={dp}")
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_meanflow_sampler_against_reference_golden(mf_nets, golden_dir, mode):
+    fx = load(golden_dir, "meanflow_full_b2.pt")
+    net = mf_nets[mode]
+    noise = seeded((2, 3, 32, 32), 5).to(dev())
+    eps = torch.stack([seeded((2, 3, 32, 32), s) for s in (6, 7, 8)]).to(dev())
+    gf = MeanFlowModel.generator_fn
+    sde = gf(net, noise, student_sample_steps=4, student_sample_type="sde", eps=eps)
+    check(sde, fx["out_sde"], mode, "meanflow 4-step sde (graph)")
+    assert torch.equal(sde, gf(net, noise, student_sample_steps=4, student_sample_type="sde", eps=eps, use_graph=False))
+    ode = gf(net, noise, student_sample_steps=4, student_sample_type="ode")
+    check(ode, fx["out_ode"], mode, "meanflow 4-step ode")
+    check(gf(net, noise, student_sample_steps=1, student_sample_type="ode"), fx["out_1step"], mode, "meanflow 1-step")
+    check(gf(net, noise, student_sample_steps=2, t_list=[0.999, 0.5, 0.0], student_sample_type="ode"), fx["out_tlist"],
+          mode, "meanflow 2-step recommended t_list")
+    # the generic per-step loop through the module's forward gives the fused loop's bits
+    with torch.inference_mode():
+        tl = net.noise_scheduler.get_t_list(4).to(dev())
+        x = net.noise_scheduler.latents(noise, tl[0])
+        gen = MeanFlowModel._student_sample_loop(net, x, tl, student_sample_type="ode")
+    assert torch.equal(gen, ode)
+    # FastGenModel's x0 loop is not defined for this network and is refused, not approximated
+    with pytest.raises(NotImplementedError):
+        net.few_step_sample(noise, None, [0.999, 0.0], loop="x0")
+    with pytest.raises(_lib.FastGenAMDError):  # t outside the rectified-flow range
+        gf(net, noise, student_sample_steps=1, t_list=[1.5, 0.0], student_sample_type="ode")
+
+
+def test_meanflow_batch16_against_oracle(mf_nets, mf_sd):
+    B = 16
+    noise = seeded((B, 3, 32, 32), 0)
+    eps = [seeded((B, 3, 32, 32), s) for s in (1, 2, 3)]
+    cfg = R.CIFAR10_MEANFLOW
+    want_sde = R.generator_fn(mf_sd, cfg, noise, None, 4, sample_type="sde", eps_list=eps, loop="meanflow")
+    want_ode = R.generator_fn(mf_sd, cfg, noise, None, 2, sample_type="ode", loop="meanflow")
+    for mode in ("fp32", "bf16"):
+        got = MeanFlowModel.generator_fn(mf_nets[mode], noise.to(dev()), student_sample_steps=4,
+                                         student_sample_type="sde", eps=torch.stack(eps).to(dev()))
+        check(got, want_sde, mode, f"meanflow B=16 sde {mode}")
+        got = MeanFlowModel.generator_fn(mf_nets[mode], noise.to(dev()), student_sample_steps=2,
+                                         student_sample_type="ode")
+        check(got, want_ode, mode, f"meanflow B=16 ode {mode}")

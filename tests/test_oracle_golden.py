@@ -129,3 +129,66 @@ def test_sampler_full_b2(golden_dir, full_sd):
     assert torch.allclose(R.generator_fn(full_sd, R.CIFAR10, noise, fx["cond"], 1), fx["out_1step"], rtol=1e-4, atol=2e-5)
     assert torch.allclose(R.generator_fn(full_sd, R.CIFAR10, noise, fx["cond"], 2, t_list=[40.0, 1.5, 0.0],
                                          sample_type="ode"), fx["out_tlist"], rtol=1e-4, atol=2e-5)
+
+
+# ---- MeanFlow student: r_timestep network, drop_precond, rectified-flow schedule -----------------------------------
+
+
+@pytest.fixture(scope="module")
+def mf_sd():
+    return R.random_state_dict(R.CIFAR10_MEANFLOW, seed=4321)
+
+
+def test_meanflow_state_dict_names_match_reference(golden_dir):
+    want = {}
+    for line in open(os.path.join(golden_dir, "state_dict_keys_meanflow.txt")):
+        parts = line.split()
+        want[parts[0]] = tuple(int(p) for p in parts[1:])
+    got = R.param_shapes(R.CIFAR10_MEANFLOW)
+    assert got == want
+    assert got["model.map_layer0.weight"] == (512, 256) and "model.map_label.weight" not in got
+
+
+def test_schedule_rf(golden_dir):
+    fx = _load(golden_dir, "schedule_rf.pt")
+    for n in (1, 2, 4):
+        assert torch.equal(R.rf_t_list(n), fx[f"t_list_{n}"])
+    x, e = _seeded((2, 3, 8, 8), 11), _seeded((2, 3, 8, 8), 12)
+    t = torch.tensor([0.7492, 0.2497], dtype=torch.float64)
+    assert torch.equal(R.forward_process(x, e, t, "rf"), fx["fp_out"])
+    assert torch.equal(R.latents(x, torch.tensor(0.999, dtype=torch.float64)), fx["lat_out"])
+    assert torch.equal(R.x0_to_eps(x, e, t, schedule="rf"), fx["x0eps_out"])
+
+
+def test_meanflow_forward_and_drop_precond(golden_dir, mf_sd):
+    fx = _load(golden_dir, "meanflow_full_b2.pt")
+    assert torch.allclose(_sd_cs(mf_sd), fx["sd_checksum"])
+    x = _seeded((2, 3, 32, 32), 41)
+    assert torch.allclose(_cs(x), fx["x_checksum"])
+    cfg = R.CIFAR10_MEANFLOW
+    with torch.inference_mode():
+        tr = {}
+        out = R.edm_precond_forward(mf_sd, cfg, x, fx["t"], None, trace=tr, r=fx["r"])
+        assert torch.allclose(tr["emb"], fx["emb"], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(out, fx["out"], rtol=1e-4, atol=2e-5)
+        for dp in (None, "input", "output"):
+            cfg_v = R.SongUNetConfig(**{**cfg.__dict__, "drop_precond": dp})
+            got = R.edm_precond_forward(mf_sd, cfg_v, x, fx["t"], None, r=fx["r"])
+            assert torch.allclose(got, fx[f"out_drop_{dp}"], rtol=1e-4, atol=2e-5), dp
+        with pytest.raises(ValueError):  # EDM/network.py:510
+            R.edm_precond_forward(R.random_state_dict(R.CIFAR10, 1), R.CIFAR10, x, fx["t"], None, r=fx["r"])
+
+
+def test_meanflow_sampler(golden_dir, mf_sd):
+    fx = _load(golden_dir, "meanflow_full_b2.pt")
+    cfg = R.CIFAR10_MEANFLOW
+    noise = _seeded((2, 3, 32, 32), 5)
+    assert torch.allclose(_cs(noise), fx["noise_checksum"])
+    eps = [_seeded((2, 3, 32, 32), s) for s in (6, 7, 8)]
+    kw = dict(rtol=1e-4, atol=2e-5)
+    assert torch.allclose(R.generator_fn(mf_sd, cfg, noise, None, 4, sample_type="sde", eps_list=eps, loop="meanflow"),
+                          fx["out_sde"], **kw)
+    assert torch.allclose(R.generator_fn(mf_sd, cfg, noise, None, 4, sample_type="ode", loop="meanflow"), fx["out_ode"], **kw)
+    assert torch.allclose(R.generator_fn(mf_sd, cfg, noise, None, 1, sample_type="ode", loop="meanflow"), fx["out_1step"], **kw)
+    assert torch.allclose(R.generator_fn(mf_sd, cfg, noise, None, 2, t_list=[0.999, 0.5, 0.0], sample_type="ode",
+                                         loop="meanflow"), fx["out_tlist"], **kw)
