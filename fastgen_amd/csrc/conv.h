@@ -40,6 +40,11 @@ enum { OUT_NHWC = 0, OUT_QKV = 1 };
 int launch_conv_fused(int dtype, int ks, int pro, int res, int outmode, const ConvArgs& a, hipStream_t stream);
 // partial-statistics slots per image for an output of width W (= pixel tiles per image, 1 when a tile spans images)
 int conv_stat_slots(int W);
+// wave-specialised persistent kernel for the dominant bf16 3x3 shapes (conv_ws.hip); launch_conv_fused dispatches to it
+bool conv_ws_supported(int dtype, int ks, int pro, int res, int outmode, const ConvArgs& a);
+bool conv_ws_enabled();
+int launch_conv_ws(int res, const ConvArgs& a, hipStream_t stream, bool prepare_only);
+int launch_conv_ws_debug(const ConvArgs& a, int abl, hipStream_t stream);  // ablation builds of the 32x32 shape
 int launch_conv_debug(int dtype, const ConvArgs& a, hipStream_t stream);  // ablation build, honours a.dbg
 // set the dynamic-LDS attribute of every instantiation of this dtype (call once, outside stream capture)
 int conv_prepare_all(int dtype);

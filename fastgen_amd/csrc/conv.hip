@@ -22,6 +22,7 @@
 //     writes them to a small side buffer, so the NEXT GroupNorm never re-reads the tensor (misc.hip gn_finalize).
 #include "common.h"
 #include "conv.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -499,16 +500,17 @@ __global__ void pack_conv_weights_kernel(const float* __restrict__ w, T* __restr
     }
 }
 
+size_t g_debug_extra_lds = 0;  // ablation only: pad the dynamic LDS request to force one workgroup per CU
 bool g_prepare_only = false;  // conv_prepare_all(): walk the dispatch tables, set attributes, launch nothing
 
 template <typename T, int KS, int PRO, int RES, int LOGW, int OUTMODE, int ABL = 0>
 int launch_one(const ConvArgs& a, hipStream_t stream) {
     using G = Geom<KS, LOGW>;
     const int tiles = (G::IMGS > 1) ? (a.B + G::IMGS - 1) / G::IMGS : a.B * G::TPI;
-    const size_t lds = 2 * (size_t)G::ABUF;
+    const size_t lds = 2 * (size_t)G::ABUF + (ABL ? g_debug_extra_lds : 0);
     auto kern = conv_fused_kernel<T, KS, PRO, RES, LOGW, OUTMODE, ABL>;
     static bool attr_done = false;  // raise the dynamic-LDS cap once per instantiation (never inside stream capture)
-    if (!attr_done) {
+    if (!attr_done || (ABL && g_debug_extra_lds)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
@@ -555,7 +557,8 @@ int launch_t(int ks, int pro, int res, int outmode, const ConvArgs& a, hipStream
 // compile-time ablation builds of the dominant shape (bf16, 3x3, no resample, 32x32): scripts/conv_ablate.py only
 int launch_conv_debug(int dtype, const ConvArgs& a, hipStream_t stream) {
     if (!dtype || a.W != 32) return (int)hipErrorInvalidValue;
-    switch (a.dbg) {
+    g_debug_extra_lds = (a.dbg & 16) ? 48 * 1024 : 0;
+    switch (a.dbg & 15) {
         case 0: return launch_one<__bf16, 3, PRO_GN_SILU, RES_NONE, 5, OUT_NHWC, 0>(a, stream);
         case 1: return launch_one<__bf16, 3, PRO_GN_SILU, RES_NONE, 5, OUT_NHWC, 1>(a, stream);
         case 2: return launch_one<__bf16, 3, PRO_GN_SILU, RES_NONE, 5, OUT_NHWC, 2>(a, stream);
@@ -577,7 +580,17 @@ int launch_conv_fused(int dtype, int ks, int pro, int res, int outmode, const Co
     if (res == RES_UP && (2 * a.Hs != a.H || 2 * a.Ws != a.W)) return (int)hipErrorInvalidValue;
     if (pro != PRO_NONE && !a.ab) return (int)hipErrorInvalidValue;
     if (outmode == OUT_QKV && (a.Cout != 768 || a.W > 16)) return (int)hipErrorInvalidValue;
+    if (conv_ws_enabled() && conv_ws_supported(dtype, ks, pro, res, outmode, a)) return launch_conv_ws(res, a, stream, false);
     return dtype ? launch_t<__bf16>(ks, pro, res, outmode, a, stream) : launch_t<float>(ks, pro, res, outmode, a, stream);
+}
+
+// FASTGEN_AMD_CONV_WS=0 keeps every conv on conv_fused_kernel (A/B measurements); read once.
+bool conv_ws_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("FASTGEN_AMD_CONV_WS");
+        return !(e && e[0] == '0');
+    }();
+    return on;
 }
 
 int conv_stat_slots(int W) { return W == 32 ? Geom<3, 5>::TPI : (W == 16 ? Geom<3, 4>::TPI : Geom<3, 3>::TPI); }
@@ -601,6 +614,15 @@ int conv_prepare_all(int dtype) {
             rc = dtype ? launch_t<__bf16>(1, PRO_GN, RES_NONE, OUT_QKV, a, nullptr) : launch_t<float>(1, PRO_GN, RES_NONE, OUT_QKV, a, nullptr);
     }
     g_prepare_only = false;
+    if (!rc && dtype) {
+        ConvArgs w{};
+        for (int res : {RES_NONE, RES_UP}) {
+            w.W = w.H = 32;
+            if (!rc) rc = launch_conv_ws(res, w, nullptr, true);
+            w.W = w.H = 16;
+            if (!rc) rc = launch_conv_ws(res, w, nullptr, true);
+        }
+    }
     return rc;
 }
 

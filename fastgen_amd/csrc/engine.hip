@@ -927,7 +927,7 @@ int fg_debug_conv_bench(int dtype, int batch, int cin, int res, int ks, int with
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    auto run = [&]() { return dbg < 0 ? launch_conv_fused(dtype, ks, ks == 3 ? PRO_GN_SILU : PRO_NONE, RES_NONE, OUT_NHWC, a, nullptr) : launch_conv_debug(dtype, a, nullptr); };
+    auto run = [&]() { return dbg >= 64 ? launch_conv_ws_debug(a, dbg - 64, nullptr) : dbg < 0 ? launch_conv_fused(dtype, ks, ks == 3 ? PRO_GN_SILU : PRO_NONE, RES_NONE, OUT_NHWC, a, nullptr) : launch_conv_debug(dtype, a, nullptr); };
     for (int i = 0; i < 3; ++i) HIP_TRY(run());
     HIP_TRY(hipEventRecord(e0, nullptr));
     for (int i = 0; i < iters; ++i) HIP_TRY(run());
