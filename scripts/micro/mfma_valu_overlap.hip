@@ -14,7 +14,7 @@ __global__ __launch_bounds__(512) void k(float* out, int n_mfma, int n_valu, int
     if (threadIdx.x < 1024) lds[threadIdx.x & 1023] = f32x4{1.f, 2.f, 3.f, 4.f};
     __syncthreads();
     if (wave < 4) {
-        if (prio) __builtin_amdgcn_s_setprio(3);
+        if (prio == 1) __builtin_amdgcn_s_setprio(3);
         f32x16 acc[8];
         for (int i = 0; i < 8; ++i)
             for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
@@ -26,6 +26,7 @@ __global__ __launch_bounds__(512) void k(float* out, int n_mfma, int n_valu, int
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+                if (MODE >= 10) asm volatile("s_nop %0" ::"n"(MODE >= 10 ? MODE - 10 : 0));  // pad: keep the next MFMA away from the issue port
                 if (MODE == 4) {  // same-wave interleave: 8 independent v_fma behind every MFMA
 #pragma unroll
                     for (int j = 0; j < 8; ++j) w[(i & 1) * 8 + j] = fmaf(w[(i & 1) * 8 + j], 1.0001f, 0.5f);
@@ -37,11 +38,12 @@ __global__ __launch_bounds__(512) void k(float* out, int n_mfma, int n_valu, int
         for (int i = 0; i < 8; ++i) s += acc[i][0];
         if (s == 12345.f) out[0] = s;
     } else {
+        if (prio == 2) __builtin_amdgcn_s_setprio(3);
         float v[16];
         for (int j = 0; j < 16; ++j) v[j] = threadIdx.x * 0.01f + j;
         f32x4 q = {0.f, 0.f, 0.f, 0.f};
         for (int it = 0; it < n_valu; ++it) {
-            if (MODE == 1) {
+            if (MODE == 1 || MODE >= 10) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -78,9 +80,14 @@ int main() {
     const int NM = 20000;  // 160k MFMAs x 32 cycles = 5.1M cycles ~ 2.1 ms
     printf("mfma alone: %.1f us\n", run<1>(out, NM, 0, 0));
     const int nv1 = 20000, nv2 = 20000, nv3 = 20000;
-    printf("fma   alone %.1f us | both %.1f us | both+prio %.1f us   (%d x 64 v_fma)\n", run<1>(out, 0, nv1, 0), run<1>(out, NM, nv1, 0), run<1>(out, NM, nv1, 1), nv1);
-    printf("exp   alone %.1f us | both %.1f us | both+prio %.1f us   (%d x 16 v_exp + 16 v_mul)\n", run<2>(out, 0, nv2, 0), run<2>(out, NM, nv2, 0), run<2>(out, NM, nv2, 1), nv2);
+    printf("fma   alone %.1f us | both %.1f us | both+prio(mfma) %.1f us | both+prio(valu) %.1f us  (%d x 64 v_fma)\n", run<1>(out, 0, nv1, 0), run<1>(out, NM, nv1, 0), run<1>(out, NM, nv1, 1), run<1>(out, NM, nv1, 2), nv1);
+    printf("exp   alone %.1f us | both %.1f us | both+prio(mfma) %.1f us | both+prio(valu) %.1f us  (%d x 16 v_exp + 16 v_mul)\n", run<2>(out, 0, nv2, 0), run<2>(out, NM, nv2, 0), run<2>(out, NM, nv2, 1), run<2>(out, NM, nv2, 2), nv2);
     printf("same-wave interleave (8 v_fma per MFMA, 64 per 8 MFMAs): %.1f us\n", run<4>(out, NM, 0, 0));
-    printf("ldsrd alone %.1f us | both %.1f us | both+prio %.1f us   (%d x 16 ds_read_b128)\n", run<3>(out, 0, nv3, 0), run<3>(out, NM, nv3, 0), run<3>(out, NM, nv3, 1), nv3);
+    printf("pad s_nop 0: mfma alone %.1f | both %.1f\n", run<10>(out, NM, 0, 0), run<10>(out, NM, nv1, 0));
+    printf("pad s_nop 1: mfma alone %.1f | both %.1f\n", run<11>(out, NM, 0, 0), run<11>(out, NM, nv1, 0));
+    printf("pad s_nop 3: mfma alone %.1f | both %.1f\n", run<13>(out, NM, 0, 0), run<13>(out, NM, nv1, 0));
+    printf("pad s_nop 5: mfma alone %.1f | both %.1f\n", run<15>(out, NM, 0, 0), run<15>(out, NM, nv1, 0));
+    printf("pad s_nop 7: mfma alone %.1f | both %.1f\n", run<17>(out, NM, 0, 0), run<17>(out, NM, nv1, 0));
+    printf("ldsrd alone %.1f us | both %.1f us | both+prio(mfma) %.1f us | both+prio(valu) %.1f us  (%d x 16 ds_read_b128)\n", run<3>(out, 0, nv3, 0), run<3>(out, NM, nv3, 0), run<3>(out, NM, nv3, 1), run<3>(out, NM, nv3, 2), nv3);
     return 0;
 }
