@@ -1,3 +1,4 @@
+// Build: hipcc -O3 --offload-arch=gfx950 -Wno-unused-value mfma_valu_overlap.hip -o mfma_valu_overlap ; run on an MI355X.
 // Micro-benchmark: do VALU instructions of one wave execute in the shadow of another wave's MFMAs on the same SIMD?
 // 512-thread workgroups, one per CU: waves 0-3 issue chains of independent v_mfma_f32_32x32x16_bf16, waves 4-7 issue
 // v_fma_f32 (mode 1), v_exp_f32 (mode 2) or ds_read_b128 (mode 3).  Prints time of each side alone and together.
