@@ -183,10 +183,12 @@ def main():
         # HBM bytes per launch of that kernel come from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file);
         # they cannot be collected from inside this process, so the committed profile of the same command is quoted
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_traffic_dominant_kernel.json")
+        tfile = os.path.join(ROOT, "profiles", "r01_ws_pmc_dominant_kernel.json")
         if args.dtype == "bf16" and B == 512 and os.path.exists(tfile):
             traffic = int(json.load(open(tfile))["hbm_bytes_per_launch"])
-        roof = {"bound": "mfma", "kernel": "conv_fused_kernel<T,3,PRO_GN_SILU,RES_NONE,32x32>",
+        kname = ("conv3_ws_kernel<RES_NONE,32x32> (GroupNorm+SiLU -> 3x3 conv -> bias/temb/residual/scale + GN statistics)"
+                 if args.dtype == "bf16" else "conv_fused_kernel<float,3,PRO_GN_SILU,RES_NONE,32x32>")
+        roof = {"bound": "mfma", "kernel": kname,
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2),
                 "avg_launch_gflop": round(fl.value / max(n.value, 1) / 1e9, 2),
