@@ -13,6 +13,7 @@ struct ConvArgs {
     int B;
     const float2* ab;   // [B][C1+C2] GroupNorm coefficients y = a*x+b, or nullptr
     const void* wpack;  // packed weights (compute dtype), see pack_conv_weights_kernel
+    const void* wpack_ws;  // the same weights in the layout of conv_ws.hip (bf16 3x3 convs it supports), or nullptr
     const float* bias;  // [Cout] or nullptr
     const float* temb;  // [B][temb_stride] per-image per-channel additive term (affine(emb)), or nullptr
     int temb_stride;
@@ -44,6 +45,8 @@ int conv_stat_slots(int W);
 bool conv_ws_supported(int dtype, int ks, int pro, int res, int outmode, const ConvArgs& a);
 bool conv_ws_enabled();
 int launch_conv_ws(int res, const ConvArgs& a, hipStream_t stream, bool prepare_only);
+bool conv_ws_shape_ok(int dtype, int cout, int cin, int res);
+int launch_pack_conv_weights_ws(const float* w_oihw, void* wpack_ws, int cout, int cin, hipStream_t stream);
 int launch_conv_ws_debug(const ConvArgs& a, int abl, hipStream_t stream);  // ablation builds of the 32x32 shape
 int launch_conv_debug(int dtype, const ConvArgs& a, hipStream_t stream);  // ablation build, honours a.dbg
 // set the dynamic-LDS attribute of every instantiation of this dtype (call once, outside stream capture)

@@ -56,6 +56,7 @@ struct Block {
         proj_w = -1, proj_b = -1, w = -1, b = -1;
     // packed weights (owned device memory, compute dtype)
     void *p_conv0 = nullptr, *p_conv1 = nullptr, *p_skip = nullptr, *p_qkv = nullptr, *p_proj = nullptr;
+    void *p_conv0_ws = nullptr, *p_conv1_ws = nullptr;  // conv_ws.hip layout, where that kernel applies
     float* qkv_bias = nullptr;  // [3C] permuted to q|k|v
     void* p_aux = nullptr;      // K_AUX_CONV: weights packed for the MFMA output head
     void* p_stem = nullptr;     // K_STEM: weights packed for the MFMA stem
@@ -423,7 +424,7 @@ int run_block(fg_edm* h, const Block& b, const Act& x1, int c1, const Act& x2, i
     ConvArgs a{};
     a.src1 = x1.p; a.src2 = c2 ? x2.p : nullptr; a.C1 = c1; a.C2 = c2;
     a.Hs = a.Ws = b.res_in; a.H = a.W = b.res_out; a.B = B;
-    a.ab = w.ab0; a.wpack = b.p_conv0; a.bias = h->P(b.conv0_b);
+    a.ab = w.ab0; a.wpack = b.p_conv0; a.wpack_ws = b.p_conv0_ws; a.bias = h->P(b.conv0_b);
     a.temb = temb + b.temb_off; a.temb_stride = h->temb_total;
     a.resid = nullptr; a.scale = 1.0f; a.out = w.h.p; a.Cout = b.cout; a.stats = w.h.st;
     if (b.down && !c2) {
@@ -450,7 +451,7 @@ int run_block(fg_edm* h, const Block& b, const Act& x1, int c1, const Act& x2, i
     Act& x_mid = b.attn ? w.xattn : out;
     ConvArgs d{};
     d.src1 = w.h.p; d.C1 = b.cout; d.Hs = d.Ws = d.H = d.W = b.res_out; d.B = B;
-    d.ab = w.ab1; d.wpack = b.p_conv1; d.bias = h->P(b.conv1_b);
+    d.ab = w.ab1; d.wpack = b.p_conv1; d.wpack_ws = b.p_conv1_ws; d.bias = h->P(b.conv1_b);
     d.resid = resid; d.scale = kSkipScale; d.out = x_mid.p; d.Cout = b.cout; d.stats = x_mid.st;
     HIP_TRY(conv_launch(h, 3, PRO_GN_SILU, RES_NONE, OUT_NHWC, d, s));
     x_mid.slots = slots;
@@ -616,6 +617,12 @@ int ensure_device_state(fg_edm* h) {
     for (Block* b : h->blocks) {
         if ((rc = dev_alloc(h, &b->p_conv0, conv_pack_elems(b->cout, b->cin, 3) * tsz))) return rc;
         if ((rc = dev_alloc(h, &b->p_conv1, conv_pack_elems(b->cout, b->cout, 3) * tsz))) return rc;
+        if (conv_ws_shape_ok(h->dtype, b->cout, b->cin, b->res_out) && !b->down &&
+            (rc = dev_alloc(h, &b->p_conv0_ws, conv_pack_elems(b->cout, b->cin, 3) * tsz)))
+            return rc;
+        if (conv_ws_shape_ok(h->dtype, b->cout, b->cout, b->res_out) &&
+            (rc = dev_alloc(h, &b->p_conv1_ws, conv_pack_elems(b->cout, b->cout, 3) * tsz)))
+            return rc;
         if (b->has_skip && (rc = dev_alloc(h, &b->p_skip, conv_pack_elems(b->cout, b->cin, 1) * tsz))) return rc;
         if (b->attn) {
             if ((rc = dev_alloc(h, &b->p_qkv, conv_pack_elems(3 * b->cout, b->cout, 1) * tsz))) return rc;
@@ -727,6 +734,8 @@ int fg_edm_pack_weights(fg_edm* h, void* stream) {
     for (Block* b : h->blocks) {
         HIP_TRY(launch_pack_conv_weights(h->dtype, h->P(b->conv0_w), b->p_conv0, b->cout, b->cin, 3, 0, s));
         HIP_TRY(launch_pack_conv_weights(h->dtype, h->P(b->conv1_w), b->p_conv1, b->cout, b->cout, 3, 0, s));
+        if (b->p_conv0_ws) HIP_TRY(launch_pack_conv_weights_ws(h->P(b->conv0_w), b->p_conv0_ws, b->cout, b->cin, s));
+        if (b->p_conv1_ws) HIP_TRY(launch_pack_conv_weights_ws(h->P(b->conv1_w), b->p_conv1_ws, b->cout, b->cout, s));
         if (b->has_skip) HIP_TRY(launch_pack_conv_weights(h->dtype, h->P(b->skip_w), b->p_skip, b->cout, b->cin, 1, 0, s));
         if (b->attn) {
             HIP_TRY(launch_pack_conv_weights(h->dtype, h->P(b->qkv_w), b->p_qkv, 3 * b->cout, b->cout, 1, 1, s));
@@ -938,7 +947,7 @@ int fg_debug_conv_bench(int dtype, int batch, int cin, int res, int ks, int with
     if (conv_prepare_all(dtype) != 0) return fail(FG_EHIP, "prepare failed");
     ConvArgs a{};
     a.src1 = x; a.C1 = cin; a.Hs = a.Ws = a.H = a.W = res; a.B = batch;
-    a.ab = ab; a.wpack = wp; a.bias = bias; a.resid = with_resid ? resid : nullptr; a.scale = 1.f; a.out = out; a.Cout = 256;
+    a.ab = ab; a.wpack = wp; a.wpack_ws = wp; a.bias = bias; a.resid = with_resid ? resid : nullptr; a.scale = 1.f; a.out = out; a.Cout = 256;
     a.dbg = dbg;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));

@@ -31,6 +31,27 @@ __global__ __launch_bounds__(512) void k(float* out, const u32x4* ops, int iters
     if (s == 12345.678f) out[0] = s;
 }
 
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+// same FLOPs with v_mfma_f32_16x16x32_bf16 (16 cycles each, 32 accumulator tiles of 16x16)
+__global__ __launch_bounds__(512) void k16(float* out, const u32x4* ops, int iters) {
+    bf16x8 a[8], b[8];
+    for (int i = 0; i < 8; ++i) {
+        a[i] = __builtin_bit_cast(bf16x8, ops[(i * 2 + 0) * 512 + threadIdx.x]);
+        b[i] = __builtin_bit_cast(bf16x8, ops[(i * 2 + 1) * 512 + threadIdx.x]);
+    }
+    f32x4 acc[32];
+    for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; it += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[(i + 16 * (u & 1))] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 7], b[(i + u) & 7], acc[(i + 16 * (u & 1))], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 32; ++i) s += acc[i][0] + acc[i][3];
+    if (s == 12345.678f) out[0] = s;
+}
+
 int main() {
     const int n = 16 * 512 * 4;
     uint32_t* h = (uint32_t*)malloc(n * 4);
@@ -70,6 +91,15 @@ int main() {
             const double flop = 256.0 * (threads / 64) * iters * 8.0 * 32 * 32 * 16 * 2;
             printf("%-46s %d waves/SIMD: %8.1f us  %7.1f TFLOP/s  (%.2f GHz-equivalent at 32 cyc/MFMA)\n", names[mode], threads / 256,
                    ms * 1e3, flop / (ms * 1e-3) / 1e12, (double)iters * 8 * 32 * (threads / 256) / (ms * 1e-3) / 1e9);
+            hipLaunchKernelGGL(k16, dim3(256), dim3(threads), 0, 0, out, d, iters);
+            hipEventRecord(e0);
+            for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k16, dim3(256), dim3(threads), 0, 0, out, d, iters);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+            ms /= 3;
+            const double flop16 = 256.0 * (threads / 64) * iters * 16.0 * 16 * 16 * 32 * 2;
+            printf("%-46s %d waves/SIMD: %8.1f us  %7.1f TFLOP/s  [16x16x32]\n", names[mode], threads / 256, ms * 1e3, flop16 / (ms * 1e-3) / 1e12);
         }
     }
     return 0;
