@@ -39,6 +39,10 @@ SIGNATURES = {
     "fg_edm_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "fg_edm_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                c_size_t, c_void_p]),
+    "fg_edm_num_feature_taps": (c_int, [c_void_p]),
+    "fg_edm_feature_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int), POINTER(c_int)]),
+    "fg_edm_forward_features": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p), c_int,
+                                        c_void_p, c_size_t, c_void_p]),
     "fg_sampler_run": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double), c_int, c_int, c_int, c_void_p, c_uint64,
                                c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "fg_edm_t_list": (c_int, [c_int, POINTER(c_double)]),

@@ -57,6 +57,7 @@ struct Block {
     // packed weights (owned device memory, compute dtype)
     void *p_conv0 = nullptr, *p_conv1 = nullptr, *p_skip = nullptr, *p_qkv = nullptr, *p_proj = nullptr;
     void *p_conv0_ws = nullptr, *p_conv1_ws = nullptr;  // conv_ws.hip layout, where that kernel applies
+    int tap = -1;  // index among the encoder's `block3` outputs (feature taps), or -1
     float* qkv_bias = nullptr;  // [3C] permuted to q|k|v
     void* p_aux = nullptr;      // K_AUX_CONV: weights packed for the MFMA output head
     void* p_stem = nullptr;     // K_STEM: weights packed for the MFMA stem
@@ -116,6 +117,7 @@ struct GraphKey {
 struct fg_edm {
     fg_edm_config cfg;
     int dtype = 0;
+    int num_taps = 0;  // encoder `block3` outputs available as feature taps
     int emb_ch = 0, noise_ch = 0, cond_ch = 0;  // cond_ch = noise_ch * (1 + r_timestep), EDM/network.py:376
     std::vector<Param> params;
     std::vector<Block> enc, dec;  // dec includes aux_norm / aux_conv entries
@@ -258,6 +260,8 @@ void build_layout(fg_edm* h) {
             cout = c.model_channels * c.channel_mult[level];
             h->enc.push_back(make_block("model.enc." + res_name(res) + "_block" + std::to_string(idx), cin, cout, res,
                                         false, false, is_attn_res(res), 0, false));
+            // feature taps: every encoder entry whose name contains "block3" (EDM/network.py:535), numbered in order
+            if (std::to_string(idx).rfind("3", 0) == 0) h->enc.back().tap = h->num_taps++;
             skips.push_back(cout);
         }
     }
@@ -488,8 +492,11 @@ int run_mapping(fg_edm* h, const float* labels, int B, Workspace& w, hipStream_t
 
 // EDMPrecond.forward (eval, fwd_pred_type = net_pred_type): EDM/network.py:881-974 + SongUNet.forward :489-574.
 // r (target time of r_timestep networks) is required iff cfg.r_timestep.
+// feats (nullable): one entry per resolution level, the NCHW fp32 destination of that level's `block3` encoder output
+// (SongUNet.forward feature taps, EDM/network.py:535-539) or nullptr; early: return after the encoder (:542-544).
 int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, const double* r, int r_stride,
-                const float* labels, float* out, int B, Workspace& w, hipStream_t s) {
+                const float* labels, float* out, int B, Workspace& w, hipStream_t s, float* const* feats = nullptr,
+                bool early = false) {
     const fg_edm_config& c = h->cfg;
     HIP_TRY(launch_precond_coef(t, t_stride, c.r_timestep ? r : nullptr, r_stride, c.sigma_data, c.sigma_shift, 1e-6,
                                 c.drop_precond, w.coef, B, s));
@@ -509,9 +516,12 @@ int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, cons
         } else {
             rc = run_block(h, b, *x, b.cin, none, 0, w.temb, w.skip[i], B, w, s);
             if (rc) return rc;
+            if (feats && b.tap >= 0 && feats[b.tap])
+                HIP_TRY(launch_act_to_nchw(h->dtype, w.skip[i].p, feats[b.tap], B, b.cout, b.res_out * b.res_out, s));
         }
         x = &w.skip[i];
     }
+    if (early) return FG_OK;
     // decoder (skip stack popped from the back; concat is virtual)
     int sp = (int)h->enc.size();
     Act* pong[2] = {&w.xa, &w.xb};
@@ -781,6 +791,37 @@ int fg_edm_forward(fg_edm* h, const float* x_t, const double* t, const double* r
     if (rc) return rc;
     if (emb_out) HIP_TRY(hipMemcpyAsync(emb_out, w.emb, sizeof(float) * (size_t)batch * h->emb_ch, hipMemcpyDeviceToDevice, s));
     return FG_OK;
+}
+
+int fg_edm_num_feature_taps(const fg_edm* h) { return h ? h->num_taps : 0; }
+
+int fg_edm_feature_info(const fg_edm* h, int index, const char** key, int* channels, int* resolution) {
+    if (!h) return fail(FG_EINVAL, "null handle");
+    for (const Block& b : h->enc)
+        if (b.tap == index && index >= 0) {
+            if (key) *key = b.key.c_str();
+            if (channels) *channels = b.cout;
+            if (resolution) *resolution = b.res_out;
+            return FG_OK;
+        }
+    return fail(FG_EINVAL, "feature index out of range");
+}
+
+int fg_edm_forward_features(fg_edm* h, const float* x_t, const double* t, const double* r, const float* class_labels,
+                            float* out, float* const* features, int batch, void* workspace, size_t workspace_bytes,
+                            void* stream) {
+    if (!h || !x_t || !t || !features) return fail(FG_EINVAL, "null argument");
+    if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
+    if (out == x_t) return fail(FG_EINVAL, "out must not alias x_t");
+    if (r && !h->cfg.r_timestep) return fail(FG_EINVAL, "r_noise_labels provided, but r_timestep is not set");
+    if (!r && h->cfg.r_timestep) return fail(FG_EINVAL, "this network was built with r_timestep: r is required");
+    for (const Block& b : h->enc)
+        if (b.tap >= 0 && features[b.tap] && ((b.cout % 32) || ((b.res_out * b.res_out) % 32)))
+            return fail(FG_EINVAL, "feature tap %d: channels and pixels must be multiples of 32", b.tap);
+    Workspace w;
+    int rc = setup_ws(h, batch, workspace, workspace_bytes, w);
+    if (rc) return rc;
+    return run_forward(h, x_t, t, 1, r, 1, class_labels, out, batch, w, (hipStream_t)stream, features, out == nullptr);
 }
 
 int fg_edm_t_list(int sample_steps, double* out_host) {

@@ -572,6 +572,24 @@ int launch_from_act(int dtype, const void* in, float* out, int64_t total, hipStr
         hipLaunchKernelGGL((convert_kernel<float, float>), dim3(ew_grid(total)), dim3(256), 0, s, (const float*)in, out, total);
     RET_LAST();
 }
+// feature tap: NHWC activation (compute dtype) -> NCHW fp32, 32 x 32 tiles through LDS (both sides coalesced)
+template <typename AT>
+__global__ __launch_bounds__(256) void nhwc_act_to_nchw_kernel(const AT* __restrict__ in, float* __restrict__ out, int C, int HW) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) tile[i][tx] = (float)in[((size_t)b * HW + p0 + i) * C + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) out[((size_t)b * C + c0 + i) * HW + p0 + tx] = tile[tx][i];
+}
+int launch_act_to_nchw(int dtype, const void* in, float* out, int B, int C, int HW, hipStream_t s) {
+    dim3 grid(HW / 32, C / 32, B);
+    if (dtype)
+        hipLaunchKernelGGL(nhwc_act_to_nchw_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)in, out, C, HW);
+    else
+        hipLaunchKernelGGL(nhwc_act_to_nchw_kernel<float>, grid, dim3(256), 0, s, (const float*)in, out, C, HW);
+    RET_LAST();
+}
 int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, hipStream_t s) {
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid((int64_t)B * C * HW)), dim3(256), 0, s, in, out, B, C, HW);
     RET_LAST();

@@ -16,8 +16,11 @@ Both network flavours of the reference's EDM CIFAR-10 configs are covered: the D
 (x0 prediction, EDM schedule, full preconditioning) and the MeanFlow student (configs/experiments/EDM/
 config_mf_cifar10.py: r_timestep=True, drop_precond='both', schedule_type='rf', net_pred_type='flow').
 
-Not provided on this path (raises, never falls back): training backward, feature taps, non-SongUNet model types,
-and any device but a HIP GPU.
+`feature_indices` / `return_features_early` (the encoder `block3` taps the DMD2 discriminator reads,
+EDM/network.py:525-544) are served by the same engine, forward only.
+
+Not provided on this path (raises, never falls back): training backward, non-SongUNet model types, and any device but a
+HIP GPU.
 """
 from __future__ import annotations
 
@@ -295,8 +298,6 @@ class EDMPrecond(FastGenNetwork):
             fwd_pred_type = self.net_pred_type
         else:
             assert fwd_pred_type in NET_PRED_TYPES, f"{fwd_pred_type} is not supported as fwd_pred_type"
-        if len(feature_indices) or return_features_early:
-            raise NotImplementedError("feature taps (feature_indices) belong to the training path; not implemented")
         if r is not None and not self.r_timestep:
             raise ValueError("r_noise_labels provided, but r_timestep is not set")
         if r is None and self.r_timestep:
@@ -329,15 +330,44 @@ class EDMPrecond(FastGenNetwork):
         labels = self._labels(condition, B, dev)
         dt, h = self._engine(dev)
         ws = self._workspace(dt, h, B, dev)
-        out = torch.empty_like(x32)
-        _lib.check(_lib.lib().fg_edm_forward(
-            h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
-            ctypes.c_void_p(r64.data_ptr() if r64 is not None else None),
-            ctypes.c_void_p(labels.data_ptr() if labels is not None else None), ctypes.c_void_p(out.data_ptr()), None,
-            B, ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream(dev)))
+        L = _lib.lib()
+        features: List[torch.Tensor] = []
+        if len(feature_indices):
+            # tap i = the i-th encoder block named *block3* (EDM/network.py:535-539); indices beyond the taps are ignored by
+            # the reference's loop and trip its length assert only when returning early (:543)
+            ntap = L.fg_edm_num_feature_taps(h)
+            ptrs = (ctypes.c_void_p * max(ntap, 1))()
+            ch, res = ctypes.c_int(), ctypes.c_int()
+            for i in range(ntap):
+                if i in feature_indices:
+                    _lib.check(L.fg_edm_feature_info(h, i, None, ctypes.byref(ch), ctypes.byref(res)))
+                    f = torch.empty(B, ch.value, res.value, res.value, dtype=torch.float32, device=dev)
+                    ptrs[i] = f.data_ptr()
+                    features.append(f)
+            if return_features_early:
+                assert len(features) == len(feature_indices), f"{len(features)} != {len(feature_indices)}"
+            out = None if return_features_early else torch.empty_like(x32)
+            _lib.check(L.fg_edm_forward_features(
+                h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
+                ctypes.c_void_p(r64.data_ptr() if r64 is not None else None),
+                ctypes.c_void_p(labels.data_ptr() if labels is not None else None),
+                ctypes.c_void_p(out.data_ptr() if out is not None else None), ptrs, B, ctypes.c_void_p(ws.data_ptr()),
+                ws.numel(), self._stream(dev)))
+            features = [f.to(x_t.dtype) for f in features]
+            if return_features_early:
+                return features
+        else:
+            out = torch.empty_like(x32)
+            _lib.check(L.fg_edm_forward(
+                h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
+                ctypes.c_void_p(r64.data_ptr() if r64 is not None else None),
+                ctypes.c_void_p(labels.data_ptr() if labels is not None else None), ctypes.c_void_p(out.data_ptr()), None,
+                B, ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream(dev)))
         out = out.to(x_t.dtype)
         out = self.noise_scheduler.convert_model_output(x_t, out, t64, src_pred_type=self.net_pred_type,
                                                         target_pred_type=fwd_pred_type)
+        if len(feature_indices):
+            out = [out, features]
         if return_logvar:
             return out, self._logvar(t64)
         return out

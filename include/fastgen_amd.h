@@ -107,6 +107,17 @@ size_t fg_edm_workspace_bytes(const fg_edm* h, int batch);
 int fg_edm_forward(fg_edm* h, const float* x_t, const double* t, const double* r, const float* class_labels, float* out,
                    float* emb_out, int batch, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same forward with the encoder feature taps of SongUNet.forward (EDM/network.py:525-544, 562-567): tap i is the i-th
+ * encoder block whose name contains "block3" (the last block of resolution level i for num_blocks = 4), the tensors the
+ * DMD2 discriminator reads (methods/distribution_matching/dmd2.py:142).  features: HOST array of
+ * fg_edm_num_feature_taps() device pointers, each NULL (not requested: the reference's feature_indices set) or an
+ * [B, channels, res, res] fp32 NCHW buffer.  out == NULL is return_features_early: the decoder is not run. */
+int fg_edm_num_feature_taps(const fg_edm* h);
+int fg_edm_feature_info(const fg_edm* h, int index, const char** key, int* channels, int* resolution);
+int fg_edm_forward_features(fg_edm* h, const float* x_t, const double* t, const double* r, const float* class_labels,
+                            float* out, float* const* features, int batch, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
 /* FastGenModel.generator_fn (methods/model.py:374-420) around one of the student sampling loops:
  *   x = noise * sigma(t_list[0]);
  *   FG_LOOP_X0 (model.py:315-372, x0-predicting network without r_timestep):

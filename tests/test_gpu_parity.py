@@ -408,3 +408,40 @@ def test_meanflow_batch16_against_oracle(mf_nets, mf_sd):
         got = MeanFlowModel.generator_fn(mf_nets[mode], noise.to(dev()), student_sample_steps=2,
                                          student_sample_type="ode")
         check(got, want_ode, mode, f"meanflow B=16 ode {mode}")
+
+
+# ---- encoder feature taps (the DMD2 discriminator's inputs, EDM/network.py:525-544) ------------------------------------
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_feature_taps(nets, sd, golden_dir, mode):
+    fx = load(golden_dir, "forward_full_b2.pt")
+    net = nets[mode]
+    x = (seeded((2, 3, 32, 32), 21) * fx["t"].reshape(2, 1, 1, 1).float())
+    xd, td, cd = x.to(dev()), fx["t"].to(dev()), fx["cond"].to(dev())
+    tr = {}
+    with torch.inference_mode():
+        want_out = R.edm_precond_forward(sd, R.CIFAR10, x, fx["t"], fx["cond"], trace=tr)
+        out, feats = net(xd, td, condition=cd, feature_indices={0, 1, 2})
+        early = net(xd, td, condition=cd, feature_indices={0, 1, 2}, return_features_early=True)
+        only1 = net(xd, td, condition=cd, feature_indices={1}, return_features_early=True)
+        (out_lv, feats_lv), logvar = net(xd, td, condition=cd, feature_indices={2}, return_logvar=True)
+        plain = net(xd, td, condition=cd)
+    keys = ["model.enc.32x32_block3", "model.enc.16x16_block3", "model.enc.8x8_block3"]
+    shapes = [(2, 256, 32, 32), (2, 256, 16, 16), (2, 256, 8, 8)]
+    assert [tuple(f.shape) for f in feats] == shapes and len(early) == 3
+    for i, k in enumerate(keys):
+        check(feats[i], tr[k], mode, f"feature {k} vs oracle")
+        # the strided samples recorded from the reference's own forward hooks
+        v = feats[i].float().cpu()
+        sample = v.reshape(-1)[:: max(1, v.numel() // 4096)][:4096]
+        check(sample, fx[f"blk/enc.{k.split('.')[-1]}/sample"], mode, f"feature {k} vs reference sample")
+        assert torch.equal(early[i], feats[i])
+    assert len(only1) == 1 and torch.equal(only1[0], feats[1])
+    assert len(feats_lv) == 1 and torch.equal(feats_lv[0], feats[2]) and logvar.shape == (2, 1)
+    assert torch.equal(out, plain) and torch.equal(out_lv, plain)
+    check(out, want_out, mode, "output next to the features")
+    with torch.inference_mode():
+        assert net(xd, td, condition=cd, return_features_early=True) == []
+        with pytest.raises(AssertionError):  # the reference's length assert (:543): tap 7 does not exist
+            net(xd, td, condition=cd, feature_indices={0, 7}, return_features_early=True)

@@ -129,8 +129,10 @@ def test_product_path_fails_loudly_without_gpu(net):
             FastGenModel.generator_fn(net, x, student_sample_steps=4)
         with pytest.raises(ValueError):
             net(x, t, r=t)
-        with pytest.raises(NotImplementedError):
+        with pytest.raises(RuntimeError, match="HIP GPU only"):
             net(x, t, feature_indices={0})
+        with pytest.raises(RuntimeError, match="HIP GPU only"):
+            net(x, t, feature_indices={0, 2}, return_features_early=True)
 
 
 def test_schedule_mirror_matches_golden(golden_dir):
