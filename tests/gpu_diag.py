@@ -1,4 +1,4 @@
-"""GPU diagnostic (not a test): prints per-op / per-block error of the HIP path against the oracle + golden fixtures
+"""GPU diagnostic (test infrastructure, not collected by pytest; run as `python tests/gpu_diag.py`): prints per-op / per-block error of the HIP path against the oracle + golden fixtures
 without asserting, so one run on the GPU box localises a wrong kernel."""
 import ctypes
 import os
