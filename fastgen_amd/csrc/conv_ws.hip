@@ -79,7 +79,11 @@ __global__ __launch_bounds__(WS_NTHR) void conv3_ws_kernel(const ConvArgs a, con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Cin = a.C1 + a.C2;
     const int nchunk = Cin / WS_KC;  // pipeline steps per tile (> WS_NQ and even, checked by the launcher)
-    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;  // >= 1: grid <= ntiles
+    // Workgroup b runs on XCD b % 8 (round-robin dispatch).  Give each XCD a contiguous run of tiles per sweep — whole images
+    // — so that the halo rows neighbouring tiles share, and an image's residual / statistics lines, meet in one L2.
+    const int G8 = (int)gridDim.x >> 3;
+    const int wg = ((gridDim.x & 7) == 0) ? ((int)blockIdx.x & 7) * G8 + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int my_tiles = (ntiles - wg + (int)gridDim.x - 1) / (int)gridDim.x;  // >= 1: grid <= ntiles
     const int S = my_tiles * nchunk;
     const int H = a.H;
 
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(WS_NTHR) void conv3_ws_kernel(const ConvArgs a, con
         }
     };
     Staged st;
-    int t_cur = blockIdx.x, c = 0;   // step s
+    int t_cur = wg, c = 0;   // step s
     int t1 = t_cur, c1 = 0;          // step s+1
     stage_load(st, t1, c1);
     stage_store(st, abuf0);
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(WS_NTHR) void conv3_ws_kernel(const ConvArgs a, con
         ws_barrier();
     }
     if (!(ABL & 2)) {
-        const int t_last = (int)blockIdx.x + (my_tiles - 1) * gstride;
+        const int t_last = wg + (my_tiles - 1) * gstride;
         for (int part = 0; part < WS_NQ; ++part) {
             if (part) retire_prefetch(t_last, part);
             retire_part(t_last, part);
