@@ -18,4 +18,4 @@ for C in "FETCH_SIZE" "WRITE_SIZE" \
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc$i -o pmc -- $CMD > $OUT/pmc$i.log 2>&1
   echo "pass $i done: $C"
 done
-python3 $ROOT/scripts/summarise_profiles.py $OUT $TAG
+echo "now run: python scripts/summarise_profiles.py gpurun_out/prof_$TAG $TAG   (in the repo; profiles/ does not travel back from the GPU box)"
