@@ -472,3 +472,24 @@ def generator_fn(sd, cfg, noise: Tensor, condition, student_sample_steps=4, t_li
         x = latents(noise, t_list[0])
         fn = meanflow_sample_loop if loop == "meanflow" else student_sample_loop
         return fn(sd, cfg, x, t_list, condition, sample_type, eps_list, trace).to(noise.dtype)
+
+
+def edm_sample(sd, cfg, noise: Tensor, condition=None, neg_condition=None, guidance_scale: Optional[float] = 5.0,
+               num_steps: int = 50) -> Tensor:
+    """EDMPrecond.sample — deterministic Euler sampler of the (teacher) network with optional classifier-free guidance,
+    EDM/network.py:976-1026.  As in the reference, `d = (x - x0) / t` divides by the float64 timestep, so x (and every
+    network evaluation after the first step) is float64 from the second step on."""
+    sigmas = edm_t_list(num_steps)
+    x = latents(noise, sigmas[0])
+    for sigma, sigma_next in zip(sigmas[:-1], sigmas[1:]):
+        t = sigma.expand(x.shape[0])
+        if guidance_scale is not None and guidance_scale > 1.0 and neg_condition is not None:
+            x0 = edm_precond_forward(sd, cfg, torch.cat([x, x], 0), torch.cat([t, t], 0),
+                                     torch.cat([neg_condition, condition], 0).to(x.dtype))
+            x0_uncond, x0_cond = x0.chunk(2)
+            x0 = x0_uncond + guidance_scale * (x0_cond - x0_uncond)
+        else:
+            x0 = edm_precond_forward(sd, cfg, x, t, None if condition is None else condition.to(x.dtype))
+        d = (x - x0) / t.reshape(-1, 1, 1, 1)
+        x = x + (sigma_next - sigma).to(x.dtype) * d
+    return x

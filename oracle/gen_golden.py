@@ -10,6 +10,7 @@ drift of the RNG stream is detected instead of silently comparing different prob
 
 Usage:  python oracle/gen_golden.py            (writes tests/golden/*.pt)
         python oracle/gen_golden.py meanflow   (only the MeanFlow / rectified-flow fixtures)
+        python oracle/gen_golden.py sample     (only the teacher Euler-sampler fixture)
 """
 import os
 import sys
@@ -120,10 +121,29 @@ def meanflow_fixtures(edm_net, ns):
                os.path.join(OUT, "meanflow_full_b2.pt"))
 
 
+def teacher_sample_fixture(edm_net):
+    """EDMPrecond.sample (Euler sampler with classifier-free guidance, EDM/network.py:976-1026), full width, B = 2."""
+    cfg = edm_ref.CIFAR10
+    sd = edm_ref.random_state_dict(cfg, seed=1234)
+    net = ref_net(edm_net, cfg, sd)
+    noise = seeded((2, 3, 32, 32), 50)
+    cond = torch.nn.functional.one_hot(torch.tensor([3, 7]), 10).float()
+    neg = torch.zeros(2, 10)
+    with torch.inference_mode():
+        out_cfg = net.sample(noise, condition=cond, neg_condition=neg, guidance_scale=2.0, num_steps=4)
+        out_plain = net.sample(noise, condition=cond, guidance_scale=None, num_steps=3)
+    torch.save({"sd_checksum": sd_checksum(sd), "noise_checksum": checksum(noise), "cond": cond,
+                "out_cfg": out_cfg.clone(), "out_plain": out_plain.clone()}, os.path.join(OUT, "teacher_sample_b2.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     edm_net, ns, model = _ref_import.import_reference()
     torch.manual_seed(0)
+    if sys.argv[1:] == ["sample"]:
+        teacher_sample_fixture(edm_net)
+        print("teacher sample fixture written to", OUT)
+        return
     if sys.argv[1:] == ["meanflow"]:
         meanflow_fixtures(edm_net, ns)
         print("MeanFlow fixtures written to", OUT)
@@ -250,6 +270,7 @@ def main():
                os.path.join(OUT, "forward_small.pt"))
 
     meanflow_fixtures(edm_net, ns)
+    teacher_sample_fixture(edm_net)
 
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):

@@ -445,3 +445,20 @@ def test_feature_taps(nets, sd, golden_dir, mode):
         assert net(xd, td, condition=cd, return_features_early=True) == []
         with pytest.raises(AssertionError):  # the reference's length assert (:543): tap 7 does not exist
             net(xd, td, condition=cd, feature_indices={0, 7}, return_features_early=True)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_teacher_euler_sampler(nets, golden_dir, mode):
+    """EDMPrecond.sample (EDM/network.py:976-1026): Euler steps with classifier-free guidance through the module's forward.
+    The reference evaluates the network in float64 from the second step on (x is promoted by the division by t); this engine
+    computes in fp32 / bf16, which is what the tolerance covers."""
+    fx = load(golden_dir, "teacher_sample_b2.pt")
+    net = nets[mode]
+    noise = seeded((2, 3, 32, 32), 50).to(dev())
+    cond = fx["cond"].to(dev())
+    with torch.inference_mode():
+        out = net.sample(noise, condition=cond, neg_condition=torch.zeros(2, 10, device=dev()), guidance_scale=2.0, num_steps=4)
+        assert out.dtype == torch.float64  # same promotion as the reference
+        check(out, fx["out_cfg"], mode, "Euler sampler with CFG")
+        out = net.sample(noise, condition=cond, guidance_scale=None, num_steps=3)
+        check(out, fx["out_plain"], mode, "Euler sampler without guidance")

@@ -192,3 +192,16 @@ def test_meanflow_sampler(golden_dir, mf_sd):
     assert torch.allclose(R.generator_fn(mf_sd, cfg, noise, None, 1, sample_type="ode", loop="meanflow"), fx["out_1step"], **kw)
     assert torch.allclose(R.generator_fn(mf_sd, cfg, noise, None, 2, t_list=[0.999, 0.5, 0.0], sample_type="ode",
                                          loop="meanflow"), fx["out_tlist"], **kw)
+
+
+def test_teacher_euler_sampler(golden_dir, full_sd):
+    """EDMPrecond.sample with and without classifier-free guidance (EDM/network.py:976-1026)."""
+    fx = _load(golden_dir, "teacher_sample_b2.pt")
+    noise = _seeded((2, 3, 32, 32), 50)
+    assert torch.allclose(_cs(noise), fx["noise_checksum"])
+    with torch.inference_mode():
+        got = R.edm_sample(full_sd, R.CIFAR10, noise, fx["cond"], torch.zeros(2, 10), 2.0, 4)
+        assert got.dtype == fx["out_cfg"].dtype == torch.float64
+        assert torch.allclose(got, fx["out_cfg"], rtol=1e-6, atol=1e-7)
+        got = R.edm_sample(full_sd, R.CIFAR10, noise, fx["cond"], None, None, 3)
+        assert torch.allclose(got, fx["out_plain"], rtol=1e-6, atol=1e-7)
