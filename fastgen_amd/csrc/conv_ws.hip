@@ -413,6 +413,9 @@ int launch_ws_one(const ConvArgs& a, hipStream_t stream, bool prepare_only) {
 // bf16 3x3 GroupNorm+SiLU convs with 256 output channels at 32x32 / 16x16 (RES_NONE or RES_UP)
 bool conv_ws_supported(int dtype, int ks, int pro, int res, int outmode, const ConvArgs& a) {
     const int cin = a.C1 + a.C2;
+    // the staged loads use 32-bit byte offsets into each source tensor
+    const size_t src_bytes = (size_t)a.B * a.Hs * a.Ws * (size_t)(a.C1 > a.C2 ? a.C1 : a.C2) * 2;
+    if (src_bytes >= (1ull << 32)) return false;
     return dtype == 1 && ks == 3 && pro == PRO_GN_SILU && (res == RES_NONE || res == RES_UP) && outmode == OUT_NHWC &&
            (a.W == 32 || a.W == 16) && a.H == a.W && a.Cout == 256 && (cin % 64) == 0 && cin / WS_KC > WS_NQ &&
            (a.C1 % WS_KC) == 0 && a.ab != nullptr && a.wpack_ws != nullptr;
