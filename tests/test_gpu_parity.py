@@ -462,3 +462,34 @@ def test_teacher_euler_sampler(nets, golden_dir, mode):
         check(out, fx["out_cfg"], mode, "Euler sampler with CFG")
         out = net.sample(noise, condition=cond, guidance_scale=None, num_steps=3)
         check(out, fx["out_plain"], mode, "Euler sampler without guidance")
+
+
+def test_meanflow_full_size_properties(mf_nets):
+    """MeanFlow sampler at batch 512: per-image independence (bit-exact vs. the same images in a batch of 16), determinism,
+    seed control, and agreement of 'ode' one-step with a hand-written x - t * u(x, t, 0)."""
+    net = mf_nets["bf16"]
+    B = 512
+    noise = seeded((B, 3, 32, 32), 13).to(dev())
+    eps = torch.stack([seeded((B, 3, 32, 32), s) for s in (14, 15, 16)]).to(dev())
+    gf = MeanFlowModel.generator_fn
+    big = gf(net, noise, student_sample_steps=4, student_sample_type="sde", eps=eps)
+    assert torch.isfinite(big).all()
+    assert torch.equal(big, gf(net, noise, student_sample_steps=4, student_sample_type="sde", eps=eps))
+    for lo in (0, 496):
+        sl = slice(lo, lo + 16)
+        small = gf(net, noise[sl].contiguous(), student_sample_steps=4, student_sample_type="sde", eps=eps[:, sl].contiguous())
+        assert torch.equal(big[sl], small), f"image result depends on its batch (rows {lo}..{lo + 15})"
+    a = gf(net, noise, student_sample_steps=4, student_sample_type="sde", seed=7)
+    b = gf(net, noise, student_sample_steps=4, student_sample_type="sde", seed=7)
+    c = gf(net, noise, student_sample_steps=4, student_sample_type="sde", seed=8)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    # one 'ode' step from t = 0.999 to 0 is x - 0.999 * u(x, 0.999, r = 0), x = 0.999 * noise
+    one = gf(net, noise, student_sample_steps=1, student_sample_type="ode")
+    with torch.inference_mode():
+        t = torch.full((B,), 0.999, dtype=torch.float64, device=dev())
+        x = net.noise_scheduler.latents(noise, t[0])
+        u = net(x, t, r=torch.zeros_like(t), fwd_pred_type="flow")
+        assert torch.equal(one, x - t[0].to(x.dtype) * u)
+        # scalar / broadcast forms of t and r are accepted like the reference's expand()
+        u1 = net(x[:4], torch.tensor(0.999, dtype=torch.float64, device=dev()), r=torch.tensor(0.0, device=dev()))
+        assert torch.equal(u1, u[:4])

@@ -277,3 +277,29 @@ def test_meanflow_generic_loop_matches_reference_semantics():
     assert torch.equal(out, x)
     with pytest.raises(NotImplementedError):
         MeanFlowModel.generator_fn(net, noise, student_sample_steps=2, student_sample_type="euler")
+
+
+def test_schedule_mirrors_equal_oracle_on_random_inputs():
+    """Property test: the host-side schedule mirrors and the oracle's schedule functions are the same maps (bit for bit) on
+    random tensors and timesteps, for both schedules."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=25, deadline=None)
+    @given(st.integers(0, 2**31 - 1), st.floats(0.002, 80.0), st.floats(0.0, 0.999))
+    def prop(seed, t_edm, t_rf):
+        g = torch.Generator().manual_seed(seed)
+        x, e = torch.randn(2, 3, 4, 4, generator=g), torch.randn(2, 3, 4, 4, generator=g)
+        for name, tv in (("edm", t_edm), ("rf", t_rf)):
+            s = get_noise_schedule(name)
+            t = torch.full((2,), tv, dtype=torch.float64)
+            assert torch.equal(s.forward_process(x, e, t), R.forward_process(x, e, t, name))
+            assert torch.equal(s.x0_to_eps(x, e, t), R.x0_to_eps(x, e, t, schedule=name))
+            if tv > 0:
+                assert torch.equal(s.latents(x, t[0]), R.latents(x, t[0]))
+            # conversions invert each other up to rounding
+            xt = s.forward_process(x, e, t)
+            if tv > 1e-3:
+                fl = s.convert_model_output(xt, x, t, "x0", "flow")
+                assert torch.allclose(s.convert_model_output(xt, fl, t, "flow", "x0"), x, atol=1e-4 * max(1.0, tv))
+
+    prop()
