@@ -92,13 +92,23 @@ __global__ __launch_bounds__(WS_NTHR) void conv3_ws_kernel(const ConvArgs a, con
         const int col = lane & 15, g = lane >> 4;
         // weights packed for the 16x16x32 B operand: [cout/16][step][tap][lane][8]  (pack_conv_weights_ws_kernel)
         const size_t wstride = (size_t)nchunk * 9 * 512;  // elements per 16-output-channel group
-        const T* wp = reinterpret_cast<const T*>(a.wpack_ws) + (size_t)(wave * 4) * wstride + lane * 8;
+        // Weight fragments come through a buffer resource over this wave's 64 output channels: wave-uniform byte offsets
+        // travel in SGPRs (soffset), the lane part is one constant VGPR, so a load costs no vector address arithmetic.
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<T*>(reinterpret_cast<const T*>(a.wpack_ws) + (size_t)(wave * 4) * wstride), 0, 0x7fffffff, 0x00020000);
+        const int wvoff = lane * 16;
+        const int wsb = (int)(wstride * 2);  // bytes between 16-channel groups
+        auto load_w = [&](int byte_off) -> Frag8<T> {
+            Frag8<T> f;
+            f.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, byte_off, 0));
+            return f;
+        };
 
         Frag8<T> bq[WS_RING][4];
 #pragma unroll
         for (int j = 0; j < WS_RING; ++j)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bq[j][nt] = load_frag(wp + nt * wstride + j * 512);
+            for (int nt = 0; nt < 4; ++nt) bq[j][nt] = load_w(nt * wsb + j * 1024);
 
         f32x4 acc[8][4];
 #pragma unroll
@@ -115,8 +125,8 @@ __global__ __launch_bounds__(WS_NTHR) void conv3_ws_kernel(const ConvArgs a, con
         for (int s = 0; s < S; ++s) {
             const char* abase = abuf0 + (s & 1) * G::ABUF + lane_off;
             const int cn = (c + 1 == nchunk) ? 0 : c + 1;
-            const T* wcur = wp + (size_t)c * (9 * 512);
-            const T* wnxt = (s + 1 < S) ? wp + (size_t)cn * (9 * 512) : wcur;  // the very last refills re-read this step (never used)
+            const int wcur = c * (9 * 1024);                          // byte offset of this step's taps
+            const int wnxt = (s + 1 < S) ? cn * (9 * 1024) : wcur;  // the very last refills re-read this step (never used)
 
             // half-tap j: tap j >> 1, pixel rows 4 (j & 1) .. +3
             auto read_a = [&](int j, Frag8<T> (&af)[4]) {
@@ -133,9 +143,9 @@ __global__ __launch_bounds__(WS_NTHR) void conv3_ws_kernel(const ConvArgs a, con
                     for (int nt = 0; nt < 4; ++nt)
                         if (!(ABL & 16)) mma32(acc[half * 4 + m][nt], af[m], bq[tap % WS_RING][nt]);
                 if ((ABL & 8) || !half) return;
-                const T* pn = (tap + WS_RING < 9) ? wcur + (tap + WS_RING) * 512 : wnxt + (tap + WS_RING - 9) * 512;
+                const int pn = (tap + WS_RING < 9) ? wcur + (tap + WS_RING) * 1024 : wnxt + (tap + WS_RING - 9) * 1024;
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) bq[tap % WS_RING][nt] = load_frag(pn + nt * wstride);
+                for (int nt = 0; nt < 4; ++nt) bq[tap % WS_RING][nt] = load_w(pn + nt * wsb);
             };
             Frag8<T> a0[4], a1[4];
             if (!(ABL & 16)) read_a(0, a0);
