@@ -55,6 +55,12 @@ __device__ __forceinline__ void mma16(f32x16& acc, const Frag8<float>& a, const 
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[3], b.hi[3], acc, 0, 0, 0);
 }
 
+// Fragment loads through a buffer resource: wave-uniform byte offset in an SGPR (soffset), lane part in one VGPR, so the
+// load needs no vector address arithmetic (weights streamed from L2 in the MFMA loops).
+typedef __attribute__((ext_vector_type(4))) unsigned fg_u32x4;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
 // 16-byte-aligned fragment loads (global or LDS; address space is inferred after inlining).
 __device__ __forceinline__ Frag8<__bf16> load_frag(const __bf16* p) {
     Frag8<__bf16> f;
@@ -66,6 +72,14 @@ __device__ __forceinline__ Frag8<float> load_frag(const float* p) {
     f.lo = *reinterpret_cast<const f32x4*>(p);
     f.hi = *reinterpret_cast<const f32x4*>(p + 4);
     return f;
+}
+// lane_elems = lane * 8 (element offset of this lane inside a 512-element fragment)
+__device__ __forceinline__ void load_frag_rsrc(Frag8<__bf16>& f, __amdgpu_buffer_rsrc_t r, int lane_elems, int elem_off) {
+    f.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, lane_elems * 2, elem_off * 2, 0));
+}
+__device__ __forceinline__ void load_frag_rsrc(Frag8<float>& f, __amdgpu_buffer_rsrc_t r, int lane_elems, int elem_off) {
+    f.lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_elems * 4, elem_off * 4, 0));
+    f.hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_elems * 4 + 16, elem_off * 4, 0));
 }
 __device__ __forceinline__ void store_frag(__bf16* p, const float (&x)[8]) {
     bf16x8 v;

@@ -124,7 +124,10 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
 
     // this wave's packed weights: [cout/32][step][kk][lane][8], two consecutive 32-channel groups
     const size_t wstride = (size_t)nsteps * (KK * 512);
-    const T* wp = reinterpret_cast<const T*>(a.wpack) + (size_t)(nblk * (4 * NT) + wave * NT) * wstride + lane * 8;
+    // weights through a buffer resource: SGPR offsets, no vector address arithmetic (common.h load_frag_rsrc)
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const T*>(a.wpack) + (size_t)(nblk * (4 * NT) + wave * NT) * wstride);
+    const int wlane = lane * 8;
+    const int wst = (int)wstride;
 
     const ST* src1 = reinterpret_cast<const ST*>(a.src1);
     const ST* src2 = reinterpret_cast<const ST*>(a.src2);
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) bfr[nt][kk] = load_frag(wp + nt * wstride + kk * 512);
+        for (int kk = 0; kk < KK; ++kk) load_frag_rsrc(bfr[nt][kk], wrs, wlane, nt * wst + kk * 512);
 
     f32x16 acc[4][NT];
 #pragma unroll
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         for (int tap = 0; tap < G::TAPS; ++tap, ++step) {
             // (1) weights: each fragment is refilled in place for the NEXT step right after its last use below
             //     (clamped: the last step re-reads itself), so B needs 2*KK fragments with one step of prefetch distance
-            const T* pnext = wp + (size_t)((step + 1 < nsteps) ? step + 1 : step) * (KK * 512);
+            const int pnext = ((step + 1 < nsteps) ? step + 1 : step) * (KK * 512);
             // (2) issue this step's share of the next chunk's activation loads
             Frag8<ST> raw[IPS][ND];
             bool valid[IPS];
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
                     for (int nt = 0; nt < NT; ++nt) mma16(acc[mt][nt], af[mt], bfr[nt][kk]);
                 if (!(dbg & 2)) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bfr[nt][kk] = load_frag(pnext + nt * wstride + kk * 512);
+                    for (int nt = 0; nt < NT; ++nt) load_frag_rsrc(bfr[nt][kk], wrs, wlane, pnext + nt * wst + kk * 512);
                 }
             };
             if (dbg & 8) {
