@@ -188,6 +188,14 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         if (hq >= G::HALO_PIX) return;
         int n, y, x, lo;
         const bool ok = decode(hq, n, y, x, lo);
+        if (DEFER && PRO == PRO_NONE && ND == 1) {
+            // nothing to transform: park the loaded fragment as it is (zeros outside the image) — no widening, no
+            // re-rounding, no vector arithmetic beyond the select
+            Frag8<T> z = rawp[0];
+            if (!valid) z = Frag8<T>{};
+            *reinterpret_cast<Frag8<T>*>(abuf + lo) = z;
+            return;
+        }
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = 0.f;
