@@ -493,3 +493,18 @@ def test_meanflow_full_size_properties(mf_nets):
         # scalar / broadcast forms of t and r are accepted like the reference's expand()
         u1 = net(x[:4], torch.tensor(0.999, dtype=torch.float64, device=dev()), r=torch.tensor(0.0, device=dev()))
         assert torch.equal(u1, u[:4])
+
+
+def test_generic_conv_kernel_path():
+    """FASTGEN_AMD_CONV_WS=0 routes every conv through conv_fused_kernel (the kernel that serves fp32 mode and the shapes the
+    wave-specialised kernel does not take).  The switch is read once per process, so the bf16 block / forward parity tests run
+    again in a child process with it set."""
+    import subprocess
+    import sys
+
+    if os.environ.get("FASTGEN_AMD_CONV_WS") == "0":
+        pytest.skip("already running with the generic kernel")
+    env = dict(os.environ, FASTGEN_AMD_CONV_WS="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "(blocks_against or forward_against) and bf16"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
