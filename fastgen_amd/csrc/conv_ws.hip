@@ -290,6 +290,7 @@ __global__ __launch_bounds__(WS_NTHR) void conv3_ws_kernel(const ConvArgs a, con
         const size_t tb = tile_base(t, part, n, slot);
         radd = bias4;
         if (a.temb) radd += *reinterpret_cast<const f32x4*>(a.temb + (size_t)n * a.temb_stride + co);
+        radd *= a.scale;  // (acc + add + resid) * scale evaluated as fma(acc, scale, add * scale) [+ fma(resid, scale, .)]
         if (has_resid) {
             const T* rb = resid + tb;
 #pragma unroll
@@ -309,9 +310,14 @@ __global__ __launch_bounds__(WS_NTHR) void conv3_ws_kernel(const ConvArgs a, con
         }
 #pragma unroll
         for (int j = 0; j < WS_QJ; ++j) {
-            f32x4 v = dv[j] + radd;
-            if (has_resid) v += widen4(rr[j]);
-            v *= a.scale;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(dv[j][e], a.scale, radd[e]);
+            if (has_resid) {
+                const f32x4 rw = widen4(rr[j]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(rw[e], a.scale, v[e]);
+            }
             if (!(ABL & 32)) store4(ob + (loff + (unsigned)(((j >> 2) * G::W + (j & 3) * 4) * 256)), v);
             // GroupNorm partial sums from the fp32 values: the bf16 rounding of the stored tensor is zero-mean noise of 2^-9
             // relative size per element, far below the statistics' own resolution over >= 8192 elements per group
