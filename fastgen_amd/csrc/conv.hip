@@ -101,7 +101,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
     constexpr int IPS = (NITEMS + G::TAPS - 1) / G::TAPS;             // items staged per (chunk, tap) step
     constexpr int ND = (RES == RES_DOWN) ? 4 : 1;                     // source pixels per staged pixel (2x2 mean when down-sampling)
     // split load / transform+write around the MFMAs; with down-sampling an item holds 4 raw fragments: bf16 3x3 only
-    constexpr bool DEFER = (OUTMODE != OUT_QKV) && (RES != RES_DOWN || (KS == 3 && sizeof(T) == 2));
+    constexpr bool DEFER = (RES != RES_DOWN || (KS == 3 && sizeof(T) == 2));
     constexpr bool AB_REGS = (PRO != PRO_NONE) && (G::IMGS == 1);     // per-chunk GN coefficients live in registers
     constexpr bool PIPE_A = (sizeof(T) == 2);                         // two A-fragment register sets (bf16 only)
     constexpr int NT = conv_nt(KS, LOGW, OUTMODE);                    // 32-channel tiles per wave: 2, or 1 (N split over 2 workgroups)
