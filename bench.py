@@ -116,6 +116,19 @@ def cpu_baseline(budget_s: float = 20.0):
             "sample": f"{n} batches of 16 images, 4-step sde, fp32 torch-CPU oracle ({dt:.1f} s)"}
 
 
+def result_line(value, world, steps, warmup, dt, dtype, batch, sample_steps, graph, roofline, cpu):
+    """The ONE JSON line of the driver contract (fields and meanings: the task brief, 'Measurement')."""
+    return {
+        "metric": "images/sec at 4-step distilled (DMD2) sampling", "value": round(value, 2), "unit": "img/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": f"EDM CIFAR-10 32x32 SongUNet (55.7M params) DMD2 {sample_steps}-step 'sde' sampling, "
+                               f"batch={batch} per GPU", "global_batch": batch * world, "sample_steps": sample_steps,
+                   "parallelism": f"replicas x{world} (no data-path collective)", "graph": graph},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,15 +215,7 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
-        line = {
-            "metric": "images/sec at 4-step distilled (DMD2) sampling", "value": round(value, 2), "unit": "img/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"EDM CIFAR-10 32x32 SongUNet (55.7M params) DMD2 {args.sample_steps}-step 'sde' sampling, "
-                                   f"batch={B} per GPU", "global_batch": B * world, "sample_steps": args.sample_steps,
-                       "parallelism": f"replicas x{world} (no data-path collective)", "graph": not args.no_graph},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
+        line = result_line(value, world, args.steps, args.warmup, dt, args.dtype, B, args.sample_steps, not args.no_graph, roof, cpu)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -62,3 +62,23 @@ def test_single_rank_needs_no_process_group():
     n = [0]
     dt = bench.timed_region(lambda: n.__setitem__(0, n[0] + 1), steps=3, warmup=1, world=1, sync_fn=lambda: None)
     assert n[0] == 4 and dt >= 0
+
+
+def test_bench_line_contract():
+    """The JSON line bench.py prints carries every field the driver reads, with the agreed types."""
+    import json
+
+    import bench
+
+    roof = {"bound": "mfma", "kernel": "k", "achieved": 1.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.0004, "traffic": None}
+    cpu = {"value": 10.0, "unit": "img/s", "cores": 16, "kind": "port", "sample": "s"}
+    line = json.loads(json.dumps(bench.result_line(6000.0, 2, 10, 3, 1.7, "bf16", 512, 4, True, roof, cpu)))
+    for k, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                   ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                   ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(line[k], typ), k
+    assert line["vs_baseline"] is None and line["scaling"] == "weak" and line["higher_is_better"] is True
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 1024 and "workload" in line["config"]
+    assert "model" not in line["config"]
+    assert set(roof) <= set(line["roofline"]) and {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+    assert abs(line["ms_per_step"] - 170.0) < 1e-9
