@@ -22,23 +22,18 @@ class MeanFlowModel(FastGenModel):
     @classmethod
     def _student_sample_loop(cls, net, x: torch.Tensor, t_list: torch.Tensor, condition: Any = None,
                              student_sample_type: str = "sde", **kwargs) -> torch.Tensor:
-        """x <- x - dt * u(x, t, r): 'sde' jumps to r = 0 with dt = t_cur and re-noises to t_next, 'ode' integrates the
-        average velocity over [t_next, t_cur] (mean_flow.py:336-381)."""
-        batch_size = x.shape[0]
-        for t_cur, t_next in zip(t_list[:-1], t_list[1:]):
-            t_cur_batch = t_cur.expand(batch_size)
-            t_next_batch = t_next.expand(batch_size)
-            if student_sample_type == "sde":
-                delta_t = expand_like(t_cur, x).to(x.dtype)
-                x = x - delta_t * net(x, t=t_cur_batch, condition=condition, r=torch.zeros_like(t_next_batch),
-                                      fwd_pred_type="flow")
-                if t_next > 0:
-                    eps_infer = torch.randn_like(x)
-                    x = net.noise_scheduler.forward_process(x, eps_infer, t_next_batch)
-            elif student_sample_type == "ode":
-                delta_t = expand_like(t_cur - t_next, x).to(x.dtype)
-                x = x - delta_t * net(x, t=t_cur_batch, condition=condition, r=t_next_batch, fwd_pred_type="flow")
-            else:
-                raise NotImplementedError(
-                    f"student_sample_type must be one of 'sde', 'ode' but got {student_sample_type}")
+        """x <- x - dt * u(x, t, r) per interval of t_list (mean_flow.py:336-381).
+        'sde': r = 0, dt = t (a jump to the data end), then re-noise to the next timestep unless it is 0;
+        'ode': r = next timestep, dt = t - r (the average velocity integrates the interval exactly)."""
+        if student_sample_type not in ("sde", "ode"):
+            raise NotImplementedError(f"student_sample_type must be one of 'sde', 'ode' but got {student_sample_type}")
+        n = x.shape[0]
+        jump = student_sample_type == "sde"
+        for i in range(len(t_list) - 1):
+            t, t_to = t_list[i], t_list[i + 1]
+            r = torch.zeros_like(t_to) if jump else t_to
+            dt = expand_like(t if jump else t - t_to, x).to(x.dtype)
+            x = x - dt * net(x, t=t.expand(n), condition=condition, r=r.expand(n), fwd_pred_type="flow")
+            if jump and t_to > 0:
+                x = net.noise_scheduler.forward_process(x, torch.randn_like(x), t_to.expand(n))
         return x

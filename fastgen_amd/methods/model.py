@@ -41,27 +41,27 @@ class FastGenModel:
     @classmethod
     def _student_sample_loop(cls, net, x: torch.Tensor, t_list: torch.Tensor, condition: Any = None,
                              student_sample_type: str = "sde", **kwargs) -> torch.Tensor:
-        """Generic per-step loop (methods/model.py:315-372) for networks without a fused sampler."""
-        batch_size = x.shape[0]
-        has_hook = hasattr(net, "preserve_conditioning")
-        x_pred = x
-        for t_cur, t_next in zip(t_list[:-1], t_list[1:]):
-            t_batch = t_cur.expand(batch_size)
-            x_pred = net(x, t_batch, condition=condition, fwd_pred_type="x0")
-            if has_hook:
-                x_pred = net.preserve_conditioning(x_pred, condition)
-            if t_next > 0:
-                if student_sample_type == "sde":
-                    eps = torch.randn_like(x_pred)
-                elif student_sample_type == "ode":
-                    eps = net.noise_scheduler.x0_to_eps(xt=x, x0=x_pred, t=t_batch)
-                else:
+        """Generic per-step loop (methods/model.py:315-372) for networks without a fused sampler: predict x0 at t_i, and unless
+        t_{i+1} is 0 re-noise it to t_{i+1} — with fresh noise ('sde') or with the noise implied by (x, x0) ('ode').  Networks
+        with a `preserve_conditioning` hook get it applied to every prediction and every re-noised state."""
+        n = x.shape[0]
+        keep = getattr(net, "preserve_conditioning", None)
+        sched = net.noise_scheduler
+        x0 = x
+        for i in range(len(t_list) - 1):
+            t = t_list[i].expand(n)
+            x0 = net(x, t, condition=condition, fwd_pred_type="x0")
+            if keep is not None:
+                x0 = keep(x0, condition)
+            if t_list[i + 1] > 0:
+                if student_sample_type not in ("sde", "ode"):  # as in the reference, only a re-noising step can object
                     raise NotImplementedError(
                         f"student_sample_type must be one of 'sde', 'ode' but got {student_sample_type}")
-                x = net.noise_scheduler.forward_process(x_pred, eps, t_next.expand(batch_size))
-                if has_hook:
-                    x = net.preserve_conditioning(x, condition)
-        return x_pred
+                eps = torch.randn_like(x0) if student_sample_type == "sde" else sched.x0_to_eps(xt=x, x0=x0, t=t)
+                x = sched.forward_process(x0, eps, t_list[i + 1].expand(n))
+                if keep is not None:
+                    x = keep(x, condition)
+        return x0
 
     @classmethod
     def generator_fn(cls, net, noise: torch.Tensor, student_sample_steps: int = 1, t_list: Optional[List[float]] = None,
