@@ -630,6 +630,11 @@ int conv_prepare_all(int dtype) {
         for (int res : {RES_NONE, RES_UP}) {
             w.W = w.H = 32;
             if (!rc) rc = launch_conv_ws(res, w, nullptr, true);
+            if (res == RES_NONE) {  // the 128-input-channel instantiation
+                w.C1 = -128;
+                if (!rc) rc = launch_conv_ws(res, w, nullptr, true);
+                w.C1 = 0;
+            }
             w.W = w.H = 16;
             if (!rc) rc = launch_conv_ws(res, w, nullptr, true);
         }

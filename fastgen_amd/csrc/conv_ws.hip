@@ -36,8 +36,8 @@ constexpr int WS_PA = 16;               // LDS bytes per halo pixel inside one c
 constexpr int WS_DBYTES = 128 * 1024;   // hand-off tile
 constexpr int WS_RING = 3;              // weight ring depth in taps (4 fragments of 16 output channels each)
 constexpr int WS_HSTEPS = 18;           // half-taps per step: (tap, pixel rows 0-3 | 4-7), 16 MFMAs each
-constexpr int WS_NQ = 4;                // a finished tile is retired in WS_NQ parts, one per step of the next tile
-constexpr int WS_QJ = 32 / WS_NQ;       // quads per lane and part
+// A finished tile is retired in NQ parts, one per step of the next tile (template parameter): 4 normally, 2 for a 128-channel
+// input whose tiles have only 4 steps (the parts have to be done before the tile's own accumulators arrive).
 
 template <int LOGW>
 struct WsGeom {
@@ -66,8 +66,9 @@ __device__ __forceinline__ void mma32(f32x4& acc, const Frag8<__bf16>& a, const 
 
 // ABL: compile-time ablation mask for scripts/conv_ablate.py (0 in production): 1 no staging, 2 no retire (drain),
 // 4 no accumulator hand-off, 8 no weight refill, 16 no MFMA / A reads
-template <int RES, int LOGW, int ABL = 0>
+template <int RES, int LOGW, int ABL = 0, int WS_NQ = 4>
 __global__ __launch_bounds__(WS_NTHR) void conv3_ws_kernel(const ConvArgs a, const int ntiles) {
+    constexpr int WS_QJ = 32 / WS_NQ;  // quads per lane and part
     typedef __bf16 T;
     using G = WsGeom<LOGW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -400,10 +401,10 @@ __global__ void pack_conv_weights_ws_kernel(const float* __restrict__ w, __bf16*
 
 int g_ws_cus = 0;
 
-template <int RES, int LOGW, int ABL = 0>
+template <int RES, int LOGW, int ABL = 0, int NQ = 4>
 int launch_ws_one(const ConvArgs& a, hipStream_t stream, bool prepare_only) {
     using G = WsGeom<LOGW>;
-    auto kern = conv3_ws_kernel<RES, LOGW, ABL>;
+    auto kern = conv3_ws_kernel<RES, LOGW, ABL, NQ>;
     const size_t lds = ws_lds_bytes();
     static bool attr_done = false;
     if (!attr_done) {
@@ -433,11 +434,16 @@ bool conv_ws_supported(int dtype, int ks, int pro, int res, int outmode, const C
     const size_t src_bytes = (size_t)a.B * a.Hs * a.Ws * (size_t)(a.C1 > a.C2 ? a.C1 : a.C2) * 2;
     if (src_bytes >= (1ull << 32)) return false;
     return dtype == 1 && ks == 3 && pro == PRO_GN_SILU && (res == RES_NONE || res == RES_UP) && outmode == OUT_NHWC &&
-           (a.W == 32 || a.W == 16) && a.H == a.W && a.Cout == 256 && (cin % 64) == 0 && cin / WS_KC > WS_NQ &&
+           (a.W == 32 || a.W == 16) && a.H == a.W && a.Cout == 256 && (cin % 64) == 0 && cin / WS_KC >= 4 &&
            (a.C1 % WS_KC) == 0 && a.ab != nullptr && a.wpack_ws != nullptr;
 }
 
 int launch_conv_ws(int res, const ConvArgs& a, hipStream_t stream, bool prepare_only) {
+    if ((a.C1 + a.C2) / WS_KC == 4 || (prepare_only && a.C1 == -128)) {
+        // 128 input channels: four steps per tile, retire in two parts (the U-Net's first block, 32x32, no resampling)
+        if (res != RES_NONE || a.W != 32) return (int)hipErrorInvalidValue;
+        return launch_ws_one<RES_NONE, 5, 0, 2>(a, stream, prepare_only);
+    }
     if (a.W == 32) return res == RES_UP ? launch_ws_one<RES_UP, 5>(a, stream, prepare_only) : launch_ws_one<RES_NONE, 5>(a, stream, prepare_only);
     return res == RES_UP ? launch_ws_one<RES_UP, 4>(a, stream, prepare_only) : launch_ws_one<RES_NONE, 4>(a, stream, prepare_only);
 }
@@ -464,7 +470,7 @@ int launch_conv_ws_debug(const ConvArgs& a, int abl, hipStream_t stream) {
 
 // whether a 3x3 conv with these dimensions can take the wave-specialised kernel (decides if its weights are also packed for it)
 bool conv_ws_shape_ok(int dtype, int cout, int cin, int res) {
-    return dtype == 1 && cout == 256 && (res == 32 || res == 16) && (cin % 64) == 0 && cin / WS_KC > WS_NQ;
+    return dtype == 1 && cout == 256 && (res == 32 || res == 16) && (cin % 64) == 0 && cin / WS_KC >= 4;
 }
 
 int launch_pack_conv_weights_ws(const float* w_oihw, void* wpack_ws, int cout, int cin, hipStream_t stream) {
