@@ -3,7 +3,10 @@
 Mirrors the surface of the reference's `BaseNoiseSchedule` / `EDMNoiseSchedule` / `RFNoiseSchedule`
 (fastgen/networks/noise_schedule.py:23-726, 729-1035, 1306-1486) that the sampling callers read
 (methods/model.py:361-413, methods/consistency_model/mean_flow.py:336-381): get_t_list, latents, forward_process,
-x0_to_eps, convert_model_output, max_t, max_sigma, t_precision, sigmas, is_t_valid, sample_t.  These are tiny tensor
+x0_to_eps, convert_model_output, max_t, max_sigma, t_precision, sigmas, is_t_valid, sample_t — and the ones the training
+callers read (methods/distribution_matching/dmd2.py:100-120, consistency_model/*.py): sample_from_t_list,
+next_in_t_list, rescale_t, alpha_prime / sigma_prime, cond_velocity, sqrt_snr(_to_t), closest_sigma_idx,
+sigma_idx_to_t, safe_clamp.  These are tiny tensor
 expressions evaluated with torch on whatever device the inputs live on; inside the fused sampler (fg_sampler_run)
 the same formulas run as HIP kernels (csrc/misc.hip) and these classes only supply the timestep list.
 """
@@ -57,6 +60,18 @@ class BaseNoiseSchedule(torch.nn.Module):
     def sigma(self, t):
         return t
 
+    def alpha_prime(self, t):
+        raise NotImplementedError
+
+    def sigma_prime(self, t):
+        """d sigma / dt = 1 for both schedules (noise_schedule.py:782-783, 1346-1347)."""
+        return torch.ones_like(t)
+
+    def rescale_t(self, t: torch.Tensor) -> torch.Tensor:
+        """The timestep as the network consumes it (noise_schedule.py:140-148)."""
+        assert self.is_t_valid(t), f"t must be in range [{self.min_t}, {self.max_t}], but got {t}"
+        return self._rescale(t)
+
     # -- helpers ---------------------------------------------------------------------------------------
     def is_t_valid(self, t: torch.Tensor) -> torch.Tensor:
         """min_t <= t <= max_t up to one ulp of t's dtype (noise_schedule.py:409-423)."""
@@ -68,11 +83,81 @@ class BaseNoiseSchedule(torch.nn.Module):
     def non_zero_clamp(self, x: torch.Tensor) -> torch.Tensor:
         return torch.where(x >= 0, x.clamp(min=self.clamp_min), x.clamp(max=-self.clamp_min))
 
+    @staticmethod
+    def safe_clamp(t: torch.Tensor, min: Optional[float] = None, max: Optional[float] = None) -> torch.Tensor:
+        """clamp whose bounds are first moved inwards to values representable in t's dtype, so that
+        min <= result <= max holds exactly (noise_schedule.py:90-121)."""
+        def inward(bound, towards):
+            b = torch.as_tensor(bound, dtype=t.dtype, device=t.device)
+            crossed = b.item() < bound if towards > 0 else b.item() > bound
+            if crossed:
+                b = torch.nextafter(b, torch.tensor(towards * float("inf"), dtype=t.dtype, device=t.device))
+            return b.item()
+
+        lo = inward(min, +1) if min is not None else None
+        hi = inward(max, -1) if max is not None else None
+        return torch.clamp(t, min=lo, max=hi)
+
     # -- what the samplers call ------------------------------------------------------------------------------
     def get_t_list(self, sample_steps: int, device: Optional[torch.device] = None) -> torch.Tensor:
         """linspace(max_t, 0, sample_steps+1) (noise_schedule.py:259-272)."""
         t = torch.linspace(self.max_t, 0, sample_steps + 1, device=device or self._sigmas.device, dtype=self.t_precision)
         return t.clamp(max=self.max_t)
+
+    def _resolve_t_list(self, sample_steps: int, t_list, device) -> torch.Tensor:
+        if t_list is None:
+            return self.get_t_list(sample_steps=sample_steps, device=device or self._sigmas.device)
+        return torch.as_tensor(t_list, device=device, dtype=self.t_precision)
+
+    def sample_from_t_list(self, n: int, sample_steps: int, t_list=None, return_ids: Optional[bool] = False,
+                           device: Optional[torch.device] = None):
+        """n uniform draws from t_list[:-1] — the final (clean, t = 0) entry is never trained on
+        (noise_schedule.py:274-304).  The index draw uses the CPU generator, like the reference's."""
+        tl = self._resolve_t_list(sample_steps, t_list, device)
+        ids = torch.randint(0, len(tl) - 1, (n,)).to(device=device)
+        return (tl[ids], ids) if return_ids else tl[ids]
+
+    def next_in_t_list(self, ids: torch.Tensor, sample_steps: int, t_list, device: Optional[torch.device] = None,
+                       stride: int = 1) -> torch.Tensor:
+        """t_list[ids + stride]; running past the end is an error, not a clamp (noise_schedule.py:306-340)."""
+        tl = self._resolve_t_list(sample_steps, t_list, device)
+        if t_list is not None:
+            assert tl.shape == (sample_steps + 1,), f"t_list must be of shape (sample_steps + 1,), but got {tl.shape}"
+        nxt = ids + stride
+        if nxt.max() > sample_steps:
+            raise ValueError(f"Clamping next ids to sample steps. ids: {ids}, next_ids: {nxt}, sample_steps: {sample_steps}")
+        return tl[nxt]
+
+    def cond_velocity(self, x: torch.Tensor, eps: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        """dx_t/dt = alpha'(t) x_0 + sigma'(t) eps in fp64, cast back (noise_schedule.py:451-476)."""
+        assert self.is_t_valid(t), f"t must be in [{self.min_t}, {self.max_t}], but got {t}"
+        t64 = t.to(torch.float64)
+        out = x.to(torch.float64) * expand_like(self.alpha_prime(t64), x) + eps.to(torch.float64) * expand_like(
+            self.sigma_prime(t64), eps)
+        return out.to(x.dtype)
+
+    def closest_sigma_idx(self, sigma_t: torch.Tensor) -> torch.Tensor:
+        """Index of the table entry nearest to each sigma; ties go to the lower index (noise_schedule.py:478-505)."""
+        shape = sigma_t.shape
+        flat = sigma_t.reshape(shape[0]) if sigma_t.ndim > 1 else sigma_t
+        table = self.sigmas.to(flat)
+        hi = torch.searchsorted(table, flat, side="right")
+        lo = (hi - 1).clamp(min=0)
+        hi = hi.clamp(max=table.numel() - 1)
+        pick_hi = (table[hi] - flat).abs() < (table[lo] - flat).abs()
+        return torch.where(pick_hi, hi, lo).view(shape)
+
+    def sigma_idx_to_t(self, sigma_idx: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    def sqrt_snr(self, t: torch.Tensor) -> torch.Tensor:
+        """alpha(t) / clamp(sigma(t)), evaluated and returned in fp64 (noise_schedule.py:518-531)."""
+        assert self.is_t_valid(t)
+        t64 = t.to(torch.float64)
+        return self.alpha(t64) / self.non_zero_clamp(self.sigma(t64))
+
+    def sqrt_snr_to_t(self, sqrt_snr_t: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
 
     def latents(self, noise: torch.Tensor, t_init: Optional[torch.Tensor] = None) -> torch.Tensor:
         """noise * sigma(t_init), evaluated in fp64 (noise_schedule.py:72-88)."""
@@ -152,6 +237,21 @@ class EDMNoiseSchedule(BaseNoiseSchedule):
     def alpha(self, t):
         return torch.ones_like(t)
 
+    def alpha_prime(self, t):
+        return torch.zeros_like(t)
+
+    def _rescale(self, t):
+        return t
+
+    def sigma_idx_to_t(self, sigma_idx: torch.Tensor) -> torch.Tensor:
+        """sigma(t) = t: the table entry itself (noise_schedule.py:785-799)."""
+        assert sigma_idx.dtype == torch.long
+        return self._sigmas.to(device=sigma_idx.device)[sigma_idx]
+
+    def sqrt_snr_to_t(self, sqrt_snr_t: torch.Tensor) -> torch.Tensor:
+        """alpha / sigma = 1 / t  =>  t = 1 / clamp(sqrt_snr), in fp64 (noise_schedule.py:801-817)."""
+        return (1 / self.non_zero_clamp(sqrt_snr_t.to(torch.float64))).to(sqrt_snr_t.dtype)
+
     def get_t_list(self, sample_steps: int, device: Optional[torch.device] = None) -> torch.Tensor:
         """sample_steps+1 decreasing timesteps: table entries at linspace(max_step, min_step).long(), last := 0
         (noise_schedule.py:940-973)."""
@@ -160,16 +260,28 @@ class EDMNoiseSchedule(BaseNoiseSchedule):
         t[-1] = 0.0
         return t.to(device=device or self._sigmas.device, dtype=self.t_precision).clamp(max=self.max_t)
 
-    def sample_t(self, n: int, time_dist_type: str = "polynomial", device=None, **kwargs) -> torch.Tensor:
-        """Training-time timestep draws; only the table-index ('polynomial') and uniform forms are provided here."""
+    def sample_t(self, n: int, time_dist_type: str = "polynomial", train_p_mean: float = -1.2, train_p_std: float = 1.2,
+                 min_t: Optional[float] = 0.002, max_t: Optional[float] = 80.0, device=None, **kwargs) -> torch.Tensor:
+        """Training-time timestep draws (noise_schedule.py:878-938): 'polynomial' (uniform over the table indices
+        [min_step, max_step]), 'uniform', 'lognormal' (ln t ~ N(mean, std) truncated to [min_t, max_t], by inverse CDF in
+        t_precision on the CPU generator, :819-843).  The Student-t form ('log_t', scipy) is not provided."""
+        min_t = max(min_t, self.min_t) if min_t is not None else self.min_t
+        max_t = min(max_t, self.max_t) if max_t is not None else self.max_t
+        dev = device or self._sigmas.device
         if time_dist_type == "polynomial":
-            idx = torch.randint(self._min_step, self._max_step + 1, (n,))
-            t = self._sigmas[idx]
+            idx = torch.randint(self._min_step, self._max_step + 1, (n,), device=self._sigmas.device)
+            t = self._sigmas[idx].to(device=dev, dtype=self.t_precision)
         elif time_dist_type == "uniform":
-            t = torch.rand(n, dtype=self.t_precision) * (self.max_t - self.min_t) + self.min_t
+            t = torch.rand(n, device=dev, dtype=self.t_precision) * (max_t - min_t) + min_t
+        elif time_dist_type == "lognormal":
+            normal = torch.distributions.Normal(torch.tensor(train_p_mean, dtype=self.t_precision),
+                                                torch.tensor(train_p_std, dtype=self.t_precision))
+            c_lo = normal.cdf(torch.tensor(max(min_t, self.clamp_min), dtype=self.t_precision).log())
+            c_hi = normal.cdf(torch.tensor(max_t, dtype=self.t_precision).log())
+            t = normal.icdf(torch.rand(n, dtype=self.t_precision) * (c_hi - c_lo) + c_lo).exp().to(device=dev)
         else:
             raise ValueError(f"Unsupported time distribution type: {time_dist_type} in EDMNoiseSchedule.")
-        return t.to(device=device, dtype=self.t_precision).clamp(self.min_t, self.max_t)
+        return self.safe_clamp(t, min_t, max_t)
 
 
 class RFNoiseSchedule(BaseNoiseSchedule):
@@ -189,22 +301,38 @@ class RFNoiseSchedule(BaseNoiseSchedule):
     def alpha(self, t):
         return 1 - t
 
+    def alpha_prime(self, t):
+        return -torch.ones_like(t)
+
+    def _rescale(self, t):
+        return self.num_steps * t
+
+    def sigma_idx_to_t(self, sigma_idx: torch.Tensor) -> torch.Tensor:
+        """index / num_steps (noise_schedule.py:1349-1362)."""
+        assert sigma_idx.dtype == torch.long
+        return sigma_idx.to(self.t_precision) / self.num_steps
+
+    def sqrt_snr_to_t(self, sqrt_snr_t: torch.Tensor) -> torch.Tensor:
+        """(1 - t) / t = s  =>  t = 1 / (s + 1), in fp64 (noise_schedule.py:1364-1381)."""
+        return (1 / (sqrt_snr_t.to(torch.float64) + 1)).to(sqrt_snr_t.dtype)
+
     def sample_t(self, n: int, time_dist_type: str = "logitnormal", train_p_mean: float = 0, train_p_std: float = 1.0,
                  min_t: Optional[float] = 0.001, max_t: Optional[float] = 0.999, device=None, **kwargs) -> torch.Tensor:
         """Training-time timestep draws (noise_schedule.py:1383-1424)."""
         min_t = max(min_t, self.min_t) if min_t is not None else self.min_t
         max_t = min(max_t, self.max_t) if max_t is not None else self.max_t
+        dev = device or self._sigmas.device
         if time_dist_type == "logitnormal":
-            t = torch.sigmoid(torch.randn(n, dtype=self.t_precision) * train_p_std + train_p_mean) * (max_t - min_t) + min_t
+            t = torch.sigmoid(torch.randn(n, device=dev, dtype=self.t_precision) * train_p_std + train_p_mean) * (max_t - min_t) + min_t
         elif time_dist_type in ("uniform", "shifted"):
-            t = torch.rand(n, dtype=self.t_precision) * (max_t - min_t) + min_t
+            t = torch.rand(n, device=dev, dtype=self.t_precision) * (max_t - min_t) + min_t
             if time_dist_type == "shifted":
                 shift = kwargs.get("shift", 5.0)
                 assert shift >= 1, f"shift must be >= 1, got {shift}"
                 t = t * shift / (t * (shift - 1) + 1)
         else:
             raise ValueError(f"Unsupported time distribution type: {time_dist_type} in RFNoiseSchedule.")
-        return t.to(device=device).clamp(min_t, max_t)
+        return self.safe_clamp(t, min_t, max_t)
 
 
 NOISE_SCHEDULES = {"edm": EDMNoiseSchedule, "rf": RFNoiseSchedule}

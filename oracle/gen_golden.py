@@ -11,6 +11,7 @@ drift of the RNG stream is detected instead of silently comparing different prob
 Usage:  python oracle/gen_golden.py            (writes tests/golden/*.pt)
         python oracle/gen_golden.py meanflow   (only the MeanFlow / rectified-flow fixtures)
         python oracle/gen_golden.py sample     (only the teacher Euler-sampler fixture)
+        python oracle/gen_golden.py train_schedule   (only the training-side schedule helpers)
 """
 import os
 import sys
@@ -136,10 +137,54 @@ def teacher_sample_fixture(edm_net):
                 "out_cfg": out_cfg.clone(), "out_plain": out_plain.clone()}, os.path.join(OUT, "teacher_sample_b2.pt"))
 
 
+def train_schedule_fixture(ns):
+    """The schedule members only the training callers read (dmd2.py:100-120, sCM.py, mean_flow.py): derivatives,
+    conditional velocity, SNR maps, table look-ups, t_list stepping and the seeded timestep draws."""
+    fx = {}
+    x = seeded((3, 3, 4, 4), 31)
+    e = seeded((3, 3, 4, 4), 32)
+    for name, sched, t in (("edm", ns.EDMNoiseSchedule(), torch.tensor([63.2, 1.7, 0.0021], dtype=torch.float64)),
+                           ("rf", ns.RFNoiseSchedule(), torch.tensor([0.93, 0.4, 0.0], dtype=torch.float64))):
+        fx[f"{name}/t"] = t
+        fx[f"{name}/rescale_t"] = sched.rescale_t(t)
+        fx[f"{name}/alpha_prime"] = sched.alpha_prime(t)
+        fx[f"{name}/sigma_prime"] = sched.sigma_prime(t)
+        fx[f"{name}/cond_velocity"] = sched.cond_velocity(x, e, t)
+        fx[f"{name}/sqrt_snr"] = sched.sqrt_snr(t)
+        fx[f"{name}/sqrt_snr_to_t"] = sched.sqrt_snr_to_t(torch.tensor([0.0, 0.3, 7.5, 2e-7], dtype=torch.float32))
+        probe = torch.cat([t, sched.sigmas[[0, 1, 500, 999]], (sched.sigmas[10:12].mean()).reshape(1),
+                           torch.tensor([1e3, -1.0], dtype=torch.float64)])
+        fx[f"{name}/closest_probe"] = probe
+        fx[f"{name}/closest_idx"] = sched.closest_sigma_idx(probe)
+        fx[f"{name}/closest_idx_4d"] = sched.closest_sigma_idx(probe[:3].reshape(3, 1, 1, 1))
+        fx[f"{name}/sigma_idx_to_t"] = sched.sigma_idx_to_t(torch.tensor([0, 17, 999]))
+        ids = torch.tensor([0, 2, 1, 3])
+        fx[f"{name}/next_default"] = sched.next_in_t_list(ids, 4, None)
+        fx[f"{name}/next_custom_stride2"] = sched.next_in_t_list(torch.tensor([0, 1]), 3, [0.9, 0.5, 0.2, 0.0], stride=2)
+        torch.manual_seed(77)
+        tt, ii = sched.sample_from_t_list(16, 4, return_ids=True)
+        fx[f"{name}/sample_from_t_list"], fx[f"{name}/sample_from_t_list_ids"] = tt, ii
+        torch.manual_seed(78)
+        fx[f"{name}/sample_from_custom"] = sched.sample_from_t_list(8, 3, t_list=[0.9, 0.5, 0.2, 0.0])
+        kinds = ("polynomial", "uniform", "lognormal") if name == "edm" else ("logitnormal", "uniform", "shifted")
+        for k in kinds:
+            torch.manual_seed(79)
+            fx[f"{name}/sample_t_{k}"] = sched.sample_t(32, time_dist_type=k)
+        torch.manual_seed(80)
+        fx[f"{name}/sample_t_bounded"] = sched.sample_t(32, time_dist_type="uniform", min_t=0.0001, max_t=0.5)
+        fx[f"{name}/safe_clamp_f32"] = sched.safe_clamp(torch.tensor([-1.0, 0.4, 90.0], dtype=torch.float32), 0.002, 0.999)
+        fx[f"{name}/safe_clamp_bf16"] = sched.safe_clamp(torch.tensor([-1.0, 0.4, 90.0], dtype=torch.bfloat16), 0.002, 0.999)
+    torch.save(fx, os.path.join(OUT, "schedule_train.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     edm_net, ns, model = _ref_import.import_reference()
     torch.manual_seed(0)
+    if sys.argv[1:] == ["train_schedule"]:
+        train_schedule_fixture(ns)
+        print("training-side schedule fixture written to", OUT)
+        return
     if sys.argv[1:] == ["sample"]:
         teacher_sample_fixture(edm_net)
         print("teacher sample fixture written to", OUT)
@@ -270,6 +315,7 @@ def main():
                os.path.join(OUT, "forward_small.pt"))
 
     meanflow_fixtures(edm_net, ns)
+    train_schedule_fixture(ns)
     teacher_sample_fixture(edm_net)
 
     print("golden fixtures written to", OUT)

@@ -252,6 +252,57 @@ class _FakeFlowNet(torch.nn.Module):
         return x * (0.3 + t.float().reshape(-1, 1, 1, 1)) - r.float().reshape(-1, 1, 1, 1)
 
 
+@pytest.mark.parametrize("name", ["edm", "rf"])
+def test_training_side_schedule_members_match_golden(golden_dir, name):
+    """The members the DMD2 / sCM / MeanFlow training callers read, against values recorded from the reference
+    (oracle/gen_golden.py train_schedule): exact, including the seeded draws (same generator calls in the same order)."""
+    fx = {k.split("/", 1)[1]: v for k, v in torch.load(os.path.join(golden_dir, "schedule_train.pt"), weights_only=True).items()
+          if k.startswith(name + "/")}
+    sched = get_noise_schedule(name)
+    x = torch.randn((3, 3, 4, 4), generator=torch.Generator().manual_seed(31))
+    e = torch.randn((3, 3, 4, 4), generator=torch.Generator().manual_seed(32))
+    t = fx["t"]
+
+    def same(got, key):
+        want = fx[key]
+        assert got.dtype == want.dtype and got.shape == want.shape, (key, got.dtype, want.dtype, got.shape, want.shape)
+        assert torch.equal(got, want), key
+
+    same(sched.rescale_t(t), "rescale_t")
+    same(sched.alpha_prime(t), "alpha_prime")
+    same(sched.sigma_prime(t), "sigma_prime")
+    same(sched.cond_velocity(x, e, t), "cond_velocity")
+    same(sched.sqrt_snr(t), "sqrt_snr")
+    same(sched.sqrt_snr_to_t(torch.tensor([0.0, 0.3, 7.5, 2e-7], dtype=torch.float32)), "sqrt_snr_to_t")
+    same(sched.closest_sigma_idx(fx["closest_probe"]), "closest_idx")
+    same(sched.closest_sigma_idx(fx["closest_probe"][:3].reshape(3, 1, 1, 1)), "closest_idx_4d")
+    same(sched.sigma_idx_to_t(torch.tensor([0, 17, 999])), "sigma_idx_to_t")
+    same(sched.next_in_t_list(torch.tensor([0, 2, 1, 3]), 4, None), "next_default")
+    same(sched.next_in_t_list(torch.tensor([0, 1]), 3, [0.9, 0.5, 0.2, 0.0], stride=2), "next_custom_stride2")
+    with pytest.raises(ValueError):
+        sched.next_in_t_list(torch.tensor([3]), 4, None, stride=2)
+    with pytest.raises(AssertionError):
+        sched.next_in_t_list(torch.tensor([0]), 4, [0.9, 0.5, 0.0])
+    torch.manual_seed(77)
+    tt, ii = sched.sample_from_t_list(16, 4, return_ids=True)
+    same(tt, "sample_from_t_list")
+    same(ii, "sample_from_t_list_ids")
+    assert int(ii.max()) <= 3  # never the clean (t = 0) entry
+    torch.manual_seed(78)
+    same(sched.sample_from_t_list(8, 3, t_list=[0.9, 0.5, 0.2, 0.0]), "sample_from_custom")
+    for kind in (("polynomial", "uniform", "lognormal") if name == "edm" else ("logitnormal", "uniform", "shifted")):
+        torch.manual_seed(79)
+        same(sched.sample_t(32, time_dist_type=kind), f"sample_t_{kind}")
+    torch.manual_seed(80)
+    got = sched.sample_t(32, time_dist_type="uniform", min_t=0.0001, max_t=0.5)
+    same(got, "sample_t_bounded")
+    assert float(got.min()) >= sched.min_t and float(got.max()) <= 0.5
+    same(sched.safe_clamp(torch.tensor([-1.0, 0.4, 90.0], dtype=torch.float32), 0.002, 0.999), "safe_clamp_f32")
+    same(sched.safe_clamp(torch.tensor([-1.0, 0.4, 90.0], dtype=torch.bfloat16), 0.002, 0.999), "safe_clamp_bf16")
+    with pytest.raises(ValueError):
+        sched.sample_t(4, time_dist_type="no-such-distribution")
+
+
 def test_meanflow_generic_loop_matches_reference_semantics():
     net = _FakeFlowNet()
     noise = torch.randn(3, 3, 8, 8, generator=torch.Generator().manual_seed(0))
