@@ -1068,6 +1068,12 @@ int fg_op_x0_to_eps(const float* xt, const float* x0, double t, int schedule, fl
     HIP_TRY(launch_x0_to_eps(xt, x0, t, nullptr, 0, schedule, 1e-6, out, total, (hipStream_t)stream));
     return FG_OK;
 }
+int fg_op_images_to_u8(const float* images, uint8_t* out, int64_t batch, int channels, int height, int width, void* stream) {
+    if (batch < 0 || channels <= 0 || height <= 0 || width <= 0) return fail(FG_EINVAL, "fg_op_images_to_u8: bad shape");
+    if (batch && (!images || !out)) return fail(FG_EINVAL, "fg_op_images_to_u8: null pointer");
+    HIP_TRY(launch_images_to_u8(images, out, batch, channels, height * width, (hipStream_t)stream));
+    return FG_OK;
+}
 int fg_op_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, void* stream) {
     HIP_TRY(launch_randn(out, total, seed, offset, nullptr, (hipStream_t)stream));
     return FG_OK;

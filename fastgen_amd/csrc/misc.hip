@@ -639,6 +639,32 @@ int launch_act_to_nchw(int dtype, const void* in, float* out, int B, int C, int 
         hipLaunchKernelGGL(nhwc_act_to_nchw_kernel<float>, grid, dim3(256), 0, s, (const float*)in, out, C, HW);
     RET_LAST();
 }
+// Samples -> image bytes, the step that follows generator_fn in the reference's sample writer
+// (scripts/fid/compute_fid_from_ckpts.py:199): (x * 127.5 + 128).clip(0, 255).to(uint8).permute(0, 2, 3, 1).
+// fp32 multiply then add (two roundings, as torch evaluates it - no FMA contraction), clamp, truncate; NaN maps to 0.
+// One thread per pixel: C coalesced plane reads, C consecutive bytes out.
+__global__ __launch_bounds__(256) void images_to_u8_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, int64_t npix,
+                                                           int C, int HW) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const int64_t n = i / HW;
+    const int p = (int)(i - n * HW);
+    const float* src = x + n * C * HW + p;
+    uint8_t* dst = out + i * C;
+    for (int c = 0; c < C; ++c) {
+        float v = src[(int64_t)c * HW] * 127.5f;
+        v = v + 128.0f;
+        v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);  // false for NaN on both sides ...
+        dst[c] = v == v ? (uint8_t)(int)v : (uint8_t)0;  // ... which is written as 0
+    }
+}
+int launch_images_to_u8(const float* x, uint8_t* out, int64_t B, int C, int HW, hipStream_t s) {
+    const int64_t npix = B * HW;
+    if (npix <= 0) return 0;
+    hipLaunchKernelGGL(images_to_u8_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, x, out, npix, C, HW);
+    RET_LAST();
+}
 int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, hipStream_t s) {
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid((int64_t)B * C * HW)), dim3(256), 0, s, in, out, B, C, HW);
     RET_LAST();

@@ -166,6 +166,11 @@ int fg_op_latents(const float* noise, double t_init, float* out, int64_t total, 
 int fg_op_forward_process(const float* x0, const float* eps, double t, int schedule, float* out, int64_t total,
                           void* stream);
 int fg_op_x0_to_eps(const float* xt, const float* x0, double t, int schedule, float* out, int64_t total, void* stream);
+/* Samples to image bytes, the step after generator_fn in the reference's sample writer
+ * (scripts/fid/compute_fid_from_ckpts.py:199): out[n,y,x,c] = uint8(clip(images[n,c,y,x] * 127.5 + 128, 0, 255)),
+ * fp32 multiply then add, truncation; NaN -> 0.  images NCHW fp32, out NHWC bytes. */
+int fg_op_images_to_u8(const float* images, uint8_t* out, int64_t batch, int channels, int height, int width,
+                       void* stream);
 /* Standard normal draws: Philox4x32-10(key = seed, counter = (offset, index/4)) + Box-Muller. */
 int fg_op_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, void* stream);
 

@@ -493,3 +493,12 @@ def edm_sample(sd, cfg, noise: Tensor, condition=None, neg_condition=None, guida
         d = (x - x0) / t.reshape(-1, 1, 1, 1)
         x = x + (sigma_next - sigma).to(x.dtype) * d
     return x
+
+
+def images_to_uint8(images: torch.Tensor) -> torch.Tensor:
+    """The sample writer's conversion that follows generator_fn (scripts/fid/compute_fid_from_ckpts.py:199):
+    fp32 `images * 127.5 + 128`, clip to [0, 255], truncate to uint8, NCHW -> NHWC.  (No reference function to import:
+    it is one expression inside a script; pinned by the hand-derived known answers in tests/test_oracle_golden.py.)"""
+    v = images.to(torch.float32) * 127.5 + 128
+    return v.clip(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+

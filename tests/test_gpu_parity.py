@@ -111,6 +111,30 @@ def test_sampler_elementwise_bit_exact():
             assert torch.equal(od.cpu(), R.x0_to_eps(x, e, tt.expand(4), schedule=sched))
 
 
+@pytest.mark.parametrize("shape", [(512, 3, 32, 32), (7, 3, 32, 32), (3, 1, 5, 9), (0, 3, 32, 32)])
+def test_images_to_uint8_bit_exact(shape):
+    """Sample-writer bytes (scripts/fid/compute_fid_from_ckpts.py:199) against the oracle: exact, including values on the
+    truncation boundaries and saturating ones; B = 512 is the bench batch, the others are ragged / empty."""
+    from fastgen_amd.utils.images import images_to_uint8
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(shape, generator=g) * 0.7
+    if x.numel():
+        flat = x.view(-1)
+        k = torch.arange(0, 256, dtype=torch.float32)
+        edge = torch.cat([(k - 128) / 127.5, torch.nextafter((k - 128) / 127.5, torch.tensor(-9.0)), torch.tensor([-9.0, 9.0, -1.0, 1.0])])
+        n = min(edge.numel(), flat.numel())
+        flat[:n] = edge[:n]
+    got = images_to_uint8(x.cuda())
+    want = R.images_to_uint8(x)
+    assert got.dtype == torch.uint8 and tuple(got.shape) == tuple(want.shape)
+    assert torch.equal(got.cpu(), want)
+    with pytest.raises(RuntimeError):
+        images_to_uint8(x)  # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        images_to_uint8(torch.zeros(3, 4, device="cuda"))
+
+
 def test_randn_device_generator():
     L = _lib.lib()
     n = 1 << 20

@@ -205,3 +205,19 @@ def test_teacher_euler_sampler(golden_dir, full_sd):
         assert torch.allclose(got, fx["out_cfg"], rtol=1e-6, atol=1e-7)
         got = R.edm_sample(full_sd, R.CIFAR10, noise, fx["cond"], None, None, 3)
         assert torch.allclose(got, fx["out_plain"], rtol=1e-6, atol=1e-7)
+
+
+def test_images_to_uint8_known_answers():
+    """Sample-writer conversion (scripts/fid/compute_fid_from_ckpts.py:199): hand-derived bytes.  -1 -> 0.5 -> 0;
+    0 -> 128; 1 -> 255.5 -> clip 255; (k - 128) / 127.5 lands on or just around the integer k; out-of-range saturates."""
+    vals = torch.tensor([-1.0, 0.0, 1.0, -5.0, 7.0, -1.0 + 1 / 127.5, 0.999, 0.5, -0.5, 2 / 255 - 1], dtype=torch.float32)
+    want = [0, 128, 255, 0, 255, 1, 255, 191, 64, 1]
+    # 0.999 * 127.5 + 128 = 255.3725 -> 255;  0.5 -> 191.75 -> 191;  -0.5 -> 64.25 -> 64;  2/255 - 1 -> 1.5 -> 1
+    x = vals.reshape(1, 1, 1, -1).expand(2, 3, 1, -1)
+    got = R.images_to_uint8(x)
+    assert got.dtype == torch.uint8 and got.shape == (2, 1, vals.numel(), 3)
+    for c in range(3):
+        assert got[0, 0, :, c].tolist() == want
+    # layout: channel is innermost in the output
+    y = torch.stack([torch.full((2, 2), -1.0), torch.zeros(2, 2), torch.ones(2, 2)]).unsqueeze(0)
+    assert R.images_to_uint8(y)[0, 1, 1].tolist() == [0, 128, 255]
