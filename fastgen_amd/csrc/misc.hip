@@ -207,41 +207,58 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 // 32x32 output tile, operands straight from global memory (x is <= 1 MB and W is re-read from L2 by the B/32 row tiles).
 // Lane (m = lane & 31, h = lane >> 5) fetches the 8 consecutive k = k0 + 8h .. 8h+7 of its row; MFMA i of the 16-wide k
 // block then multiplies k = k0 + i (lanes 0-31) and k0 + 8 + i (lanes 32-63) - a permutation of the k order that is the same
-// for both operands.  Needs I % 16 == 0 and O % 32 == 0; ragged B is clamped on load and masked on store.
-template <int ACT>
+// for both operands.  Needs I % KB == 0 (KB = 64 or 16) and O % 32 == 0; ragged B is clamped on load and masked on store.
+// A wave covers NB row tiles (32 NB batch rows) with one weight fragment stream.
+template <int ACT, int KB, int NB>
 __global__ __launch_bounds__(64) void linear_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y, int B, int I,
                                                           int O) {
     typedef __attribute__((ext_vector_type(16))) float f32x16;
     const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
-    const int o0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
-    const int br = min(b0 + m, B - 1);
-    const float4* xp = reinterpret_cast<const float4*>(x + (size_t)br * I + 8 * h);
+    const int o0 = blockIdx.x * 32, b0 = blockIdx.y * (32 * NB);
+    const float4* xp[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) xp[t] = reinterpret_cast<const float4*>(x + (size_t)min(b0 + 32 * t + m, B - 1) * I + 8 * h);
     const float4* wp = reinterpret_cast<const float4*>(w + (size_t)(o0 + m) * I + 8 * h);
-    f32x16 acc;
+    f32x16 acc[NB];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    float4 xa = xp[0], xb = xp[1], wa = wp[0], wb = wp[1];
-    for (int k0 = 0; k0 < I; k0 += 16) {
-        const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-        const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-        const int kn = min(k0 + 16, I - 16) / 4;  // next block (the last iteration re-reads its own)
-        xa = xp[kn], xb = xp[kn + 1], wa = wp[kn], wb = wp[kn + 1];
+    for (int t = 0; t < NB; ++t)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[i], wv[i], acc, 0, 0, 0);
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    // KB k-values per trip: all of a trip's loads are issued before its MFMAs, so a wave waits for memory I / KB times
+    // (the other waves of the SIMD run their MFMAs meanwhile)
+    for (int k0 = 0; k0 < I; k0 += KB) {
+        float4 xv[NB][KB / 8], wv[KB / 8];
+#pragma unroll
+        for (int u = 0; u < KB / 16; ++u) {
+            wv[2 * u] = wp[k0 / 4 + 4 * u], wv[2 * u + 1] = wp[k0 / 4 + 4 * u + 1];
+#pragma unroll
+            for (int t = 0; t < NB; ++t) xv[t][2 * u] = xp[t][k0 / 4 + 4 * u], xv[t][2 * u + 1] = xp[t][k0 / 4 + 4 * u + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < KB / 8; ++u)
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[t][u].x, wv[u].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[t][u].y, wv[u].y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[t][u].z, wv[u].z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[t][u].w, wv[u].w, acc[t], 0, 0, 0);
+            }
     }
     // C layout: column (output feature) = lane & 31, rows (batch) 8 * (i >> 2) + 4 * h + (i & 3)
     const int o = o0 + m;
     const float bo = bias ? bias[o] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int b = b0 + 8 * (i >> 2) + 4 * h + (i & 3);
-        if (b < B) {
-            float v = acc[i] + bo;
-            if (ACT == 1) v = v / (1.0f + expf(-v));
-            y[(size_t)b * O + o] = v;
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int b = b0 + 32 * t + 8 * (i >> 2) + 4 * h + (i & 3);
+            if (b < B) {
+                float v = acc[t][i] + bo;
+                if (ACT == 1) v = v / (1.0f + expf(-v));
+                y[(size_t)b * O + o] = v;
+            }
         }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -536,11 +553,24 @@ int launch_mapping_in(const float* c_noise, const float* r_noise, const float* f
 int launch_linear(const float* x, const float* w, const float* bias, float* y, int B, int I, int O, int act_silu,
                   hipStream_t s) {
     if (I % 16 == 0 && O % 32 == 0) {
-        dim3 g(O / 32, (B + 31) / 32);
-        if (act_silu)
-            hipLaunchKernelGGL(linear_mfma_kernel<1>, g, dim3(64), 0, s, x, w, bias, y, B, I, O);
-        else
-            hipLaunchKernelGGL(linear_mfma_kernel<0>, g, dim3(64), 0, s, x, w, bias, y, B, I, O);
+        // wide outputs (the stacked affines): two row tiles per wave halve the weight traffic; otherwise keep the wave count up
+        const bool pair = I % 64 == 0 && B > 32 && O >= 2048;
+        dim3 g(O / 32, pair ? (B + 63) / 64 : (B + 31) / 32);
+        if (pair) {
+            if (act_silu)
+                hipLaunchKernelGGL((linear_mfma_kernel<1, 64, 2>), g, dim3(64), 0, s, x, w, bias, y, B, I, O);
+            else
+                hipLaunchKernelGGL((linear_mfma_kernel<0, 64, 2>), g, dim3(64), 0, s, x, w, bias, y, B, I, O);
+        } else if (I % 64 == 0) {
+            if (act_silu)
+                hipLaunchKernelGGL((linear_mfma_kernel<1, 64, 1>), g, dim3(64), 0, s, x, w, bias, y, B, I, O);
+            else
+                hipLaunchKernelGGL((linear_mfma_kernel<0, 64, 1>), g, dim3(64), 0, s, x, w, bias, y, B, I, O);
+        } else if (act_silu) {
+            hipLaunchKernelGGL((linear_mfma_kernel<1, 16, 1>), g, dim3(64), 0, s, x, w, bias, y, B, I, O);
+        } else {
+            hipLaunchKernelGGL((linear_mfma_kernel<0, 16, 1>), g, dim3(64), 0, s, x, w, bias, y, B, I, O);
+        }
         RET_LAST();
     }
     dim3 grid((O + 63) / 64, (B + 63) / 64);
