@@ -123,7 +123,7 @@ __global__ void pack_aux_weights_kernel(const float* __restrict__ w, T* __restri
 template <typename T>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ c_in,
                                                    const T* __restrict__ wpack, const float* __restrict__ bias,
-                                                   T* __restrict__ out, int B, int res, int cin) {
+                                                   T* __restrict__ out, float2* __restrict__ stats, int B, int res, int cin) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int hw = res * res;
@@ -162,8 +162,23 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const float bv = bias[nt * 32 + r];
+        float sv = 0.f, qv = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) obase[(size_t)acc_row(i, h) * 128 + nt * 32 + r] = (T)(acc[nt][i] + bv);
+        for (int i = 0; i < 16; ++i) {
+            const float v = acc[nt][i] + bv;
+            obase[(size_t)acc_row(i, h) * 128 + nt * 32 + r] = (T)v;
+            sv += v;
+            qv = fmaf(v, v, qv);
+        }
+        // GroupNorm partial statistics of this wave's 32 pixels (slot = wave within the image), per channel quad: the
+        // format the conv epilogues write (misc.hip gn_finalize_kernel), so block0's norm0 needs no pass over the tensor
+        if (stats) {
+            sv += __shfl_xor(sv, 32), qv += __shfl_xor(qv, 32);
+            sv += __shfl_xor(sv, 1), qv += __shfl_xor(qv, 1);
+            sv += __shfl_xor(sv, 2), qv += __shfl_xor(qv, 2);
+            if (h == 0 && (r & 3) == 0)
+                stats[((size_t)n * (hw / 32) + (int)(p0 % hw) / 32) * 32 + nt * 8 + (r >> 2)] = make_float2(sv, qv);
+        }
     }
 }
 
@@ -212,13 +227,13 @@ int launch_pack_stem_weights(int dtype, const float* w, void* out, int cin, hipS
         hipLaunchKernelGGL(pack_stem_weights_kernel<float>, dim3(16), dim3(256), 0, s, w, (float*)out, cin);
     return (int)hipGetLastError();
 }
-int launch_stem(int dtype, const float* x, const float* c_in, const void* wpack, const float* bias, void* out, int B,
-                int res, int cin, hipStream_t s) {
+int launch_stem(int dtype, const float* x, const float* c_in, const void* wpack, const float* bias, void* out, float2* stats,
+                int B, int res, int cin, hipStream_t s) {
     const long long waves = (long long)B * res * res / 32;
     dim3 grid((unsigned)((waves + 3) / 4));
     if (dtype)
-        hipLaunchKernelGGL(stem_kernel<__bf16>, grid, dim3(256), 0, s, x, c_in, (const __bf16*)wpack, bias, (__bf16*)out, B, res, cin);
+        hipLaunchKernelGGL(stem_kernel<__bf16>, grid, dim3(256), 0, s, x, c_in, (const __bf16*)wpack, bias, (__bf16*)out, stats, B, res, cin);
     else
-        hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, s, x, c_in, (const float*)wpack, bias, (float*)out, B, res, cin);
+        hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, s, x, c_in, (const float*)wpack, bias, (float*)out, stats, B, res, cin);
     return (int)hipGetLastError();
 }

@@ -348,22 +348,24 @@ size_t plan_workspace(const fg_edm* h, int B, Arena& A, Workspace& w) {
     w.ab1 = A.get<float2>((size_t)B * max_c);
     w.ab2 = A.get<float2>((size_t)B * max_c);
     const size_t st_elems = (size_t)B * 8 * 64;  // [B][<= 8 slots][256/4 quads]
-    auto act = [&](size_t elems) {
+    auto act = [&](size_t elems, size_t st_n) {
         Act a;
         a.p = A.take(elems * tsz);
-        a.st = A.get<float2>(st_elems);
+        a.st = A.get<float2>(st_n);
         return a;
     };
     w.skip.clear();
-    for (const Block& b : h->enc) w.skip.push_back(act((size_t)B * b.res_out * b.res_out * b.cout));
-    w.xa = act((size_t)B * max_act);
-    w.xb = act((size_t)B * max_act);
-    w.h = act((size_t)B * max_act);
+    for (const Block& b : h->enc)  // the MFMA stem writes one statistics slot per 32 pixels: [B][hw/32][128/4]
+        w.skip.push_back(act((size_t)B * b.res_out * b.res_out * b.cout,
+                             (b.kind == K_STEM && b.p_stem) ? (size_t)B * b.res_out * b.res_out : st_elems));
+    w.xa = act((size_t)B * max_act, st_elems);
+    w.xb = act((size_t)B * max_act, st_elems);
+    w.h = act((size_t)B * max_act, st_elems);
     w.sbuf = A.take((size_t)B * max_act * tsz);
     w.pool = A.take((size_t)B * max_act * tsz);
     w.cvt1 = A.take((size_t)B * max_act * 4 * tsz);  // run_block inputs: up to 512 channels at the input resolution
     w.cvt2 = A.take((size_t)B * max_act * 4 * tsz);
-    w.xattn = act((size_t)B * max_attn_hw * 256);
+    w.xattn = act((size_t)B * max_attn_hw * 256, st_elems);
     w.aout = A.take((size_t)B * max_attn_hw * 256 * tsz);
     w.q = A.take((size_t)B * max_attn_hw * 256 * tsz);
     w.k = A.take((size_t)B * max_attn_hw * 256 * tsz);
@@ -508,11 +510,13 @@ int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, cons
     for (size_t i = 0; i < h->enc.size(); ++i) {
         const Block& b = h->enc[i];
         if (b.kind == K_STEM) {
-            if (b.p_stem)
-                HIP_TRY(launch_stem(h->dtype, x_t, w.coef, b.p_stem, h->P(b.b), w.skip[i].p, B, b.res_out, b.cin, s));
-            else
+            if (b.p_stem) {  // MFMA stem: leaves GroupNorm partial statistics, one slot per 32 pixels
+                HIP_TRY(launch_stem(h->dtype, x_t, w.coef, b.p_stem, h->P(b.b), w.skip[i].p, w.skip[i].st, B, b.res_out, b.cin, s));
+                w.skip[i].slots = b.res_out * b.res_out / 32;
+            } else {
                 HIP_TRY(launch_conv_in(h->dtype, x_t, w.coef, h->P(b.w), h->P(b.b), w.skip[i].p, B, b.res_out, b.cin, b.cout, s));
-            w.skip[i].st = nullptr;  // the stem leaves no statistics: block0's norm0 takes the full-pass fallback
+                w.skip[i].st = nullptr;  // no statistics: block0's norm0 takes the full-pass fallback
+            }
         } else {
             rc = run_block(h, b, *x, b.cin, none, 0, w.temb, w.skip[i], B, w, s);
             if (rc) return rc;

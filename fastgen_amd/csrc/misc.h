@@ -49,5 +49,5 @@ int launch_aux_head(int dtype, const void* x, const float2* ab, const void* wpac
 int stem_supported(int res, int cin, int cout);
 size_t stem_pack_elems();
 int launch_pack_stem_weights(int dtype, const float* w, void* out, int cin, hipStream_t s);
-int launch_stem(int dtype, const float* x, const float* c_in, const void* wpack, const float* bias, void* out, int B,
-                int res, int cin, hipStream_t s);
+int launch_stem(int dtype, const float* x, const float* c_in, const void* wpack, const float* bias, void* out, float2* stats,
+                int B, int res, int cin, hipStream_t s);
