@@ -1072,6 +1072,21 @@ int fg_op_x0_to_eps(const float* xt, const float* x0, double t, int schedule, fl
     HIP_TRY(launch_x0_to_eps(xt, x0, t, nullptr, 0, schedule, 1e-6, out, total, (hipStream_t)stream));
     return FG_OK;
 }
+size_t fg_op_conv_wgrad_workspace_bytes(int batch, int res, int cin, int cout, int ks) {
+    return conv_wgrad_supported(res, cin, cout, ks) && batch > 0 ? conv_wgrad_workspace_bytes(batch, res, cin, cout, ks) : 0;
+}
+int fg_op_conv_wgrad(const void* act, const void* dy, float* dw, int batch, int res, int cin, int cout, int ks,
+                     int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!conv_wgrad_supported(res, cin, cout, ks))
+        return fail(FG_EINVAL, "fg_op_conv_wgrad: unsupported shape res=%d cin=%d cout=%d ks=%d (res 8/16/32, cin %% 32, cout %% 128, ks 1/3)",
+                    res, cin, cout, ks);
+    if (batch <= 0 || !act || !dy || !dw || !workspace) return fail(FG_EINVAL, "fg_op_conv_wgrad: bad argument");
+    if (workspace_bytes < conv_wgrad_workspace_bytes(batch, res, cin, cout, ks))
+        return fail(FG_EINVAL, "fg_op_conv_wgrad: workspace too small (%zu < %zu bytes)", workspace_bytes,
+                    conv_wgrad_workspace_bytes(batch, res, cin, cout, ks));
+    HIP_TRY(launch_conv_wgrad(act, dy, dw, batch, res, cin, cout, ks, accumulate, workspace, (hipStream_t)stream));
+    return FG_OK;
+}
 int fg_op_images_to_u8(const float* images, uint8_t* out, int64_t batch, int channels, int height, int width, void* stream) {
     if (batch < 0 || channels <= 0 || height <= 0 || width <= 0) return fail(FG_EINVAL, "fg_op_images_to_u8: bad shape");
     if (batch && (!images || !out)) return fail(FG_EINVAL, "fg_op_images_to_u8: null pointer");

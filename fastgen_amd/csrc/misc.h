@@ -30,6 +30,11 @@ int launch_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, cons
 int launch_gn_silu_pool(int dtype, const void* x, const float2* ab, void* out, int B, int H, int W, int C, hipStream_t s);
 int launch_to_act(int dtype, const float* in, void* out, int64_t total, hipStream_t s);
 int launch_from_act(int dtype, const void* in, float* out, int64_t total, hipStream_t s);
+// wgrad.hip: weight gradient of a 3x3 / 1x1 convolution (training step)
+int conv_wgrad_supported(int res, int cin, int cout, int ks);
+size_t conv_wgrad_workspace_bytes(int B, int res, int cin, int cout, int ks);
+int launch_conv_wgrad(const void* act, const void* dy, float* dw, int B, int res, int cin, int cout, int ks, int accumulate,
+                      void* workspace, hipStream_t s);
 int launch_images_to_u8(const float* x, uint8_t* out, int64_t B, int C, int HW, hipStream_t s);
 int launch_act_to_nchw(int dtype, const void* in, float* out, int B, int C, int HW, hipStream_t s);  // HW, C multiples of 32
 int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, hipStream_t s);

@@ -1,0 +1,194 @@
+// Weight gradient of the U-Net's convolutions (first kernel of SURVEY §8(f)1, the DMD2 training step):
+//
+//   dW[co][ci][ky][kx] = sum over (n, y, x) of  dY[n, y, x, co] * A[n, y + ky - pad, x + kx - pad, ci]
+//
+// i.e. what autograd computes for `Conv2d.forward` (fastgen/networks/EDM/network.py:93-126) in the student / fake-score
+// updates (fastgen/methods/distribution_matching/dmd2.py).  A is the conv's input operand (after GroupNorm + SiLU and any
+// resampling), dY the gradient of its output; both NHWC bf16, zero padding outside the image.  dW is fp32 in the
+// parameter's own OIHW layout.
+//
+// This is a GEMM whose contraction index is the PIXEL: M = co, N = ci (x taps), K = B*H*W.  Both operands are stored
+// pixel-major, so an MFMA lane, which needs 8 consecutive K values of one row, would have to gather 2-byte elements 2*C
+// bytes apart.  gfx950's transposing LDS read does that for free: tiles are parked in LDS exactly as they lie in memory
+// ([pixel][channel], 16-byte copies) and `ds_read_b64_tr_b16` hands every lane four consecutive pixels of its channel
+// (guide T10: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3; lane i receives column i of the 4 rows).
+//
+// Work split: one 256-thread workgroup owns the output block [128 co] x [32 ci] x [taps] (wave w: co 32w..32w+31, nine
+// 32x32 accumulators = 144 registers) and walks a contiguous range of 64-pixel tiles (4 rows x 16 pixels; one 8x8 image);
+// grid = (Cin/32) x KSPLIT x (Cout/128).  Each split writes its partial sums to a workspace and a second kernel adds the
+// KSPLIT partials in a fixed order — deterministic, no atomics.  Two workgroups fit a CU, so one's loads overlap the
+// other's MFMAs; the tile loop itself is the plain load -> barrier -> MFMA -> barrier form (first correct version).
+#include "common.h"
+#include "misc.h"
+
+namespace {
+
+constexpr int WG_THREADS = 256;
+constexpr int WG_CO = 128;       // output channels per workgroup (4 waves x 32)
+constexpr int WG_CI = 32;        // input channels per workgroup
+constexpr int WG_TILE = 64;      // pixels per tile = 4 MFMA k-steps of 16
+constexpr int WG_DYP = 2 * WG_CO + 64;  // dY tile row pitch in bytes: 4 consecutive rows tile the 64 banks (320 = 64 mod 256)
+constexpr int WG_AP = 2 * WG_CI;        // A tile bytes per (halo) pixel
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ s16x4 tr_read(const char* lds_addr) {
+    // generic -> LDS address space: the low 32 bits of a generic LDS pointer are the LDS offset
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(uint32_t)(uintptr_t)lds_addr);
+}
+
+// One MFMA operand (8 consecutive K of this lane's row/column) = two transposed reads of 4 pixels each.
+__device__ __forceinline__ Frag8<__bf16> tr_frag(const char* p0, const char* p1) {
+    const s16x4 lo = tr_read(p0), hi = tr_read(p1);
+    s16x8 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = lo[j], v[4 + j] = hi[j];
+    Frag8<__bf16> f;
+    f.v = __builtin_bit_cast(bf16x8, v);
+    return f;
+}
+
+// LOGW: log2 of the image width (5, 4, 3).  KS: 3 or 1.
+template <int LOGW, int KS>
+__global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const __bf16* __restrict__ act, const __bf16* __restrict__ dy,
+                                                                   float* __restrict__ partial, int B, int Cin, int Cout,
+                                                                   int tiles_per_split) {
+    constexpr int W = 1 << LOGW;
+    constexpr int TW = (W >= 16) ? 16 : 8;    // tile width; a k-step is 16 pixels = one tile row (two rows at 8x8)
+    constexpr int TH = WG_TILE / TW;          // 4 or 8
+    constexpr int PAD = KS / 2;
+    constexpr int HW_ = TW + 2 * PAD, HH_ = TH + 2 * PAD;
+    constexpr int HALO = HW_ * HH_;           // 108 (3x3 at W >= 16), 100 (3x3 at 8x8), 64 (1x1)
+    constexpr int TAPS = KS * KS;
+    constexpr int TCOLS = W / TW, TPI = (W / TH) * TCOLS;
+
+    __shared__ __attribute__((aligned(16))) char s_dy[WG_TILE * WG_DYP];
+    __shared__ __attribute__((aligned(16))) char s_a[HALO * WG_AP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ci0 = blockIdx.x * WG_CI, split = blockIdx.y, cob = blockIdx.z * WG_CO;
+    const int ntiles = B * TPI;
+    const int t_begin = split * tiles_per_split, t_end = min(ntiles, t_begin + tiles_per_split);
+
+    // lane roles of the transposed reads: group g = lane >> 4, row q, column quad p
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    // dY^T operand (M = co): k = 16 s + 8 (g >> 1) + 4 r + q, co = 32 wave + 16 (g & 1) + 4 p ...
+    const char* const dy_lane = s_dy + (8 * (g >> 1) + q) * WG_DYP + (32 * wave + 16 * (g & 1) + 4 * p) * 2;
+    // A operand (N = ci): halo pixel of k plus the tap shift; ci = 16 (g & 1) + 4 p ...
+    const int a_pix = (TW == 16) ? 8 * (g >> 1) + q : (g >> 1) * HW_ + q;
+    const char* const a_lane = s_a + a_pix * WG_AP + (16 * (g & 1) + 4 * p) * 2;
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int n = t / TPI, slot = t - n * TPI;
+        const int row0 = (slot / TCOLS) * TH, col0 = (slot % TCOLS) * TW;
+        // ---- park the tiles in LDS as they lie in memory ---------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < (WG_TILE * WG_CO * 2 / 16) / WG_THREADS; ++i) {  // 4 x 16 bytes per thread
+            const int c = tid + WG_THREADS * i;
+            const int k = c >> 4, ch = c & 15;  // 16 chunks of 8 channels per pixel
+            const int y = row0 + k / TW, x = col0 + k % TW;
+            const uint4 v = *reinterpret_cast<const uint4*>(dy + ((size_t)(n * W + y) * W + x) * Cout + cob + ch * 8);
+            *reinterpret_cast<uint4*>(s_dy + k * WG_DYP + ch * 16) = v;
+        }
+        for (int c = tid; c < HALO * 4; c += WG_THREADS) {
+            const int hp = c >> 2, ch = c & 3;
+            const int y = row0 + hp / HW_ - PAD, x = col0 + hp % HW_ - PAD;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (y >= 0 && y < W && x >= 0 && x < W)
+                v = *reinterpret_cast<const uint4*>(act + ((size_t)(n * W + y) * W + x) * Cin + ci0 + ch * 8);
+            *reinterpret_cast<uint4*>(s_a + hp * WG_AP + ch * 16) = v;
+        }
+        __syncthreads();
+        // ---- 4 k-steps x taps MFMAs ----------------------------------------------------------------------------------
+#pragma unroll
+        for (int s = 0; s < WG_TILE / 16; ++s) {
+            const Frag8<__bf16> fa = tr_frag(dy_lane + (16 * s) * WG_DYP, dy_lane + (16 * s + 4) * WG_DYP);
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int ky = tap / KS, kx = tap % KS;
+                // first halo pixel of the k-step for this tap (compile-time), rows of the tile are HW_ halo pixels apart
+                const int hp0 = (TW == 16) ? (s + ky) * HW_ + kx : (2 * s + ky) * HW_ + kx;
+                const Frag8<__bf16> fb = tr_frag(a_lane + hp0 * WG_AP, a_lane + (hp0 + 4) * WG_AP);
+                mma16(acc[tap], fa, fb);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- partial[split][co][ci][tap]: lane holds column ci = lane & 31, rows co = acc_row(i, lane >> 5) ------------------
+    float* dst = partial + (size_t)split * Cout * Cin * TAPS;
+    const int ci = ci0 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int co = cob + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
+            dst[((size_t)co * Cin + ci) * TAPS + tap] = acc[tap][i];
+        }
+}
+
+// dW (+)= sum over splits, fixed order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, size_t n,
+                                                           int splits, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = accumulate ? dw[i] : 0.f;
+    for (int k = 0; k < splits; ++k) s += partial[(size_t)k * n + i];
+    dw[i] = s;
+}
+
+int tiles_per_image(int res) { return res >= 16 ? (res / 4) * (res / 16) : 1; }
+
+}  // namespace
+
+int conv_wgrad_splits(int B, int res, int cin, int cout) {
+    const int blocks = (cin / WG_CI) * (cout / WG_CO);
+    const int ntiles = B * tiles_per_image(res);
+    int splits = (512 + blocks - 1) / blocks;  // about two workgroups per CU
+    if (splits > ntiles) splits = ntiles;
+    if (splits < 1) splits = 1;
+    return splits;
+}
+
+size_t conv_wgrad_workspace_bytes(int B, int res, int cin, int cout, int ks) {
+    return (size_t)conv_wgrad_splits(B, res, cin, cout) * cout * cin * ks * ks * sizeof(float);
+}
+
+int conv_wgrad_supported(int res, int cin, int cout, int ks) {
+    return (res == 8 || res == 16 || res == 32) && cin > 0 && cin % WG_CI == 0 && cout > 0 && cout % WG_CO == 0 && (ks == 1 || ks == 3);
+}
+
+int launch_conv_wgrad(const void* act, const void* dy, float* dw, int B, int res, int cin, int cout, int ks, int accumulate,
+                      void* workspace, hipStream_t s) {
+    if (!conv_wgrad_supported(res, cin, cout, ks) || B <= 0) return (int)hipErrorInvalidValue;
+    const int splits = conv_wgrad_splits(B, res, cin, cout);
+    const int ntiles = B * tiles_per_image(res);
+    const int tps = (ntiles + splits - 1) / splits;
+    dim3 grid(cin / WG_CI, splits, cout / WG_CO);
+    const __bf16* a = (const __bf16*)act;
+    const __bf16* d = (const __bf16*)dy;
+    float* part = (float*)workspace;
+#define WG_LAUNCH(LW, KS) hipLaunchKernelGGL((conv_wgrad_kernel<LW, KS>), grid, dim3(WG_THREADS), 0, s, a, d, part, B, cin, cout, tps)
+    if (ks == 3) {
+        if (res == 32) WG_LAUNCH(5, 3);
+        else if (res == 16) WG_LAUNCH(4, 3);
+        else WG_LAUNCH(3, 3);
+    } else {
+        if (res == 32) WG_LAUNCH(5, 1);
+        else if (res == 16) WG_LAUNCH(4, 1);
+        else WG_LAUNCH(3, 1);
+    }
+#undef WG_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    const size_t n = (size_t)cout * cin * ks * ks;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, dw, n, splits, accumulate);
+    return (int)hipGetLastError();
+}

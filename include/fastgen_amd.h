@@ -166,6 +166,16 @@ int fg_op_latents(const float* noise, double t_init, float* out, int64_t total, 
 int fg_op_forward_process(const float* x0, const float* eps, double t, int schedule, float* out, int64_t total,
                           void* stream);
 int fg_op_x0_to_eps(const float* xt, const float* x0, double t, int schedule, float* out, int64_t total, void* stream);
+/* ---- training step, first kernel (forward-only sampling does not use it) --------------------------------
+ * Weight gradient of Conv2d.forward (EDM/network.py:93-126) as autograd computes it in the DMD2 student / fake-score
+ * updates: dw[co][ci][ky][kx] (+)= sum_{n,y,x} dy[n,y,x,co] * act[n,y+ky-ks/2,x+kx-ks/2,ci], zero padding.
+ * act [B,res,res,cin] and dy [B,res,res,cout] are NHWC bf16 (the conv's input operand and its output gradient),
+ * dw is fp32 OIHW [cout,cin,ks,ks]; accumulate != 0 adds to dw.  Deterministic (fixed-order split-K reduction through
+ * the workspace).  res in {8,16,32}, cin % 32 == 0, cout % 128 == 0, ks in {1,3}. */
+size_t fg_op_conv_wgrad_workspace_bytes(int batch, int res, int cin, int cout, int ks);
+int fg_op_conv_wgrad(const void* act, const void* dy, float* dw, int batch, int res, int cin, int cout, int ks,
+                     int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Samples to image bytes, the step after generator_fn in the reference's sample writer
  * (scripts/fid/compute_fid_from_ckpts.py:199): out[n,y,x,c] = uint8(clip(images[n,c,y,x] * 127.5 + 128, 0, 255)),
  * fp32 multiply then add, truncation; NaN -> 0.  images NCHW fp32, out NHWC bytes. */

@@ -502,3 +502,15 @@ def images_to_uint8(images: torch.Tensor) -> torch.Tensor:
     v = images.to(torch.float32) * 127.5 + 128
     return v.clip(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
 
+
+def conv_weight_grad(act: torch.Tensor, dy: torch.Tensor, ks: int) -> torch.Tensor:
+    """Gradient of `Conv2d.forward` (EDM/network.py:93-126: F.conv2d(x, w, padding=ks // 2), no resampling) with respect
+    to its weight, as autograd computes it in a training step.  act [B, Cin, H, W] (the conv's input operand), dy
+    [B, Cout, H, W] (gradient of its output) -> [Cout, Cin, ks, ks]; fp32."""
+    act = act.to(torch.float32)
+    dy = dy.to(torch.float32)
+    w = torch.zeros(dy.shape[1], act.shape[1], ks, ks, dtype=torch.float32, requires_grad=True)
+    with torch.enable_grad():
+        torch.nn.functional.conv2d(act, w, padding=ks // 2).backward(dy)
+    return w.grad.detach()
+

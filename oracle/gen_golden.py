@@ -12,6 +12,7 @@ Usage:  python oracle/gen_golden.py            (writes tests/golden/*.pt)
         python oracle/gen_golden.py meanflow   (only the MeanFlow / rectified-flow fixtures)
         python oracle/gen_golden.py sample     (only the teacher Euler-sampler fixture)
         python oracle/gen_golden.py train_schedule   (only the training-side schedule helpers)
+        python oracle/gen_golden.py backward   (only the training-step fixtures: conv weight gradients)
 """
 import os
 import sys
@@ -177,10 +178,33 @@ def train_schedule_fixture(ns):
     torch.save(fx, os.path.join(OUT, "schedule_train.pt"))
 
 
+def backward_fixture(edm_net):
+    """Training-step pieces, recorded from the reference's own modules under autograd: the weight gradient
+    of `Conv2d` (EDM/network.py:54-126) for a 3x3 and a 1x1 kernel."""
+    fx = {}
+    for ks, cin, cout, res in ((3, 64, 128, 16), (1, 32, 128, 8)):
+        conv = edm_net.Conv2d(in_channels=cin, out_channels=cout, kernel=ks)
+        with torch.no_grad():
+            conv.weight.copy_(seeded(tuple(conv.weight.shape), 51 + ks) * 0.05)
+            conv.bias.copy_(seeded(tuple(conv.bias.shape), 52 + ks) * 0.1)
+        x = seeded((2, cin, res, res), 53 + ks).requires_grad_(True)
+        dy = seeded((2, cout, res, res), 54 + ks)
+        conv(x).backward(dy)
+        fx[f"k{ks}/weight_grad"] = conv.weight.grad.clone()
+        fx[f"k{ks}/bias_grad"] = conv.bias.grad.clone()
+        fx[f"k{ks}/input_grad"] = x.grad.clone()
+        fx[f"k{ks}/shape"] = torch.tensor([2, cin, cout, res, ks])
+    torch.save(fx, os.path.join(OUT, "backward_conv.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     edm_net, ns, model = _ref_import.import_reference()
     torch.manual_seed(0)
+    if sys.argv[1:] == ["backward"]:
+        backward_fixture(edm_net)
+        print("backward fixtures written to", OUT)
+        return
     if sys.argv[1:] == ["train_schedule"]:
         train_schedule_fixture(ns)
         print("training-side schedule fixture written to", OUT)
@@ -316,6 +340,7 @@ def main():
 
     meanflow_fixtures(edm_net, ns)
     train_schedule_fixture(ns)
+    backward_fixture(edm_net)
     teacher_sample_fixture(edm_net)
 
     print("golden fixtures written to", OUT)

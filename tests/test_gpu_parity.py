@@ -532,3 +532,72 @@ def test_generic_conv_kernel_path():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
                         "(blocks_against or forward_against) and bf16"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ---- training step, first kernel: conv weight gradient ---------------------------------------------------
+def _wgrad(act_nchw, dy_nchw, ks, accumulate_into=None):
+    """fg_op_conv_wgrad on NHWC bf16 copies of the operands; returns dW [Cout, Cin, ks, ks] fp32 (CPU)."""
+    L = _lib.lib()
+    B, cin, res, _ = act_nchw.shape
+    cout = dy_nchw.shape[1]
+    a = act_nchw.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    d = dy_nchw.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    dw = (torch.zeros(cout, cin, ks, ks) if accumulate_into is None else accumulate_into.clone()).float().cuda()
+    nbytes = L.fg_op_conv_wgrad_workspace_bytes(B, res, cin, cout, ks)
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    _lib.check(L.fg_op_conv_wgrad(a.data_ptr(), d.data_ptr(), dw.data_ptr(), B, res, cin, cout, ks,
+                                  0 if accumulate_into is None else 1, ws.data_ptr(), nbytes, None))
+    torch.cuda.synchronize()
+    return dw.cpu()
+
+
+@pytest.mark.parametrize("B,res,cin,cout,ks", [(3, 32, 64, 128, 3), (2, 16, 96, 256, 3), (5, 8, 32, 128, 3), (1, 8, 64, 256, 3),
+                                               (3, 32, 32, 256, 1), (2, 16, 64, 128, 1), (4, 8, 96, 128, 1)])
+def test_conv_wgrad_against_oracle(B, res, cin, cout, ks):
+    """Weight gradient on the matrix cores (bf16 operands, fp32 accumulation) vs autograd on the same bf16-rounded operands
+    in fp32: only the summation order differs — max |err| <= 2e-5 of the largest entry."""
+    g = torch.Generator().manual_seed(res * 1000 + cin + ks)
+    act = torch.randn((B, cin, res, res), generator=g).to(torch.bfloat16).float()
+    dy = torch.randn((B, cout, res, res), generator=g).to(torch.bfloat16).float()
+    want = R.conv_weight_grad(act, dy, ks)
+    got = _wgrad(act, dy, ks)
+    assert got.shape == want.shape
+    assert (got - want).abs().max() <= 2e-5 * want.abs().max(), float((got - want).abs().max() / want.abs().max())
+    # deterministic, and accumulate adds to what is there
+    assert torch.equal(got, _wgrad(act, dy, ks))
+    base = torch.randn(want.shape, generator=g)
+    acc = _wgrad(act, dy, ks, accumulate_into=base)
+    assert (acc - (base + got)).abs().max() <= 1e-5 * want.abs().max()
+
+
+def test_conv_wgrad_reference_golden_and_full_size(golden_dir):
+    """(1) The reference's own Conv2d weight gradient (tests/golden/backward_conv.pt): fp32 operands are rounded to bf16 on
+    the way in, so the tolerance is bf16's (relative L2 <= 1e-2).  (2) Training-size batch, 256 -> 256 at 32x32: additive
+    over a batch split (size-independent property) and equal to the oracle on a slice of output channels."""
+    fx = torch.load(os.path.join(golden_dir, "backward_conv.pt"), weights_only=True)
+    for ks in (3, 1):
+        B, cin, cout, res, _ = fx[f"k{ks}/shape"].tolist()
+        x = torch.randn((B, cin, res, res), generator=torch.Generator().manual_seed(53 + ks))
+        dy = torch.randn((B, cout, res, res), generator=torch.Generator().manual_seed(54 + ks))
+        got, want = _wgrad(x, dy, ks), fx[f"k{ks}/weight_grad"]
+        assert ((got - want).norm() / want.norm()) <= 1e-2
+    g = torch.Generator().manual_seed(99)
+    B = 64
+    act = torch.randn((B, 256, 32, 32), generator=g).to(torch.bfloat16).float()
+    dy = torch.randn((B, 256, 32, 32), generator=g).to(torch.bfloat16).float()
+    full = _wgrad(act, dy, 3)
+    halves = _wgrad(act[: B // 2], dy[: B // 2], 3) + _wgrad(act[B // 2:], dy[B // 2:], 3)
+    assert (full - halves).abs().max() <= 2e-5 * full.abs().max()
+    want = R.conv_weight_grad(act[:, :32], dy[:, :8], 3)  # [8, 32, 3, 3] corner of the full gradient
+    assert (full[:8, :32] - want).abs().max() <= 2e-5 * full.abs().max()
+
+
+def test_conv_wgrad_rejects_bad_arguments():
+    L = _lib.lib()
+    assert L.fg_op_conv_wgrad_workspace_bytes(2, 32, 48, 128, 3) == 0  # cin % 32
+    x = torch.zeros(16, device="cuda")
+    with pytest.raises(_lib.FastGenAMDError):
+        _lib.check(L.fg_op_conv_wgrad(x.data_ptr(), x.data_ptr(), x.data_ptr(), 2, 32, 64, 100, 3, 0, x.data_ptr(), 64, None))
+    with pytest.raises(_lib.FastGenAMDError):  # workspace too small
+        _lib.check(L.fg_op_conv_wgrad(x.data_ptr(), x.data_ptr(), x.data_ptr(), 2, 32, 64, 128, 3, 0, x.data_ptr(), 64, None))

@@ -221,3 +221,20 @@ def test_images_to_uint8_known_answers():
     # layout: channel is innermost in the output
     y = torch.stack([torch.full((2, 2), -1.0), torch.zeros(2, 2), torch.ones(2, 2)]).unsqueeze(0)
     assert R.images_to_uint8(y)[0, 1, 1].tolist() == [0, 128, 255]
+
+
+def test_conv_weight_grad_matches_reference_autograd(golden_dir):
+    """oracle.conv_weight_grad against the weight gradients recorded from the reference's Conv2d under autograd
+    (oracle/gen_golden.py backward): same seeded operands, fp32."""
+    fx = torch.load(os.path.join(golden_dir, "backward_conv.pt"), weights_only=True)
+    for ks in (3, 1):
+        B, cin, cout, res, k = fx[f"k{ks}/shape"].tolist()
+        assert k == ks
+        x = torch.randn((B, cin, res, res), generator=torch.Generator().manual_seed(53 + ks))
+        dy = torch.randn((B, cout, res, res), generator=torch.Generator().manual_seed(54 + ks))
+        got = R.conv_weight_grad(x, dy, ks)
+        want = fx[f"k{ks}/weight_grad"]
+        assert got.shape == want.shape
+        assert (got - want).abs().max() <= 1e-4 * want.abs().max()
+        # the bias gradient is the plain sum of dy over batch and pixels
+        assert torch.allclose(dy.sum((0, 2, 3)), fx[f"k{ks}/bias_grad"], rtol=1e-5, atol=1e-4)
