@@ -1,0 +1,326 @@
+// Elementwise / reduction kernels of the U-Net block backward pass (the DMD2 training step differentiates
+// `UNetBlock.forward`, fastgen/networks/EDM/network.py:274-299, by autograd; these are its hand-written pieces).
+// Activations and activation gradients are NHWC bf16 (the training compute dtype), statistics and parameter gradients fp32.
+//
+// GroupNorm + SiLU, forward:  y = a x + b  with a = rstd*gamma, b = beta - mean*rstd*gamma  (per image and channel),
+//                             act = silu(y)                                              (EDM/network.py:141-149, 276, 283)
+// backward, given dact:       dy = dact * silu'(y),  silu'(y) = s (1 + y (1 - s)),  s = sigmoid(y)
+//                             P1[n,c] = sum_p dy,  P2[n,c] = sum_p dy * xhat,        xhat = (x - mean) rstd
+//                             dgamma[c] += sum_n P2,  dbeta[c] += sum_n P1
+//                             S1[n,g] = sum_{c in g} gamma_c P1,  S2[n,g] = sum_{c in g} gamma_c P2
+//                             dx = a dy - rstd (S1 + xhat S2) / m,                   m = (C / groups) * H * W
+// which is torch's native_group_norm_backward followed by silu_backward, evaluated in fp32.
+#include "common.h"
+#include "misc.h"
+
+namespace {
+
+__device__ __forceinline__ float silu_fwd(float y) { return y / (1.0f + expf(-y)); }
+__device__ __forceinline__ float silu_grad(float y) {
+    const float s = 1.0f / (1.0f + expf(-y));
+    return s * fmaf(y, 1.0f - s, 1.0f);
+}
+
+__device__ __forceinline__ void load8bf(const __bf16* p, float (&v)[8]) {
+    const bf16x8 q = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)q[j];
+}
+__device__ __forceinline__ void store8bf(__bf16* p, const float (&v)[8]) {
+    bf16x8 q;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = (__bf16)v[j];
+    *reinterpret_cast<bf16x8*>(p) = q;
+}
+
+// element pointer of channel octet c0 of pixel `pix` in the virtual concat [x1 | x2]
+__device__ __forceinline__ const __bf16* cat_ptr(const __bf16* x1, int C1, const __bf16* x2, int C2, size_t pix, int c0) {
+    return (c0 < C1) ? x1 + pix * C1 + c0 : x2 + pix * C2 + (c0 - C1);
+}
+
+// ---- act = silu(a x + b) (MODE 0), a x + b (MODE 1) or x (MODE 2, ab unused): the conv operand, over the virtual concat, that
+// the weight-gradient kernel contracts with -----------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_act_kernel(const __bf16* __restrict__ x1, int C1, const __bf16* __restrict__ x2, int C2,
+                                                     const float2* __restrict__ ab, __bf16* __restrict__ out, int64_t total_oct,
+                                                     int HW) {
+    const int C = C1 + C2, OC = C >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_oct; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(i % OC) * 8;
+        const size_t pix = (size_t)(i / OC);
+        const int n = (int)(pix / HW);
+        float v[8];
+        load8bf(cat_ptr(x1, C1, x2, C2, pix, c0), v);
+        const float2* abp = MODE == 2 ? nullptr : ab + (size_t)n * C + c0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (MODE == 2) continue;  // plain copy of the concat
+            const float y = fmaf(v[j], abp[j].x, abp[j].y);
+            v[j] = MODE == 0 ? silu_fwd(y) : y;
+        }
+        store8bf(out + pix * C + c0, v);
+    }
+}
+
+// ---- P1, P2: one workgroup per (64 channels, image); 8 octets x 32 pixel lanes ------------------------------------------------
+// x (concat) NHWC, dact [B,HW,Cd] with this tensor's channels at [0, C); MODE as above.  P[n][c] = {P1, P2}.
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const __bf16* __restrict__ x1, int C1, const __bf16* __restrict__ x2,
+                                                            int C2, const __bf16* __restrict__ dact, int Cd,
+                                                            const float2* __restrict__ ab, const float2* __restrict__ mr,
+                                                            float2* __restrict__ P, int HW) {
+    const int C = C1 + C2;
+    const int groups = min(32, C / 4), cpg = C / groups;
+    const int n = blockIdx.y, oct = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int c0 = blockIdx.x * 64 + oct * 8;
+    __shared__ float s1[32][65], s2[32][65];
+    float p1[8], p2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p1[j] = p2[j] = 0.f;
+    if (c0 < C) {
+        float a[8], b[8], mean[8], rstd[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float2 t = ab[(size_t)n * C + c0 + j];
+            const float2 m = mr[(size_t)n * groups + (c0 + j) / cpg];
+            a[j] = t.x, b[j] = t.y, mean[j] = m.x, rstd[j] = m.y;
+        }
+        for (int p = pl; p < HW; p += 32) {
+            const size_t pix = (size_t)n * HW + p;
+            float xv[8], dv[8];
+            load8bf(cat_ptr(x1, C1, x2, C2, pix, c0), xv);
+            load8bf(dact + pix * Cd + c0, dv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dy = MODE == 0 ? dv[j] * silu_grad(fmaf(xv[j], a[j], b[j])) : dv[j];
+                p1[j] += dy;
+                p2[j] = fmaf(dy, (xv[j] - mean[j]) * rstd[j], p2[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[pl][oct * 8 + j] = p1[j], s2[pl][oct * 8 + j] = p2[j];
+    __syncthreads();
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < C) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int r = 0; r < 32; ++r) a1 += s1[r][threadIdx.x], a2 += s2[r][threadIdx.x];
+        P[(size_t)n * C + blockIdx.x * 64 + threadIdx.x] = make_float2(a1, a2);
+    }
+}
+
+// ---- S[n][g] = {S1, S2}; one workgroup per image -------------------------------------------------------------------------
+__global__ void gn_bwd_group_kernel(const float2* __restrict__ P, const float* __restrict__ gamma, float2* __restrict__ S, int C) {
+    const int groups = min(32, C / 4), cpg = C / groups;
+    const int n = blockIdx.x, g = threadIdx.x;
+    if (g >= groups) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        const float2 p = P[(size_t)n * C + c];
+        s1 = fmaf(gamma[c], p.x, s1);
+        s2 = fmaf(gamma[c], p.y, s2);
+    }
+    S[(size_t)n * groups + g] = make_float2(s1, s2);
+}
+
+// ---- dgamma[c] += sum_n P2, dbeta[c] += sum_n P1 (fixed order) ---------------------------------------------------------------
+__global__ void gn_bwd_param_kernel(const float2* __restrict__ P, float* __restrict__ dgamma, float* __restrict__ dbeta, int B,
+                                    int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float g = 0.f, b = 0.f;
+    for (int n = 0; n < B; ++n) {
+        const float2 p = P[(size_t)n * C + c];
+        b += p.x;
+        g += p.y;
+    }
+    if (dgamma) dgamma[c] += g;
+    if (dbeta) dbeta[c] += b;
+}
+
+// ---- dx = a dy - rstd (S1 + xhat S2) / m  [+ add_scale * add]; dx is [B,HW,C] over the whole concat ---------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const __bf16* __restrict__ x1, int C1, const __bf16* __restrict__ x2,
+                                                           int C2, const __bf16* __restrict__ dact, int Cd,
+                                                           const float2* __restrict__ ab, const float2* __restrict__ mr,
+                                                           const float2* __restrict__ S, const __bf16* __restrict__ add, int Ca,
+                                                           float add_scale, __bf16* __restrict__ dx, int64_t total_oct, int HW) {
+    const int C = C1 + C2, OC = C >> 3;
+    const int groups = min(32, C / 4), cpg = C / groups;
+    const float inv_m = 1.0f / ((float)cpg * (float)HW);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_oct; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(i % OC) * 8;
+        const size_t pix = (size_t)(i / OC);
+        const int n = (int)(pix / HW);
+        float xv[8], dv[8], av[8];
+        load8bf(cat_ptr(x1, C1, x2, C2, pix, c0), xv);
+        load8bf(dact + pix * Cd + c0, dv);
+        if (add) load8bf(add + pix * Ca + c0, av);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j, g = c / cpg;
+            const float2 t = ab[(size_t)n * C + c];
+            const float2 m = mr[(size_t)n * groups + g];
+            const float2 s = S[(size_t)n * groups + g];
+            const float dy = MODE == 0 ? dv[j] * silu_grad(fmaf(xv[j], t.x, t.y)) : dv[j];
+            const float xhat = (xv[j] - m.x) * m.y;
+            float r = fmaf(t.x, dy, -m.y * fmaf(xhat, s.y, s.x) * inv_m);
+            if (add) r = fmaf(add_scale, av[j], r);
+            o[j] = r;
+        }
+        store8bf(dx + pix * C + c0, o);
+    }
+}
+
+// ---- out[n][c] (+)= scale * sum_p t[n,p,c]: bias and embedding-affine gradients -------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ t, int Ct, int C, float* __restrict__ out, int HW,
+                                                     float scale) {
+    const int n = blockIdx.y, oct = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int c0 = blockIdx.x * 64 + oct * 8;
+    __shared__ float s1[32][65];
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (c0 < C)
+        for (int p = pl; p < HW; p += 32) {
+            float v[8];
+            load8bf(t + ((size_t)n * HW + p) * Ct + c0, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += v[j];
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[pl][oct * 8 + j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < C) {
+        float a = 0.f;
+        for (int r = 0; r < 32; ++r) a += s1[r][threadIdx.x];
+        out[(size_t)n * C + blockIdx.x * 64 + threadIdx.x] = a * scale;
+    }
+}
+
+// out[c] += sum_n in[n][c]
+__global__ void batchsum_add_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f;
+    for (int n = 0; n < B; ++n) a += in[(size_t)n * C + c];
+    out[c] += a;
+}
+
+// fp32 -> bf16 with a scale (gradient entering the block: dOut * skip_scale)
+__global__ void scale_to_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, float scale, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) out[i] = (__bf16)(in[i] * scale);
+}
+// bf16 [.., Cs] channels [c_off, c_off + C) -> fp32 [.., C]
+__global__ void slice_to_f32_kernel(const __bf16* __restrict__ in, int Cs, int c_off, float* __restrict__ out, int C, int64_t npix) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix * C; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = i / C;
+        const int c = (int)(i - p * C);
+        out[i] = (float)in[p * Cs + c_off + c];
+    }
+}
+
+// Embedding-affine backward (Linear `affine`, EDM/network.py:255, 278): dtemb [B, C] is the pixel sum of the gradient of
+// conv0's output.  dW[c][k] += sum_b dtemb[b][c] emb[b][k];  demb[b][k] += sum_c dtemb[b][c] W[c][k].
+__global__ void affine_wgrad_kernel(const float* __restrict__ dtemb, const float* __restrict__ emb, float* __restrict__ dw, int B,
+                                    int C, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * K) return;
+    const int c = i / K, k = i - c * K;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a = fmaf(dtemb[(size_t)b * C + c], emb[(size_t)b * K + k], a);
+    dw[i] += a;
+}
+__global__ void affine_dgrad_kernel(const float* __restrict__ dtemb, const float* __restrict__ w, float* __restrict__ demb, int B,
+                                    int C, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * K) return;
+    const int b = i / K, k = i - b * K;
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a = fmaf(dtemb[(size_t)b * C + c], w[(size_t)c * K + k], a);
+    demb[i] += a;
+}
+
+// Weights of the data-gradient convolution: the forward conv kernel run on dY with Wt[ci][co][tap] = W[co][ci][T-1-tap]
+// (rows ci >= cin are zero: output channels padded to the kernel's 256-channel granularity).
+__global__ void dgrad_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int cin, int cin_pad, int taps) {
+    const int64_t total = (int64_t)cin_pad * cout * taps;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int tap = (int)(i % taps);
+        const int co = (int)((i / taps) % cout);
+        const int ci = (int)(i / ((int64_t)taps * cout));
+        wt[i] = ci < cin ? w[((size_t)co * cin + ci) * taps + (taps - 1 - tap)] : 0.f;
+    }
+}
+
+inline unsigned ew_blocks(int64_t n) {
+    const int64_t b = (n + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
+}
+
+}  // namespace
+
+#define BWD_RET() return (int)hipGetLastError()
+
+int launch_gn_act(int mode, const void* x1, int c1, const void* x2, int c2, const float2* ab, void* out, int B, int hw, hipStream_t s) {
+    if ((c1 % 8) || (c2 % 8)) return (int)hipErrorInvalidValue;
+    const int64_t total = (int64_t)B * hw * ((c1 + c2) / 8);
+    if (mode == 0)
+        hipLaunchKernelGGL(gn_act_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, ab, (__bf16*)out, total, hw);
+    else if (mode == 2)
+        hipLaunchKernelGGL(gn_act_kernel<2>, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, ab, (__bf16*)out, total, hw);
+    else
+        hipLaunchKernelGGL(gn_act_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, ab, (__bf16*)out, total, hw);
+    BWD_RET();
+}
+
+// GroupNorm(+SiLU) backward.  P: [B][C] float2 scratch, S: [B][groups] float2 scratch.  dgamma / dbeta are accumulated.
+int launch_gn_bwd(int mode, const void* x1, int c1, const void* x2, int c2, const void* dact, int cd, const float2* ab,
+                  const float2* mr, const float* gamma, float2* P, float2* S, float* dgamma, float* dbeta, const void* add, int ca,
+                  float add_scale, void* dx, int B, int hw, hipStream_t s) {
+    const int C = c1 + c2;
+    if ((c1 % 8) || (c2 % 8) || C < 16) return (int)hipErrorInvalidValue;
+    const int groups = C / 4 < 32 ? C / 4 : 32;
+    dim3 rg((C + 63) / 64, B);
+    const __bf16 *X1 = (const __bf16*)x1, *X2 = (const __bf16*)x2, *D = (const __bf16*)dact, *A = (const __bf16*)add;
+    if (mode == 0)
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<0>, rg, dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, P, hw);
+    else
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<1>, rg, dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, P, hw);
+    hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(B), dim3(32), 0, s, P, gamma, S, C);
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, s, P, dgamma, dbeta, B, C);
+    const int64_t total = (int64_t)B * hw * (C / 8);
+    if (mode == 0)
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, S, A, ca, add_scale, (__bf16*)dx, total, hw);
+    else
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, S, A, ca, add_scale, (__bf16*)dx, total, hw);
+    (void)groups;
+    BWD_RET();
+}
+
+int launch_colsum(const void* t, int ct, int C, float* out, int B, int hw, float scale, hipStream_t s) {
+    if (C % 8) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, (const __bf16*)t, ct, C, out, hw, scale);
+    BWD_RET();
+}
+int launch_batchsum_add(const float* in, float* out, int B, int C, hipStream_t s) {
+    hipLaunchKernelGGL(batchsum_add_kernel, dim3((C + 255) / 256), dim3(256), 0, s, in, out, B, C);
+    BWD_RET();
+}
+int launch_scale_to_bf16(const float* in, void* out, float scale, int64_t total, hipStream_t s) {
+    hipLaunchKernelGGL(scale_to_bf16_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, in, (__bf16*)out, scale, total);
+    BWD_RET();
+}
+int launch_slice_to_f32(const void* in, int cs, int c_off, float* out, int C, int64_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(slice_to_f32_kernel, dim3(ew_blocks(npix * C)), dim3(256), 0, s, (const __bf16*)in, cs, c_off, out, C, npix);
+    BWD_RET();
+}
+int launch_affine_bwd(const float* dtemb, const float* emb, const float* w, float* dw, float* demb, int B, int C, int K, hipStream_t s) {
+    if (dw) hipLaunchKernelGGL(affine_wgrad_kernel, dim3((C * K + 255) / 256), dim3(256), 0, s, dtemb, emb, dw, B, C, K);
+    if (demb) hipLaunchKernelGGL(affine_dgrad_kernel, dim3((B * K + 255) / 256), dim3(256), 0, s, dtemb, w, demb, B, C, K);
+    BWD_RET();
+}
+int launch_dgrad_weights(const float* w, float* wt, int cout, int cin, int cin_pad, int taps, hipStream_t s) {
+    hipLaunchKernelGGL(dgrad_weights_kernel, dim3(ew_blocks((int64_t)cin_pad * cout * taps)), dim3(256), 0, s, w, wt, cout, cin, cin_pad, taps);
+    BWD_RET();
+}

@@ -39,6 +39,7 @@ struct Param {
     int64_t shape[4] = {1, 1, 1, 1};
     int64_t numel = 0;
     const float* ptr = nullptr;  // borrowed device pointer (fp32, reference layout)
+    float* grad = nullptr;       // borrowed fp32 gradient accumulator (fg_edm_bind_grad), nullptr = not requested
 };
 
 enum Kind { K_STEM, K_BLOCK, K_AUX_NORM, K_AUX_CONV };
@@ -90,6 +91,7 @@ struct Act {
 struct Workspace {
     float *coef, *emb0, *emb1, *emb, *temb;
     float2 *ab0, *ab1, *ab2;
+    float2 *mr0 = nullptr, *mr1 = nullptr;  // {mean, rstd} of norm0 / norm1, kept when a backward pass follows
     std::vector<Act> skip;  // encoder outputs
     Act xa, xb, h, xattn;
     void *sbuf, *aout, *pool;
@@ -171,6 +173,7 @@ struct fg_edm {
         return (int)params.size() - 1;
     }
     const float* P(int idx) const { return idx >= 0 ? params[idx].ptr : nullptr; }
+    float* G(int idx) const { return idx >= 0 ? params[idx].grad : nullptr; }
 };
 
 namespace {
@@ -409,11 +412,11 @@ const float kBlockEps = 1e-6f;                   // block_kwargs.eps :386, aux_n
 // GroupNorm coefficients of the virtual concat [x1 | x2]: from the producers' partial statistics when every source
 // has them, else one full pass over the tensor(s).
 int norm_coeffs(int dtype, const Act& x1, int c1, const Act& x2, int c2, const float* gamma, const float* beta, float2* ab,
-                int B, int hw, hipStream_t s) {
+                int B, int hw, hipStream_t s, float2* mr = nullptr) {
     if (x1.st && (!c2 || x2.st))
-        HIP_TRY(launch_gn_finalize(x1.st, c1, x1.slots, c2 ? x2.st : nullptr, c2, c2 ? x2.slots : 0, gamma, beta, kBlockEps, ab, B, hw, s));
+        HIP_TRY(launch_gn_finalize(x1.st, c1, x1.slots, c2 ? x2.st : nullptr, c2, c2 ? x2.slots : 0, gamma, beta, kBlockEps, ab, B, hw, s, mr));
     else
-        HIP_TRY(launch_gn_coeffs(dtype, x1.p, c1, c2 ? x2.p : nullptr, c2, gamma, beta, kBlockEps, ab, B, hw, s));
+        HIP_TRY(launch_gn_coeffs(dtype, x1.p, c1, c2 ? x2.p : nullptr, c2, gamma, beta, kBlockEps, ab, B, hw, s, mr));
     return FG_OK;
 }
 
@@ -426,7 +429,7 @@ int run_block(fg_edm* h, const Block& b, const Act& x1, int c1, const Act& x2, i
     const int slots = conv_stat_slots(b.res_out);
     int rc;
     // h = conv0(silu(norm0(x))) + affine(emb)
-    if ((rc = norm_coeffs(h->dtype, x1, c1, x2, c2, h->P(b.norm0_w), h->P(b.norm0_b), w.ab0, B, hw_in, s))) return rc;
+    if ((rc = norm_coeffs(h->dtype, x1, c1, x2, c2, h->P(b.norm0_w), h->P(b.norm0_b), w.ab0, B, hw_in, s, w.mr0))) return rc;
     ConvArgs a{};
     a.src1 = x1.p; a.src2 = c2 ? x2.p : nullptr; a.C1 = c1; a.C2 = c2;
     a.Hs = a.Ws = b.res_in; a.H = a.W = b.res_out; a.B = B;
@@ -453,7 +456,7 @@ int run_block(fg_edm* h, const Block& b, const Act& x1, int c1, const Act& x2, i
         resid = w.sbuf;
     }
     // x = (conv1(silu(norm1(h))) + skip) * sqrt(.5)
-    HIP_TRY(launch_gn_finalize(w.h.st, b.cout, slots, nullptr, 0, 0, h->P(b.norm1_w), h->P(b.norm1_b), kBlockEps, w.ab1, B, hw, s));
+    HIP_TRY(launch_gn_finalize(w.h.st, b.cout, slots, nullptr, 0, 0, h->P(b.norm1_w), h->P(b.norm1_b), kBlockEps, w.ab1, B, hw, s, w.mr1));
     Act& x_mid = b.attn ? w.xattn : out;
     ConvArgs d{};
     d.src1 = w.h.p; d.C1 = b.cout; d.Hs = d.Ws = d.H = d.W = b.res_out; d.B = B;
@@ -1050,6 +1053,157 @@ int fg_edm_run_block(fg_edm* h, int index, const float* x1, int c1, const float*
     int rc = run_block(h, b, a1, c1, a2, c2, w.temb, w.xa, batch, w, s);
     if (rc) return rc;
     HIP_TRY(launch_from_act(h->dtype, w.xa.p, out, (int64_t)npix_out * b.cout, s));
+    return FG_OK;
+}
+
+// ---- training step, block level -------------------------------------------------------------------------
+namespace {
+struct BwdScratch {
+    void *g1, *aop, *da, *dh0, *dskip, *dxin, *wpk, *wg;
+    float2 *P, *S, *mr0, *mr1;
+    float *dtemb, *wt;
+    size_t wg_bytes;
+};
+int pad256(int c) { return (c + 255) / 256 * 256; }
+size_t plan_block_bwd(int B, int res, int cin, int cout, Arena& A, BwdScratch& q) {
+    const size_t npix = (size_t)B * res * res;
+    const int cp = pad256(cin), cm = cin > cout ? cin : cout;
+    q.g1 = A.take(npix * cout * 2);
+    q.aop = A.take(npix * cm * 2);
+    q.da = A.take(npix * (cp > cout ? cp : cout) * 2);
+    q.dh0 = A.take(npix * cout * 2);
+    q.dskip = A.take(npix * cp * 2);
+    q.dxin = A.take(npix * cin * 2);
+    q.P = A.get<float2>((size_t)B * cm);
+    q.S = A.get<float2>((size_t)B * 32);
+    q.mr0 = A.get<float2>((size_t)B * 32);
+    q.mr1 = A.get<float2>((size_t)B * 32);
+    q.dtemb = A.get<float>((size_t)B * cout);
+    const size_t welems = (size_t)(cp > cout ? cp : cout) * (cin > cout ? cin : cout) * 9;
+    q.wt = A.get<float>(welems);
+    q.wpk = A.take(welems * 2);
+    q.wg_bytes = 0;
+    const int shapes[3][3] = {{cout, cout, 3}, {cin, cout, 3}, {cin, cout, 1}};
+    for (auto& sh : shapes)
+        if (conv_wgrad_supported(res, sh[0], sh[1], sh[2]))
+            q.wg_bytes = std::max(q.wg_bytes, conv_wgrad_workspace_bytes(B, res, sh[0], sh[1], sh[2]));
+    q.wg = A.take(q.wg_bytes);
+    return A.off;
+}
+// data gradient of a conv = the forward conv kernel on dY with transposed, flipped weights; output [npix][pad256(cin)]
+int conv_dgrad(fg_edm* h, const float* w_oihw, int cout, int cin, int ks, const void* dy, void* out, int B, int res, BwdScratch& q,
+               hipStream_t s) {
+    const int cp = pad256(cin);
+    HIP_TRY(launch_dgrad_weights(w_oihw, q.wt, cout, cin, cp, ks * ks, s));
+    HIP_TRY(launch_pack_conv_weights(1, q.wt, q.wpk, cp, cout, ks, 0, s));
+    ConvArgs a{};
+    a.src1 = dy; a.C1 = cout; a.C2 = 0;
+    a.Hs = a.Ws = a.H = a.W = res; a.B = B;
+    a.wpack = q.wpk; a.scale = 1.0f; a.out = out; a.Cout = cp;
+    HIP_TRY(launch_conv_fused(1, ks, PRO_NONE, RES_NONE, OUT_NHWC, a, s));
+    return FG_OK;
+}
+}  // namespace
+
+int fg_edm_bind_grad(fg_edm* h, const char* name, float* grad, int64_t numel) {
+    if (!h || !name) return fail(FG_EINVAL, "null argument");
+    const int i = h->find(name);
+    if (i < 0) return fail(FG_EINVAL, "unknown parameter '%s'", name);
+    if (grad && numel != h->params[i].numel) return fail(FG_EINVAL, "%s: expected %lld gradient elements, got %lld", name, (long long)h->params[i].numel, (long long)numel);
+    h->params[i].grad = grad;
+    return FG_OK;
+}
+
+size_t fg_edm_block_backward_workspace_bytes(const fg_edm* h, int index, int batch) {
+    if (!h || batch <= 0 || index < 0 || index >= (int)h->blocks.size()) return 0;
+    const Block& b = *h->blocks[index];
+    Arena A;
+    A.dry = true;
+    Workspace w;
+    plan_workspace(h, batch, A, w);
+    BwdScratch q;
+    return plan_block_bwd(batch, b.res_out, b.cin, b.cout, A, q);
+}
+
+int fg_edm_run_block_backward(fg_edm* h, int index, const float* x1, int c1, const float* x2, int c2, const float* emb,
+                              const float* dout, float* dx1, float* dx2, float* demb, int batch, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    if (!h || !x1 || !emb || !dout) return fail(FG_EINVAL, "null argument");
+    if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
+    if (!h->dtype) return fail(FG_EINVAL, "the backward pass runs in the bf16 compute mode only");
+    if (index < 0 || index >= (int)h->blocks.size()) return fail(FG_EINVAL, "block index out of range");
+    const Block& b = *h->blocks[index];
+    if (b.attn || b.up || b.down)
+        return fail(FG_EINVAL, "%s: backward of attention / resampling blocks is not implemented yet", b.key.c_str());
+    if (c1 + c2 != b.cin || (c1 % 8) || (c2 % 8)) return fail(FG_EINVAL, "%s: bad input channel split %d+%d", b.key.c_str(), c1, c2);
+    if (batch <= 0 || !workspace || (((uintptr_t)workspace) & 255)) return fail(FG_EINVAL, "bad batch / workspace");
+    const int B = batch, res = b.res_out, hw = res * res, cin = b.cin, cout = b.cout, cp = pad256(cin);
+    if (!conv_wgrad_supported(res, cout, cout, 3) || !conv_wgrad_supported(res, cin, cout, 3))
+        return fail(FG_EINVAL, "%s: shape not covered by the weight-gradient kernel", b.key.c_str());
+    Arena A;
+    A.base = (char*)workspace;
+    Workspace w;
+    plan_workspace(h, B, A, w);
+    BwdScratch q;
+    const size_t need = plan_block_bwd(B, res, cin, cout, A, q);
+    if (need > workspace_bytes) return fail(FG_ENOMEM, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t npix = (size_t)B * hw;
+    // ---- forward of the block, keeping what the backward pass reads (inputs, conv0 output, both norms' coefficients) ----
+    HIP_TRY(launch_linear(emb, h->aff_w, h->aff_b, w.temb, B, h->emb_ch, h->temb_total, 0, s));
+    Act a1, a2;
+    HIP_TRY(launch_to_act(1, x1, w.cvt1, (int64_t)npix * c1, s));
+    a1.p = w.cvt1;
+    if (c2) {
+        HIP_TRY(launch_to_act(1, x2, w.cvt2, (int64_t)npix * c2, s));
+        a2.p = w.cvt2;
+    }
+    w.mr0 = q.mr0;
+    w.mr1 = q.mr1;
+    int rc = run_block(h, b, a1, c1, a2, c2, w.temb, w.xa, B, w, s);
+    if (rc) return rc;
+    // ---- backward -----------------------------------------------------------------------------------------------------
+    // out = (conv1(a1) + skip) * sigma  =>  g1 = sigma * dout reaches conv1's output and the skip path alike
+    HIP_TRY(launch_scale_to_bf16(dout, q.g1, kSkipScale, (int64_t)npix * cout, s));
+    HIP_TRY(launch_colsum(q.g1, cout, cout, q.dtemb, B, hw, 1.0f, s));
+    if (h->G(b.conv1_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.conv1_b), B, cout, s));
+    if (b.has_skip && h->G(b.skip_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.skip_b), B, cout, s));
+    // conv1
+    if (h->G(b.conv1_w)) {
+        HIP_TRY(launch_gn_act(0, w.h.p, cout, nullptr, 0, w.ab1, q.aop, B, hw, s));
+        HIP_TRY(launch_conv_wgrad(q.aop, q.g1, h->G(b.conv1_w), B, res, cout, cout, 3, 1, q.wg, s));
+    }
+    if ((rc = conv_dgrad(h, h->P(b.conv1_w), cout, cout, 3, q.g1, q.da, B, res, q, s))) return rc;
+    // norm1 + silu
+    HIP_TRY(launch_gn_bwd(0, w.h.p, cout, nullptr, 0, q.da, pad256(cout), w.ab1, q.mr1, h->P(b.norm1_w), q.P, q.S, h->G(b.norm1_w),
+                          h->G(b.norm1_b), nullptr, 0, 0.f, q.dh0, B, hw, s));
+    // bias of conv0 and the embedding affine see the pixel sum of dh0
+    HIP_TRY(launch_colsum(q.dh0, cout, cout, q.dtemb, B, hw, 1.0f, s));
+    if (h->G(b.conv0_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.conv0_b), B, cout, s));
+    if (h->G(b.aff_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.aff_b), B, cout, s));
+    HIP_TRY(launch_affine_bwd(q.dtemb, emb, h->P(b.aff_w), h->G(b.aff_w), demb, B, cout, h->emb_ch, s));
+    // conv0
+    if (h->G(b.conv0_w)) {
+        HIP_TRY(launch_gn_act(0, a1.p, c1, a2.p, c2, w.ab0, q.aop, B, hw, s));
+        HIP_TRY(launch_conv_wgrad(q.aop, q.dh0, h->G(b.conv0_w), B, res, cin, cout, 3, 1, q.wg, s));
+    }
+    if ((rc = conv_dgrad(h, h->P(b.conv0_w), cout, cin, 3, q.dh0, q.da, B, res, q, s))) return rc;
+    // skip path: its gradient joins dx_in inside the norm0 backward pass
+    const void* add = q.g1;
+    int ca = cout;
+    if (b.has_skip) {
+        if (h->G(b.skip_w)) {
+            HIP_TRY(launch_gn_act(2, a1.p, c1, a2.p, c2, nullptr, q.aop, B, hw, s));
+            HIP_TRY(launch_conv_wgrad(q.aop, q.g1, h->G(b.skip_w), B, res, cin, cout, 1, 1, q.wg, s));
+        }
+        if ((rc = conv_dgrad(h, h->P(b.skip_w), cout, cin, 1, q.g1, q.dskip, B, res, q, s))) return rc;
+        add = q.dskip;
+        ca = cp;
+    }
+    HIP_TRY(launch_gn_bwd(0, a1.p, c1, a2.p, c2, q.da, cp, w.ab0, q.mr0, h->P(b.norm0_w), q.P, q.S, h->G(b.norm0_w), h->G(b.norm0_b),
+                          add, ca, 1.0f, q.dxin, B, hw, s));
+    if (dx1) HIP_TRY(launch_slice_to_f32(q.dxin, cin, 0, dx1, c1, (int64_t)npix, s));
+    if (dx2 && c2) HIP_TRY(launch_slice_to_f32(q.dxin, cin, c1, dx2, c2, (int64_t)npix, s));
     return FG_OK;
 }
 

@@ -5,9 +5,9 @@
 
 // dtype (0 fp32 / 1 bf16) is the storage type of activation tensors passed as void*
 int launch_gn_coeffs(int dtype, const void* x1, int c1, const void* x2, int c2, const float* gamma, const float* beta,
-                     float eps, float2* ab, int batch, int hw, hipStream_t s);
+                     float eps, float2* ab, int batch, int hw, hipStream_t s, float2* mr = nullptr);  // mr[b][group] = {mean, rstd}
 int launch_gn_finalize(const float2* st1, int c1, int s1, const float2* st2, int c2, int s2, const float* gamma,
-                       const float* beta, float eps, float2* ab, int batch, int hw, hipStream_t s);
+                       const float* beta, float eps, float2* ab, int batch, int hw, hipStream_t s, float2* mr = nullptr);
 int launch_precond_coef(const double* t, int t_stride, const double* r, int r_stride, double sigma_data,
                         double sigma_shift, double clamp_min, int drop, float* coef, int B, hipStream_t s);
 int launch_mapping_in(const float* c_noise, const float* r_noise, const float* freqs, const float* labels, int label_dim,
@@ -30,6 +30,17 @@ int launch_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, cons
 int launch_gn_silu_pool(int dtype, const void* x, const float2* ab, void* out, int B, int H, int W, int C, hipStream_t s);
 int launch_to_act(int dtype, const float* in, void* out, int64_t total, hipStream_t s);
 int launch_from_act(int dtype, const void* in, float* out, int64_t total, hipStream_t s);
+// bwd.hip: elementwise / reduction pieces of the block backward pass (bf16 activations)
+int launch_gn_act(int mode, const void* x1, int c1, const void* x2, int c2, const float2* ab, void* out, int B, int hw, hipStream_t s);
+int launch_gn_bwd(int mode, const void* x1, int c1, const void* x2, int c2, const void* dact, int cd, const float2* ab,
+                  const float2* mr, const float* gamma, float2* P, float2* S, float* dgamma, float* dbeta, const void* add, int ca,
+                  float add_scale, void* dx, int B, int hw, hipStream_t s);
+int launch_colsum(const void* t, int ct, int C, float* out, int B, int hw, float scale, hipStream_t s);
+int launch_batchsum_add(const float* in, float* out, int B, int C, hipStream_t s);
+int launch_scale_to_bf16(const float* in, void* out, float scale, int64_t total, hipStream_t s);
+int launch_slice_to_f32(const void* in, int cs, int c_off, float* out, int C, int64_t npix, hipStream_t s);
+int launch_affine_bwd(const float* dtemb, const float* emb, const float* w, float* dw, float* demb, int B, int C, int K, hipStream_t s);
+int launch_dgrad_weights(const float* w, float* wt, int cout, int cin, int cin_pad, int taps, hipStream_t s);
 // wgrad.hip: weight gradient of a 3x3 / 1x1 convolution (training step)
 int conv_wgrad_supported(int res, int cin, int cout, int ks);
 size_t conv_wgrad_workspace_bytes(int B, int res, int cin, int cout, int ks);

@@ -15,7 +15,7 @@ template <typename AT>
 __global__ __launch_bounds__(512) void gn_coeffs_kernel(const AT* __restrict__ x1, int C1, const AT* __restrict__ x2,
                                                         int C2, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, float2* __restrict__ ab,
-                                                        int hw) {
+                                                        int hw, float2* __restrict__ mr) {
     const int C = C1 + C2;
     const int Q = C >> 2;                 // channel quads per pixel
     const int lanes = blockDim.x / Q;     // pixel lanes
@@ -56,6 +56,7 @@ __global__ __launch_bounds__(512) void gn_coeffs_kernel(const AT* __restrict__ x
         if (var < 0.0) var = 0.0;
         s_mean[t] = (float)mean;
         s_rstd[t] = (float)(1.0 / sqrt(var + (double)eps));
+        if (mr) mr[(size_t)n * groups + t] = make_float2(s_mean[t], s_rstd[t]);  // kept for the backward pass
     }
     __syncthreads();
     for (int c = t; c < C; c += blockDim.x) {
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(512) void gn_coeffs_kernel(const AT* __restrict__ x
 // fp64 in a fixed order (deterministic).
 __global__ void gn_finalize_kernel(const float2* __restrict__ st1, int C1, int S1, const float2* __restrict__ st2, int C2,
                                    int S2, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                   float2* __restrict__ ab, int hw) {
+                                   float2* __restrict__ ab, int hw, float2* __restrict__ mr) {
     const int C = C1 + C2;
     const int groups = min(32, C / 4);
     const int cpg = C / groups;
@@ -98,6 +99,7 @@ __global__ void gn_finalize_kernel(const float2* __restrict__ st1, int C1, int S
         const float m = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
         const float a = rstd * gamma[c];
         ab[(size_t)n * C + c] = make_float2(a, fmaf(-a, m, beta[c]));
+        if (mr && c % cpg == 0) mr[(size_t)n * groups + g] = make_float2(m, rstd);  // kept for the backward pass
     }
 }
 
@@ -510,7 +512,7 @@ inline int ew_grid(int64_t total) {
 #define RET_LAST() return (int)hipGetLastError()
 
 int launch_gn_coeffs(int dtype, const void* x1, int c1, const void* x2, int c2, const float* gamma, const float* beta,
-                     float eps, float2* ab, int batch, int hw, hipStream_t s) {
+                     float eps, float2* ab, int batch, int hw, hipStream_t s, float2* mr) {
     const int C = c1 + c2;
     if (C % 4 || (c1 % 4) || C < 16 || C > 2048) return (int)hipErrorInvalidValue;
     const int groups = C / 4 < 32 ? C / 4 : 32;
@@ -519,20 +521,20 @@ int launch_gn_coeffs(int dtype, const void* x1, int c1, const void* x2, int c2, 
     if (Q > 512) return (int)hipErrorInvalidValue;
     const int threads = (512 / Q) * Q;
     if (dtype)
-        hipLaunchKernelGGL(gn_coeffs_kernel<__bf16>, dim3(batch), dim3(threads), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, gamma, beta, eps, ab, hw);
+        hipLaunchKernelGGL(gn_coeffs_kernel<__bf16>, dim3(batch), dim3(threads), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, gamma, beta, eps, ab, hw, mr);
     else
-        hipLaunchKernelGGL(gn_coeffs_kernel<float>, dim3(batch), dim3(threads), 0, s, (const float*)x1, c1, (const float*)x2, c2, gamma, beta, eps, ab, hw);
+        hipLaunchKernelGGL(gn_coeffs_kernel<float>, dim3(batch), dim3(threads), 0, s, (const float*)x1, c1, (const float*)x2, c2, gamma, beta, eps, ab, hw, mr);
     RET_LAST();
 }
 
 int launch_gn_finalize(const float2* st1, int c1, int s1, const float2* st2, int c2, int s2, const float* gamma,
-                       const float* beta, float eps, float2* ab, int batch, int hw, hipStream_t s) {
+                       const float* beta, float eps, float2* ab, int batch, int hw, hipStream_t s, float2* mr) {
     const int C = c1 + c2;
     if (C % 4 || (c1 % 4) || C < 16) return (int)hipErrorInvalidValue;
     const int groups = C / 4 < 32 ? C / 4 : 32;
     if (C % groups || (C / groups) % 4) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(C < 512 ? C : 512), 0, s, st1, c1, s1, st2, c2, s2, gamma, beta,
-                       eps, ab, hw);
+                       eps, ab, hw, mr);
     RET_LAST();
 }
 

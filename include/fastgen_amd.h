@@ -176,6 +176,17 @@ size_t fg_op_conv_wgrad_workspace_bytes(int batch, int res, int cin, int cout, i
 int fg_op_conv_wgrad(const void* act, const void* dy, float* dw, int batch, int res, int cin, int cout, int ks,
                      int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Backward of one UNetBlock (EDM/network.py:274-299) as autograd computes it, bf16 compute mode, blocks without attention
+ * or resampling (27 of the 33).  Same tensor conventions as fg_edm_run_block (NHWC fp32 x1 / x2 / dout / dx1 / dx2, emb and
+ * demb [B, emb_channels]).  The block's forward is recomputed first.  Parameter gradients are ACCUMULATED into the fp32
+ * buffers bound with fg_edm_bind_grad (same names and shapes as the parameters; unbound = not computed); demb is
+ * accumulated as well (zero it first); dx1 / dx2 are overwritten (either may be NULL). */
+int fg_edm_bind_grad(fg_edm* h, const char* name, float* grad, int64_t numel);
+size_t fg_edm_block_backward_workspace_bytes(const fg_edm* h, int index, int batch);
+int fg_edm_run_block_backward(fg_edm* h, int index, const float* x1, int c1, const float* x2, int c2, const float* emb,
+                              const float* dout, float* dx1, float* dx2, float* demb, int batch, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* Samples to image bytes, the step after generator_fn in the reference's sample writer
  * (scripts/fid/compute_fid_from_ckpts.py:199): out[n,y,x,c] = uint8(clip(images[n,c,y,x] * 127.5 + 128, 0, 255)),
  * fp32 multiply then add, truncation; NaN -> 0.  images NCHW fp32, out NHWC bytes. */

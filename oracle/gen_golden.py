@@ -197,12 +197,66 @@ def backward_fixture(edm_net):
     torch.save(fx, os.path.join(OUT, "backward_conv.pt"))
 
 
+BWD_CASES = {
+    "enc_first": ("32x32_block0", 1),  # 128 -> 256, 1x1 skip
+    "enc_plain": ("8x8_block1", 2),  # 256 -> 256 @ 8x8, identity skip
+    "dec_cat512": ("16x16_block1_dec", 1),  # 512 -> 256 (concat), 1x1 skip
+    "dec_cat384": ("32x32_block4_dec", 1),  # 384 -> 256 (12 channels per group), 1x1 skip
+}
+
+
+def summarise(t: torch.Tensor):
+    """L2 norm + a strided sample (<= 4096 entries): enough to pin a gradient tensor without storing megabytes."""
+    t = t.detach().reshape(-1)
+    return {"norm": t.double().norm().float(), "sample": t[:: max(1, t.numel() // 4096)][:4096].clone()}
+
+
+def block_backward_fixtures(edm_net):
+    """UNetBlock backward recorded from the reference's modules under autograd: d/dx, d/demb and every
+    parameter gradient for four block variants without attention / resampling, full width, seeded operands."""
+    cfg = edm_ref.CIFAR10
+    sd = edm_ref.random_state_dict(cfg, seed=1234)
+    net = ref_net(edm_net, cfg, sd)
+    enc, dec = edm_ref.layout(cfg)
+    spec = {b.key.split(".")[-1] + ("_dec" if ".dec." in b.key else ""): b for b in enc + dec}
+    fx = {"sd_checksum": sd_checksum(sd)}
+    for i, (cname, (bname, bs)) in enumerate(BWD_CASES.items()):
+        b = spec[bname]
+        mod = (net.model.enc if ".enc." in b.key else net.model.dec)[b.key.split(".")[-1]]
+        for p in mod.parameters():
+            p.requires_grad_(True)
+            p.grad = None
+        x = seeded((bs, b.cin, b.res, b.res), 300 + i).requires_grad_(True)
+        emb = (seeded((bs, 512), 320 + i) * 0.5).requires_grad_(True)
+        dout = seeded((bs, b.cout, b.res, b.res), 340 + i)
+        mod(x, emb).backward(dout)
+        grads = {"dx": x.grad, "demb": emb.grad}
+        grads.update({n: p.grad for n, p in mod.named_parameters()})
+        # own restatement under autograd must agree already here
+        sdg = {k: v.clone().requires_grad_(k.startswith(b.key + ".")) for k, v in sd.items()}
+        xo = x.detach().clone().requires_grad_(True)
+        eo = emb.detach().clone().requires_grad_(True)
+        edm_ref.unet_block(sdg, b, xo, eo).backward(dout)
+        assert torch.allclose(xo.grad, x.grad, rtol=1e-4, atol=1e-5), (cname, "dx")
+        assert torch.allclose(eo.grad, emb.grad, rtol=1e-4, atol=1e-4), (cname, "demb")
+        for n, p in mod.named_parameters():
+            assert torch.allclose(sdg[f"{b.key}.{n}"].grad, p.grad, rtol=1e-4, atol=1e-4 * float(p.grad.abs().max())), (cname, n)
+        fx[f"{cname}/key"] = b.key
+        fx[f"{cname}/bs"] = torch.tensor(bs)
+        fx[f"{cname}/seeds"] = torch.tensor([300 + i, 320 + i, 340 + i])
+        for n, g in grads.items():
+            sm = summarise(g)
+            fx[f"{cname}/{n}/norm"], fx[f"{cname}/{n}/sample"] = sm["norm"], sm["sample"]
+    torch.save(fx, os.path.join(OUT, "blocks_backward.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     edm_net, ns, model = _ref_import.import_reference()
     torch.manual_seed(0)
     if sys.argv[1:] == ["backward"]:
         backward_fixture(edm_net)
+        block_backward_fixtures(edm_net)
         print("backward fixtures written to", OUT)
         return
     if sys.argv[1:] == ["train_schedule"]:
@@ -341,6 +395,7 @@ def main():
     meanflow_fixtures(edm_net, ns)
     train_schedule_fixture(ns)
     backward_fixture(edm_net)
+    block_backward_fixtures(edm_net)
     teacher_sample_fixture(edm_net)
 
     print("golden fixtures written to", OUT)

@@ -601,3 +601,70 @@ def test_conv_wgrad_rejects_bad_arguments():
         _lib.check(L.fg_op_conv_wgrad(x.data_ptr(), x.data_ptr(), x.data_ptr(), 2, 32, 64, 100, 3, 0, x.data_ptr(), 64, None))
     with pytest.raises(_lib.FastGenAMDError):  # workspace too small
         _lib.check(L.fg_op_conv_wgrad(x.data_ptr(), x.data_ptr(), x.data_ptr(), 2, 32, 64, 128, 3, 0, x.data_ptr(), 64, None))
+
+
+# ---- training step, block level: UNetBlock backward --------------------------------------------------------
+BWD_BLOCKS = {"enc_first": "32x32_block0", "enc_plain": "8x8_block1", "dec_cat512": "16x16_block1", "dec_cat384": "32x32_block4"}
+
+
+@pytest.mark.parametrize("case", ["enc_first", "enc_plain", "dec_cat512", "dec_cat384"])
+def test_block_backward_against_reference_golden(nets, sd, golden_dir, case):
+    """d/dx, d/demb and every parameter gradient of one UNetBlock (bf16 compute) against (1) autograd through the oracle in
+    fp32 on the same operands — relative L2 <= 2e-2 per tensor (bf16 activations and activation gradients) — and (2) the
+    norms / strided samples recorded from the reference's own module under autograd (tests/golden/blocks_backward.pt)."""
+    fx = load(golden_dir, "blocks_backward.pt")
+    net = nets["bf16"]
+    L = _lib.lib()
+    enc, dec = R.layout(R.CIFAR10)
+    blocks = [b for b in enc + dec if b.kind == "block"]
+    key = fx[f"{case}/key"]
+    bi = [i for i, b in enumerate(blocks) if b.key == key][0]
+    b = blocks[bi]
+    bs = int(fx[f"{case}/bs"])
+    s_x, s_e, s_d = fx[f"{case}/seeds"].tolist()
+    x = seeded((bs, b.cin, b.res, b.res), s_x)
+    emb = seeded((bs, 512), s_e) * 0.5
+    dout = seeded((bs, b.cout, b.res, b.res), s_d)
+    # ---- oracle: autograd through the CPU restatement --------------------------------------------------------------
+    names = [k for k in sd if k.startswith(key + ".")]
+    sdg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    xo, eo = x.clone().requires_grad_(True), emb.clone().requires_grad_(True)
+    with torch.enable_grad():
+        R.unet_block(sdg, b, xo, eo).backward(dout)
+    want = {"dx": xo.grad, "demb": eo.grad, **{k[len(key) + 1:]: sdg[k].grad for k in names}}
+    # ---- HIP path through the C ABI --------------------------------------------------------------------------------------
+    with torch.inference_mode():
+        dt, h = net._engine(dev())
+        c2 = b.skip_from or 0
+        c1 = b.cin - c2
+        x1 = nhwc(x[:, :c1]).to(dev())
+        x2 = nhwc(x[:, c1:]).to(dev()) if c2 else None
+        grads = {k: torch.zeros_like(sd[k], device=dev()) for k in names}
+        for k, g in grads.items():
+            _lib.check(L.fg_edm_bind_grad(h, k.encode(), g.data_ptr(), g.numel()))
+        try:
+            dx1 = torch.empty(bs, b.res, b.res, c1, device=dev())
+            dx2 = torch.empty(bs, b.res, b.res, max(c2, 1), device=dev())
+            demb = torch.zeros(bs, 512, device=dev())
+            nbytes = L.fg_edm_block_backward_workspace_bytes(h, bi, bs)
+            assert nbytes > 0
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+            _lib.check(L.fg_edm_run_block_backward(h, bi, x1.data_ptr(), c1, x2.data_ptr() if c2 else None, c2,
+                                                   emb.to(dev()).data_ptr(), nhwc(dout).to(dev()).data_ptr(), dx1.data_ptr(),
+                                                   dx2.data_ptr() if c2 else None, demb.data_ptr(), bs, ws.data_ptr(), nbytes, None))
+            torch.cuda.synchronize()
+        finally:
+            for k in grads:
+                _lib.check(L.fg_edm_bind_grad(h, k.encode(), None, 0))
+    dx = torch.cat([nchw(dx1.cpu()), nchw(dx2.cpu())], 1) if c2 else nchw(dx1.cpu())
+    got = {"dx": dx, "demb": demb.cpu(), **{k[len(key) + 1:]: g.cpu() for k, g in grads.items()}}
+    assert set(got) == set(want)
+    for n in sorted(want):
+        rel = float((got[n] - want[n]).norm() / want[n].norm())
+        assert rel <= 2e-2, (case, n, rel)
+        # the reference's own numbers: norm and strided sample
+        gn, gs = fx[f"{case}/{n}/norm"], fx[f"{case}/{n}/sample"]
+        flat = got[n].reshape(-1)
+        smp = flat[:: max(1, flat.numel() // 4096)][:4096]
+        assert abs(float(flat.double().norm()) / float(gn) - 1) <= 2e-2, (case, n)
+        assert float((smp - gs).norm() / gs.norm()) <= 3e-2, (case, n)
