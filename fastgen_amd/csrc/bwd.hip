@@ -38,27 +38,71 @@ __device__ __forceinline__ const __bf16* cat_ptr(const __bf16* x1, int C1, const
     return (c0 < C1) ? x1 + pix * C1 + c0 : x2 + pix * C2 + (c0 - C1);
 }
 
+// Gradient tensor t lives at the conv's OUTPUT resolution; fetch what reaches input pixel p (row-major, width `res`) of image n.
+// rm 0: same resolution.  rm 1: the forward averaged 2x2 input pixels (down-sampling) -> a quarter of the coarse value.
+// rm 2: the forward repeated each input pixel 2x2 (nearest up-sampling) -> the sum of the four fine values.
+__device__ __forceinline__ void fetch_res(const __bf16* t, int Ct, int n, int p, int c0, int res, int rm, float (&v)[8]) {
+    if (rm == 0) {
+        load8bf(t + ((size_t)n * res * res + p) * Ct + c0, v);
+    } else if (rm == 1) {
+        const int y = p / res, x = p - y * res, ro = res >> 1;
+        load8bf(t + ((size_t)n * ro * ro + (y >> 1) * ro + (x >> 1)) * Ct + c0, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= 0.25f;
+    } else {
+        const int y = p / res, x = p - y * res, ro = res << 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float u[8];
+            load8bf(t + ((size_t)n * ro * ro + (2 * y + (d >> 1)) * ro + 2 * x + (d & 1)) * Ct + c0, u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += u[j];
+        }
+    }
+}
+
 // ---- act = silu(a x + b) (MODE 0), a x + b (MODE 1) or x (MODE 2, ab unused): the conv operand, over the virtual concat, that
 // the weight-gradient kernel contracts with -----------------------------------------------------------------------------------
+// `res` is the OUTPUT resolution; rm 1: output pixel = mean of the 2x2 activated input pixels (input resolution 2 res), rm 2:
+// output pixel (y, x) = activated input pixel (y/2, x/2) (input resolution res/2) - Conv2d.forward's resampling, :114-123.
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_act_kernel(const __bf16* __restrict__ x1, int C1, const __bf16* __restrict__ x2, int C2,
                                                      const float2* __restrict__ ab, __bf16* __restrict__ out, int64_t total_oct,
-                                                     int HW) {
-    const int C = C1 + C2, OC = C >> 3;
+                                                     int res, int rm) {
+    const int C = C1 + C2, OC = C >> 3, HW = res * res;
+    const int ri = rm == 1 ? res * 2 : (rm == 2 ? res / 2 : res);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_oct; i += (int64_t)gridDim.x * 256) {
         const int c0 = (int)(i % OC) * 8;
         const size_t pix = (size_t)(i / OC);
-        const int n = (int)(pix / HW);
-        float v[8];
-        load8bf(cat_ptr(x1, C1, x2, C2, pix, c0), v);
+        const int n = (int)(pix / HW), p = (int)(pix - (size_t)n * HW);
+        const int y = p / res, x = p - y * res;
         const float2* abp = MODE == 2 ? nullptr : ab + (size_t)n * C + c0;
+        float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (MODE == 2) continue;  // plain copy of the concat
-            const float y = fmaf(v[j], abp[j].x, abp[j].y);
-            v[j] = MODE == 0 ? silu_fwd(y) : y;
+        for (int j = 0; j < 8; ++j) o[j] = 0.f;
+        const int nsrc = rm == 1 ? 4 : 1;
+        for (int d = 0; d < nsrc; ++d) {
+            const int sy = rm == 1 ? 2 * y + (d >> 1) : (rm == 2 ? y >> 1 : y);
+            const int sx = rm == 1 ? 2 * x + (d & 1) : (rm == 2 ? x >> 1 : x);
+            float v[8];
+            load8bf(cat_ptr(x1, C1, x2, C2, (size_t)n * ri * ri + sy * ri + sx, c0), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = v[j];
+                if (MODE != 2) {
+                    t = fmaf(t, abp[j].x, abp[j].y);
+                    if (MODE == 0) t = silu_fwd(t);
+                }
+                o[j] += t;
+            }
         }
-        store8bf(out + pix * C + c0, v);
+        if (rm == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] *= 0.25f;
+        }
+        store8bf(out + pix * C + c0, o);
     }
 }
 
@@ -68,8 +112,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const __bf16* __restrict__ x1, int C1, const __bf16* __restrict__ x2,
                                                             int C2, const __bf16* __restrict__ dact, int Cd,
                                                             const float2* __restrict__ ab, const float2* __restrict__ mr,
-                                                            float2* __restrict__ P, int HW) {
-    const int C = C1 + C2;
+                                                            float2* __restrict__ P, int res, int rm) {
+    const int C = C1 + C2, HW = res * res;
     const int groups = min(32, C / 4), cpg = C / groups;
     const int n = blockIdx.y, oct = threadIdx.x & 7, pl = threadIdx.x >> 3;
     const int c0 = blockIdx.x * 64 + oct * 8;
@@ -89,7 +133,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const __bf16* __rest
             const size_t pix = (size_t)n * HW + p;
             float xv[8], dv[8];
             load8bf(cat_ptr(x1, C1, x2, C2, pix, c0), xv);
-            load8bf(dact + pix * Cd + c0, dv);
+            fetch_res(dact, Cd, n, p, c0, res, rm, dv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float dy = MODE == 0 ? dv[j] * silu_grad(fmaf(xv[j], a[j], b[j])) : dv[j];
@@ -143,18 +187,19 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const __bf16* __restr
                                                            int C2, const __bf16* __restrict__ dact, int Cd,
                                                            const float2* __restrict__ ab, const float2* __restrict__ mr,
                                                            const float2* __restrict__ S, const __bf16* __restrict__ add, int Ca,
-                                                           float add_scale, __bf16* __restrict__ dx, int64_t total_oct, int HW) {
-    const int C = C1 + C2, OC = C >> 3;
+                                                           float add_scale, __bf16* __restrict__ dx, int64_t total_oct, int res,
+                                                           int rm) {
+    const int C = C1 + C2, OC = C >> 3, HW = res * res;
     const int groups = min(32, C / 4), cpg = C / groups;
     const float inv_m = 1.0f / ((float)cpg * (float)HW);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_oct; i += (int64_t)gridDim.x * 256) {
         const int c0 = (int)(i % OC) * 8;
         const size_t pix = (size_t)(i / OC);
-        const int n = (int)(pix / HW);
+        const int n = (int)(pix / HW), p = (int)(pix - (size_t)n * HW);
         float xv[8], dv[8], av[8];
         load8bf(cat_ptr(x1, C1, x2, C2, pix, c0), xv);
-        load8bf(dact + pix * Cd + c0, dv);
-        if (add) load8bf(add + pix * Ca + c0, av);
+        fetch_res(dact, Cd, n, p, c0, res, rm, dv);
+        if (add) fetch_res(add, Ca, n, p, c0, res, rm, av);
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -211,6 +256,9 @@ __global__ void batchsum_add_kernel(const float* __restrict__ in, float* __restr
 __global__ void scale_to_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, float scale, int64_t total) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) out[i] = (__bf16)(in[i] * scale);
 }
+__global__ void scale_bf16_kernel(const __bf16* __restrict__ in, __bf16* __restrict__ out, float scale, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) out[i] = (__bf16)((float)in[i] * scale);
+}
 // bf16 [.., Cs] channels [c_off, c_off + C) -> fp32 [.., C]
 __global__ void slice_to_f32_kernel(const __bf16* __restrict__ in, int Cs, int c_off, float* __restrict__ out, int C, int64_t npix) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix * C; i += (int64_t)gridDim.x * 256) {
@@ -262,38 +310,40 @@ inline unsigned ew_blocks(int64_t n) {
 
 #define BWD_RET() return (int)hipGetLastError()
 
-int launch_gn_act(int mode, const void* x1, int c1, const void* x2, int c2, const float2* ab, void* out, int B, int hw, hipStream_t s) {
+int launch_gn_act(int mode, const void* x1, int c1, const void* x2, int c2, const float2* ab, void* out, int B, int res, int rm,
+                  hipStream_t s) {
     if ((c1 % 8) || (c2 % 8)) return (int)hipErrorInvalidValue;
+    const int hw = res * res;
     const int64_t total = (int64_t)B * hw * ((c1 + c2) / 8);
     if (mode == 0)
-        hipLaunchKernelGGL(gn_act_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, ab, (__bf16*)out, total, hw);
+        hipLaunchKernelGGL(gn_act_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, ab, (__bf16*)out, total, res, rm);
     else if (mode == 2)
-        hipLaunchKernelGGL(gn_act_kernel<2>, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, ab, (__bf16*)out, total, hw);
+        hipLaunchKernelGGL(gn_act_kernel<2>, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, ab, (__bf16*)out, total, res, rm);
     else
-        hipLaunchKernelGGL(gn_act_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, ab, (__bf16*)out, total, hw);
+        hipLaunchKernelGGL(gn_act_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, ab, (__bf16*)out, total, res, rm);
     BWD_RET();
 }
 
 // GroupNorm(+SiLU) backward.  P: [B][C] float2 scratch, S: [B][groups] float2 scratch.  dgamma / dbeta are accumulated.
 int launch_gn_bwd(int mode, const void* x1, int c1, const void* x2, int c2, const void* dact, int cd, const float2* ab,
                   const float2* mr, const float* gamma, float2* P, float2* S, float* dgamma, float* dbeta, const void* add, int ca,
-                  float add_scale, void* dx, int B, int hw, hipStream_t s) {
-    const int C = c1 + c2;
+                  float add_scale, void* dx, int B, int res, int rm, hipStream_t s) {
+    const int C = c1 + c2, hw = res * res;
     if ((c1 % 8) || (c2 % 8) || C < 16) return (int)hipErrorInvalidValue;
     const int groups = C / 4 < 32 ? C / 4 : 32;
     dim3 rg((C + 63) / 64, B);
     const __bf16 *X1 = (const __bf16*)x1, *X2 = (const __bf16*)x2, *D = (const __bf16*)dact, *A = (const __bf16*)add;
     if (mode == 0)
-        hipLaunchKernelGGL(gn_bwd_reduce_kernel<0>, rg, dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, P, hw);
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<0>, rg, dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, P, res, rm);
     else
-        hipLaunchKernelGGL(gn_bwd_reduce_kernel<1>, rg, dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, P, hw);
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<1>, rg, dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, P, res, rm);
     hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(B), dim3(32), 0, s, P, gamma, S, C);
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, s, P, dgamma, dbeta, B, C);
     const int64_t total = (int64_t)B * hw * (C / 8);
     if (mode == 0)
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, S, A, ca, add_scale, (__bf16*)dx, total, hw);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, S, A, ca, add_scale, (__bf16*)dx, total, res, rm);
     else
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, S, A, ca, add_scale, (__bf16*)dx, total, hw);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, S, A, ca, add_scale, (__bf16*)dx, total, res, rm);
     (void)groups;
     BWD_RET();
 }
@@ -309,6 +359,10 @@ int launch_batchsum_add(const float* in, float* out, int B, int C, hipStream_t s
 }
 int launch_scale_to_bf16(const float* in, void* out, float scale, int64_t total, hipStream_t s) {
     hipLaunchKernelGGL(scale_to_bf16_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, in, (__bf16*)out, scale, total);
+    BWD_RET();
+}
+int launch_scale_bf16(const void* in, void* out, float scale, int64_t total, hipStream_t s) {
+    hipLaunchKernelGGL(scale_bf16_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)in, (__bf16*)out, scale, total);
     BWD_RET();
 }
 int launch_slice_to_f32(const void* in, int cs, int c_off, float* out, int C, int64_t npix, hipStream_t s) {

@@ -1065,15 +1065,15 @@ struct BwdScratch {
     size_t wg_bytes;
 };
 int pad256(int c) { return (c + 255) / 256 * 256; }
-size_t plan_block_bwd(int B, int res, int cin, int cout, Arena& A, BwdScratch& q) {
-    const size_t npix = (size_t)B * res * res;
+size_t plan_block_bwd(int B, int res_in, int res, int cin, int cout, Arena& A, BwdScratch& q) {
+    const size_t npix = (size_t)B * res * res, npix_in = (size_t)B * res_in * res_in;
     const int cp = pad256(cin), cm = cin > cout ? cin : cout;
     q.g1 = A.take(npix * cout * 2);
     q.aop = A.take(npix * cm * 2);
     q.da = A.take(npix * (cp > cout ? cp : cout) * 2);
     q.dh0 = A.take(npix * cout * 2);
     q.dskip = A.take(npix * cp * 2);
-    q.dxin = A.take(npix * cin * 2);
+    q.dxin = A.take(npix_in * cin * 2);
     q.P = A.get<float2>((size_t)B * cm);
     q.S = A.get<float2>((size_t)B * 32);
     q.mr0 = A.get<float2>((size_t)B * 32);
@@ -1103,6 +1103,64 @@ int conv_dgrad(fg_edm* h, const float* w_oihw, int cout, int cin, int ks, const 
     HIP_TRY(launch_conv_fused(1, ks, PRO_NONE, RES_NONE, OUT_NHWC, a, s));
     return FG_OK;
 }
+
+// Backward of one UNetBlock (bf16).  a1 / a2: the block's inputs (virtual concat) at res_in; gout: dL/d(block output), bf16
+// [B, res_out^2, cout]; dxin: bf16 [B, res_in^2, cin] (overwritten); demb [B, emb_ch] and the bound parameter gradients are
+// accumulated.  The block's forward is recomputed here (activation checkpointing at block granularity).
+int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& a2, int c2, const float* emb, const float* temb,
+                   const void* gout, void* dxin, float* demb, int B, Workspace& w, BwdScratch& q, hipStream_t s) {
+    if (b.attn) return fail(FG_EINVAL, "%s: backward of attention blocks is not implemented yet", b.key.c_str());
+    const int res = b.res_out, res_in = b.res_in, hw = res * res, cin = b.cin, cout = b.cout, cp = pad256(cin);
+    const int rm = b.down ? 1 : (b.up ? 2 : 0);
+    if (!conv_wgrad_supported(res, cout, cout, 3) || !conv_wgrad_supported(res, cin, cout, 3))
+        return fail(FG_EINVAL, "%s: shape not covered by the weight-gradient kernel", b.key.c_str());
+    const size_t npix = (size_t)B * hw;
+    w.mr0 = q.mr0;
+    w.mr1 = q.mr1;
+    int rc = run_block(h, b, a1, c1, a2, c2, temb, w.xa, B, w, s);
+    w.mr0 = w.mr1 = nullptr;
+    if (rc) return rc;
+    // out = (conv1(act1) + skip) * sigma  =>  g1 = sigma * gout reaches conv1's output and the skip path alike
+    HIP_TRY(launch_scale_bf16(gout, q.g1, kSkipScale, (int64_t)npix * cout, s));
+    HIP_TRY(launch_colsum(q.g1, cout, cout, q.dtemb, B, hw, 1.0f, s));
+    if (h->G(b.conv1_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.conv1_b), B, cout, s));
+    if (b.has_skip && h->G(b.skip_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.skip_b), B, cout, s));
+    // conv1
+    if (h->G(b.conv1_w)) {
+        HIP_TRY(launch_gn_act(0, w.h.p, cout, nullptr, 0, w.ab1, q.aop, B, res, 0, s));
+        HIP_TRY(launch_conv_wgrad(q.aop, q.g1, h->G(b.conv1_w), B, res, cout, cout, 3, 1, q.wg, s));
+    }
+    if ((rc = conv_dgrad(h, h->P(b.conv1_w), cout, cout, 3, q.g1, q.da, B, res, q, s))) return rc;
+    // norm1 + silu
+    HIP_TRY(launch_gn_bwd(0, w.h.p, cout, nullptr, 0, q.da, pad256(cout), w.ab1, q.mr1, h->P(b.norm1_w), q.P, q.S, h->G(b.norm1_w),
+                          h->G(b.norm1_b), nullptr, 0, 0.f, q.dh0, B, res, 0, s));
+    // bias of conv0 and the embedding affine see the pixel sum of dh0
+    HIP_TRY(launch_colsum(q.dh0, cout, cout, q.dtemb, B, hw, 1.0f, s));
+    if (h->G(b.conv0_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.conv0_b), B, cout, s));
+    if (h->G(b.aff_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.aff_b), B, cout, s));
+    HIP_TRY(launch_affine_bwd(q.dtemb, emb, h->P(b.aff_w), h->G(b.aff_w), demb, B, cout, h->emb_ch, s));
+    // conv0: its operand is silu(norm0(x)), resampled to the output resolution
+    if (h->G(b.conv0_w)) {
+        HIP_TRY(launch_gn_act(0, a1.p, c1, a2.p, c2, w.ab0, q.aop, B, res, rm, s));
+        HIP_TRY(launch_conv_wgrad(q.aop, q.dh0, h->G(b.conv0_w), B, res, cin, cout, 3, 1, q.wg, s));
+    }
+    if ((rc = conv_dgrad(h, h->P(b.conv0_w), cout, cin, 3, q.dh0, q.da, B, res, q, s))) return rc;
+    // skip path: its gradient joins dx_in inside the norm0 backward pass (both live at the output resolution)
+    const void* add = q.g1;
+    int ca = cout;
+    if (b.has_skip) {
+        if (h->G(b.skip_w)) {
+            HIP_TRY(launch_gn_act(2, a1.p, c1, a2.p, c2, nullptr, q.aop, B, res, rm, s));
+            HIP_TRY(launch_conv_wgrad(q.aop, q.g1, h->G(b.skip_w), B, res, cin, cout, 1, 1, q.wg, s));
+        }
+        if ((rc = conv_dgrad(h, h->P(b.skip_w), cout, cin, 1, q.g1, q.dskip, B, res, q, s))) return rc;
+        add = q.dskip;
+        ca = cp;
+    }
+    HIP_TRY(launch_gn_bwd(0, a1.p, c1, a2.p, c2, q.da, cp, w.ab0, q.mr0, h->P(b.norm0_w), q.P, q.S, h->G(b.norm0_w), h->G(b.norm0_b),
+                          add, ca, 1.0f, dxin, B, res_in, rm, s));
+    return FG_OK;
+}
 }  // namespace
 
 int fg_edm_bind_grad(fg_edm* h, const char* name, float* grad, int64_t numel) {
@@ -1122,7 +1180,9 @@ size_t fg_edm_block_backward_workspace_bytes(const fg_edm* h, int index, int bat
     Workspace w;
     plan_workspace(h, batch, A, w);
     BwdScratch q;
-    return plan_block_bwd(batch, b.res_out, b.cin, b.cout, A, q);
+    plan_block_bwd(batch, b.res_in, b.res_out, b.cin, b.cout, A, q);
+    A.take((size_t)batch * b.res_out * b.res_out * b.cout * 2);  // gout in bf16
+    return A.off;
 }
 
 int fg_edm_run_block_backward(fg_edm* h, int index, const float* x1, int c1, const float* x2, int c2, const float* emb,
@@ -1133,77 +1193,32 @@ int fg_edm_run_block_backward(fg_edm* h, int index, const float* x1, int c1, con
     if (!h->dtype) return fail(FG_EINVAL, "the backward pass runs in the bf16 compute mode only");
     if (index < 0 || index >= (int)h->blocks.size()) return fail(FG_EINVAL, "block index out of range");
     const Block& b = *h->blocks[index];
-    if (b.attn || b.up || b.down)
-        return fail(FG_EINVAL, "%s: backward of attention / resampling blocks is not implemented yet", b.key.c_str());
     if (c1 + c2 != b.cin || (c1 % 8) || (c2 % 8)) return fail(FG_EINVAL, "%s: bad input channel split %d+%d", b.key.c_str(), c1, c2);
     if (batch <= 0 || !workspace || (((uintptr_t)workspace) & 255)) return fail(FG_EINVAL, "bad batch / workspace");
-    const int B = batch, res = b.res_out, hw = res * res, cin = b.cin, cout = b.cout, cp = pad256(cin);
-    if (!conv_wgrad_supported(res, cout, cout, 3) || !conv_wgrad_supported(res, cin, cout, 3))
-        return fail(FG_EINVAL, "%s: shape not covered by the weight-gradient kernel", b.key.c_str());
+    const int B = batch;
     Arena A;
     A.base = (char*)workspace;
     Workspace w;
     plan_workspace(h, B, A, w);
     BwdScratch q;
-    const size_t need = plan_block_bwd(B, res, cin, cout, A, q);
-    if (need > workspace_bytes) return fail(FG_ENOMEM, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    plan_block_bwd(B, b.res_in, b.res_out, b.cin, b.cout, A, q);
+    const size_t npix = (size_t)B * b.res_out * b.res_out, npix_in = (size_t)B * b.res_in * b.res_in;
+    void* gout = A.take(npix * b.cout * 2);
+    if (A.off > workspace_bytes) return fail(FG_ENOMEM, "workspace too small: need %zu bytes, got %zu", A.off, workspace_bytes);
     hipStream_t s = (hipStream_t)stream;
-    const size_t npix = (size_t)B * hw;
-    // ---- forward of the block, keeping what the backward pass reads (inputs, conv0 output, both norms' coefficients) ----
     HIP_TRY(launch_linear(emb, h->aff_w, h->aff_b, w.temb, B, h->emb_ch, h->temb_total, 0, s));
     Act a1, a2;
-    HIP_TRY(launch_to_act(1, x1, w.cvt1, (int64_t)npix * c1, s));
+    HIP_TRY(launch_to_act(1, x1, w.cvt1, (int64_t)npix_in * c1, s));
     a1.p = w.cvt1;
     if (c2) {
-        HIP_TRY(launch_to_act(1, x2, w.cvt2, (int64_t)npix * c2, s));
+        HIP_TRY(launch_to_act(1, x2, w.cvt2, (int64_t)npix_in * c2, s));
         a2.p = w.cvt2;
     }
-    w.mr0 = q.mr0;
-    w.mr1 = q.mr1;
-    int rc = run_block(h, b, a1, c1, a2, c2, w.temb, w.xa, B, w, s);
+    HIP_TRY(launch_scale_to_bf16(dout, gout, 1.0f, (int64_t)npix * b.cout, s));
+    int rc = block_backward(h, b, a1, c1, a2, c2, emb, w.temb, gout, q.dxin, demb, B, w, q, s);
     if (rc) return rc;
-    // ---- backward -----------------------------------------------------------------------------------------------------
-    // out = (conv1(a1) + skip) * sigma  =>  g1 = sigma * dout reaches conv1's output and the skip path alike
-    HIP_TRY(launch_scale_to_bf16(dout, q.g1, kSkipScale, (int64_t)npix * cout, s));
-    HIP_TRY(launch_colsum(q.g1, cout, cout, q.dtemb, B, hw, 1.0f, s));
-    if (h->G(b.conv1_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.conv1_b), B, cout, s));
-    if (b.has_skip && h->G(b.skip_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.skip_b), B, cout, s));
-    // conv1
-    if (h->G(b.conv1_w)) {
-        HIP_TRY(launch_gn_act(0, w.h.p, cout, nullptr, 0, w.ab1, q.aop, B, hw, s));
-        HIP_TRY(launch_conv_wgrad(q.aop, q.g1, h->G(b.conv1_w), B, res, cout, cout, 3, 1, q.wg, s));
-    }
-    if ((rc = conv_dgrad(h, h->P(b.conv1_w), cout, cout, 3, q.g1, q.da, B, res, q, s))) return rc;
-    // norm1 + silu
-    HIP_TRY(launch_gn_bwd(0, w.h.p, cout, nullptr, 0, q.da, pad256(cout), w.ab1, q.mr1, h->P(b.norm1_w), q.P, q.S, h->G(b.norm1_w),
-                          h->G(b.norm1_b), nullptr, 0, 0.f, q.dh0, B, hw, s));
-    // bias of conv0 and the embedding affine see the pixel sum of dh0
-    HIP_TRY(launch_colsum(q.dh0, cout, cout, q.dtemb, B, hw, 1.0f, s));
-    if (h->G(b.conv0_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.conv0_b), B, cout, s));
-    if (h->G(b.aff_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.aff_b), B, cout, s));
-    HIP_TRY(launch_affine_bwd(q.dtemb, emb, h->P(b.aff_w), h->G(b.aff_w), demb, B, cout, h->emb_ch, s));
-    // conv0
-    if (h->G(b.conv0_w)) {
-        HIP_TRY(launch_gn_act(0, a1.p, c1, a2.p, c2, w.ab0, q.aop, B, hw, s));
-        HIP_TRY(launch_conv_wgrad(q.aop, q.dh0, h->G(b.conv0_w), B, res, cin, cout, 3, 1, q.wg, s));
-    }
-    if ((rc = conv_dgrad(h, h->P(b.conv0_w), cout, cin, 3, q.dh0, q.da, B, res, q, s))) return rc;
-    // skip path: its gradient joins dx_in inside the norm0 backward pass
-    const void* add = q.g1;
-    int ca = cout;
-    if (b.has_skip) {
-        if (h->G(b.skip_w)) {
-            HIP_TRY(launch_gn_act(2, a1.p, c1, a2.p, c2, nullptr, q.aop, B, hw, s));
-            HIP_TRY(launch_conv_wgrad(q.aop, q.g1, h->G(b.skip_w), B, res, cin, cout, 1, 1, q.wg, s));
-        }
-        if ((rc = conv_dgrad(h, h->P(b.skip_w), cout, cin, 1, q.g1, q.dskip, B, res, q, s))) return rc;
-        add = q.dskip;
-        ca = cp;
-    }
-    HIP_TRY(launch_gn_bwd(0, a1.p, c1, a2.p, c2, q.da, cp, w.ab0, q.mr0, h->P(b.norm0_w), q.P, q.S, h->G(b.norm0_w), h->G(b.norm0_b),
-                          add, ca, 1.0f, q.dxin, B, hw, s));
-    if (dx1) HIP_TRY(launch_slice_to_f32(q.dxin, cin, 0, dx1, c1, (int64_t)npix, s));
-    if (dx2 && c2) HIP_TRY(launch_slice_to_f32(q.dxin, cin, c1, dx2, c2, (int64_t)npix, s));
+    if (dx1) HIP_TRY(launch_slice_to_f32(q.dxin, b.cin, 0, dx1, c1, (int64_t)npix_in, s));
+    if (dx2 && c2) HIP_TRY(launch_slice_to_f32(q.dxin, b.cin, c1, dx2, c2, (int64_t)npix_in, s));
     return FG_OK;
 }
 

@@ -31,13 +31,15 @@ int launch_gn_silu_pool(int dtype, const void* x, const float2* ab, void* out, i
 int launch_to_act(int dtype, const float* in, void* out, int64_t total, hipStream_t s);
 int launch_from_act(int dtype, const void* in, float* out, int64_t total, hipStream_t s);
 // bwd.hip: elementwise / reduction pieces of the block backward pass (bf16 activations)
-int launch_gn_act(int mode, const void* x1, int c1, const void* x2, int c2, const float2* ab, void* out, int B, int hw, hipStream_t s);
+int launch_gn_act(int mode, const void* x1, int c1, const void* x2, int c2, const float2* ab, void* out, int B, int res, int rm,
+                  hipStream_t s);  // res = output resolution; rm 0 none, 1 down (avg 2x2), 2 up (nearest)
 int launch_gn_bwd(int mode, const void* x1, int c1, const void* x2, int c2, const void* dact, int cd, const float2* ab,
                   const float2* mr, const float* gamma, float2* P, float2* S, float* dgamma, float* dbeta, const void* add, int ca,
-                  float add_scale, void* dx, int B, int hw, hipStream_t s);
+                  float add_scale, void* dx, int B, int res, int rm, hipStream_t s);  // res = the norm's (input) resolution
 int launch_colsum(const void* t, int ct, int C, float* out, int B, int hw, float scale, hipStream_t s);
 int launch_batchsum_add(const float* in, float* out, int B, int C, hipStream_t s);
 int launch_scale_to_bf16(const float* in, void* out, float scale, int64_t total, hipStream_t s);
+int launch_scale_bf16(const void* in, void* out, float scale, int64_t total, hipStream_t s);
 int launch_slice_to_f32(const void* in, int cs, int c_off, float* out, int C, int64_t npix, hipStream_t s);
 int launch_affine_bwd(const float* dtemb, const float* emb, const float* w, float* dw, float* demb, int B, int C, int K, hipStream_t s);
 int launch_dgrad_weights(const float* w, float* wt, int cout, int cin, int cin_pad, int taps, hipStream_t s);

@@ -202,6 +202,8 @@ BWD_CASES = {
     "enc_plain": ("8x8_block1", 2),  # 256 -> 256 @ 8x8, identity skip
     "dec_cat512": ("16x16_block1_dec", 1),  # 512 -> 256 (concat), 1x1 skip
     "dec_cat384": ("32x32_block4_dec", 1),  # 384 -> 256 (12 channels per group), 1x1 skip
+    "enc_down": ("16x16_down", 1),  # 32 -> 16: 2x2 average in conv0 and in the skip conv
+    "dec_up": ("16x16_up_dec", 2),  # 8 -> 16: nearest up-sampling in conv0 and in the skip conv
 }
 
 
@@ -226,7 +228,8 @@ def block_backward_fixtures(edm_net):
         for p in mod.parameters():
             p.requires_grad_(True)
             p.grad = None
-        x = seeded((bs, b.cin, b.res, b.res), 300 + i).requires_grad_(True)
+        rin = b.res * 2 if b.down else (b.res // 2 if b.up else b.res)
+        x = seeded((bs, b.cin, rin, rin), 300 + i).requires_grad_(True)
         emb = (seeded((bs, 512), 320 + i) * 0.5).requires_grad_(True)
         dout = seeded((bs, b.cout, b.res, b.res), 340 + i)
         mod(x, emb).backward(dout)

@@ -607,7 +607,7 @@ def test_conv_wgrad_rejects_bad_arguments():
 BWD_BLOCKS = {"enc_first": "32x32_block0", "enc_plain": "8x8_block1", "dec_cat512": "16x16_block1", "dec_cat384": "32x32_block4"}
 
 
-@pytest.mark.parametrize("case", ["enc_first", "enc_plain", "dec_cat512", "dec_cat384"])
+@pytest.mark.parametrize("case", ["enc_first", "enc_plain", "dec_cat512", "dec_cat384", "enc_down", "dec_up"])
 def test_block_backward_against_reference_golden(nets, sd, golden_dir, case):
     """d/dx, d/demb and every parameter gradient of one UNetBlock (bf16 compute) against (1) autograd through the oracle in
     fp32 on the same operands — relative L2 <= 2e-2 per tensor (bf16 activations and activation gradients) — and (2) the
@@ -622,11 +622,12 @@ def test_block_backward_against_reference_golden(nets, sd, golden_dir, case):
     b = blocks[bi]
     bs = int(fx[f"{case}/bs"])
     s_x, s_e, s_d = fx[f"{case}/seeds"].tolist()
-    x = seeded((bs, b.cin, b.res, b.res), s_x)
+    rin = b.res * 2 if b.down else (b.res // 2 if b.up else b.res)
+    x = seeded((bs, b.cin, rin, rin), s_x)
     emb = seeded((bs, 512), s_e) * 0.5
     dout = seeded((bs, b.cout, b.res, b.res), s_d)
     # ---- oracle: autograd through the CPU restatement --------------------------------------------------------------
-    names = [k for k in sd if k.startswith(key + ".")]
+    names = [k for k in sd if k.startswith(key + ".") and "resample_filter" not in k]  # buffers carry no gradient
     sdg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
     xo, eo = x.clone().requires_grad_(True), emb.clone().requires_grad_(True)
     with torch.enable_grad():
@@ -643,8 +644,8 @@ def test_block_backward_against_reference_golden(nets, sd, golden_dir, case):
         for k, g in grads.items():
             _lib.check(L.fg_edm_bind_grad(h, k.encode(), g.data_ptr(), g.numel()))
         try:
-            dx1 = torch.empty(bs, b.res, b.res, c1, device=dev())
-            dx2 = torch.empty(bs, b.res, b.res, max(c2, 1), device=dev())
+            dx1 = torch.empty(bs, rin, rin, c1, device=dev())
+            dx2 = torch.empty(bs, rin, rin, max(c2, 1), device=dev())
             demb = torch.zeros(bs, 512, device=dev())
             nbytes = L.fg_edm_block_backward_workspace_bytes(h, bi, bs)
             assert nbytes > 0
