@@ -1,0 +1,151 @@
+// Backward of the U-Net's single-head self-attention (reference fastgen/networks/EDM/network.py:160-196: AttentionOp and its
+// hand-written backward; :290-296 in UNetBlock.forward) - part of the training step, SURVEY §8(f)1.
+//
+//   forward (per image):  S = q k^T / sqrt(C),  P = softmax_rows(S),  O = P v            q, k, v, O: [T][C], T = 256 | 64, C = 256
+//   backward, given dO:   dv = P^T dO,  dP = dO v^T,  dS = P o (dP - rowsum(dP o P)),  dq = dS k / sqrt(C),  dk = dS^T q / sqrt(C)
+//
+// 0.17 GFLOP per image - 0.4 % of the block's backward - so this first version favours obviously-correct structure over
+// speed: every product is the SAME small batched kernel  C[m][n] = scale * sum_k A[m][k] B[n][k]  (both operands contiguous
+// along the contraction: one 16-byte load per lane feeds v_mfma_f32_32x32x16_bf16), with explicit bf16 transposes in between
+// and fp32 logits / dP in global memory.
+#include "common.h"
+#include "misc.h"
+
+namespace {
+
+// C[b][m][n] = scale * sum_k A[b][m][k] * Bm[b][n][k]; one wave per 32x32 tile; M, N % 32 == 0, K % 16 == 0.
+template <bool OUT_BF16>
+__global__ __launch_bounds__(64) void nt_gemm_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ Bm, void* __restrict__ C,
+                                                      int M, int N, int K, float scale) {
+    const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const size_t b = blockIdx.z;
+    const __bf16* ap = A + (b * M + m0 + m) * K + 8 * h;
+    const __bf16* bp = Bm + (b * N + n0 + m) * K + 8 * h;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) mma16(acc, load_frag(ap + k0), load_frag(bp + k0));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const size_t o = (b * M + m0 + (i & 3) + 8 * (i >> 2) + 4 * h) * N + n0 + m;
+        if (OUT_BF16)
+            reinterpret_cast<__bf16*>(C)[o] = (__bf16)(acc[i] * scale);
+        else
+            reinterpret_cast<float*>(C)[o] = acc[i] * scale;
+    }
+}
+
+// out[b][c][r] = in[b][r][c]   (bf16, R and Cc multiples of 32)
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const __bf16* __restrict__ in, __bf16* __restrict__ out, int R, int Cc) {
+    __shared__ __bf16 tile[32][34];
+    const size_t b = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) tile[i][tx] = in[(b * R + r0 + i) * Cc + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) out[(b * Cc + c0 + i) * R + r0 + tx] = tile[tx][i];
+}
+
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float u = __shfl_xor(v, o);
+        v = is_max ? fmaxf(v, u) : v + u;
+    }
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < nw; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+    return r;
+}
+
+// P[row][k] = softmax_k(S[row][k] * sc); one workgroup (T threads) per row
+__global__ void softmax_rows_kernel(const float* __restrict__ S, __bf16* __restrict__ P, int T, float sc) {
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    const float s = S[row * T + threadIdx.x] * sc;
+    const float mx = block_reduce(s, true, red);
+    const float e = expf(s - mx);
+    const float sum = block_reduce(e, false, red);
+    P[row * T + threadIdx.x] = (__bf16)(e / sum);
+}
+
+// dS[row][k] = P (dP - sum_k dP P); one workgroup (T threads) per row
+__global__ void attn_ds_kernel(const __bf16* __restrict__ P, const float* __restrict__ dP, __bf16* __restrict__ dS, int T) {
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    const float p = (float)P[row * T + threadIdx.x], g = dP[row * T + threadIdx.x];
+    const float d = block_reduce(p * g, false, red);
+    dS[row * T + threadIdx.x] = (__bf16)(p * (g - d));
+}
+
+// dqkv[b][t][c*3 + plane] <- dq[b][t][c] | dk[b][t][c] | dvt[b][c][t]   (the reference's channel order, :160-163)
+__global__ void qkv_interleave_kernel(const __bf16* __restrict__ dq, const __bf16* __restrict__ dk, const __bf16* __restrict__ dvt,
+                                      __bf16* __restrict__ out, int T, int C, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t bt = i / C;
+        const int t = (int)(bt % T);
+        const int64_t b = bt / T;
+        __bf16* o = out + (bt * C + c) * 3;
+        o[0] = dq[i];
+        o[1] = dk[i];
+        o[2] = dvt[(b * C + c) * T + t];
+    }
+}
+
+template <bool OB>
+void nt_gemm(const void* A, const void* Bm, void* C, int batch, int M, int N, int K, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(nt_gemm_kernel<OB>, dim3(N / 32, M / 32, batch), dim3(64), 0, s, (const __bf16*)A, (const __bf16*)Bm, C, M, N, K, scale);
+}
+void transpose(const void* in, void* out, int batch, int R, int Cc, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(Cc / 32, R / 32, batch), dim3(256), 0, s, (const __bf16*)in, (__bf16*)out, R, Cc);
+}
+
+}  // namespace
+
+// bytes of scratch: 4 transposes [B][T][C] + 4 bf16 [B][T][T] + 2 fp32 [B][T][T]
+size_t attention_backward_scratch_bytes(int B, int T, int C) {
+    return (size_t)B * T * C * 2 * 4 + (size_t)B * T * T * (2 * 4 + 4 * 2) + 4096;
+}
+
+// q, k, dO, dq, dk: [B][T][C]; vt, dvt: [B][C][T]; all bf16.  T in {64, 256}, C % 32 == 0.
+int launch_attention_backward(const void* q, const void* k, const void* vt, const void* dO, void* dq, void* dk, void* dvt,
+                              void* scratch, int B, int T, int C, hipStream_t s) {
+    if ((T != 64 && T != 256) || (C % 32)) return (int)hipErrorInvalidValue;
+    char* p = (char*)scratch;
+    auto take = [&](size_t bytes) {
+        void* r = p;
+        p += (bytes + 255) & ~(size_t)255;
+        return r;
+    };
+    const size_t tc = (size_t)B * T * C * 2, tt2 = (size_t)B * T * T * 2, tt4 = (size_t)B * T * T * 4;
+    void *v = take(tc), *kT = take(tc), *qT = take(tc), *dOT = take(tc);
+    void *P = take(tt2), *PT = take(tt2), *dS = take(tt2), *dST = take(tt2);
+    float *S = (float*)take(tt4), *dP = (float*)take(tt4);
+    const float sc = 1.0f / sqrtf((float)C);
+    transpose(vt, v, B, C, T, s);   // v [T][C]
+    transpose(k, kT, B, T, C, s);   // k^T [C][T]
+    transpose(q, qT, B, T, C, s);
+    transpose(dO, dOT, B, T, C, s);
+    nt_gemm<false>(q, k, S, B, T, T, C, 1.0f, s);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((size_t)B * T)), dim3(T), 0, s, S, (__bf16*)P, T, sc);
+    nt_gemm<false>(dO, v, dP, B, T, T, C, 1.0f, s);
+    hipLaunchKernelGGL(attn_ds_kernel, dim3((unsigned)((size_t)B * T)), dim3(T), 0, s, (const __bf16*)P, dP, (__bf16*)dS, T);
+    transpose(P, PT, B, T, T, s);
+    transpose(dS, dST, B, T, T, s);
+    nt_gemm<true>(dS, kT, dq, B, T, C, T, sc, s);    // dq[q][c] = sum_k dS[q][k] k[k][c]
+    nt_gemm<true>(dST, qT, dk, B, T, C, T, sc, s);   // dk[k][c] = sum_q dS[q][k] q[q][c]
+    nt_gemm<true>(dOT, PT, dvt, B, C, T, T, 1.0f, s);  // dv^T[c][k] = sum_q dO[q][c] P[q][k]
+    return (int)hipGetLastError();
+}
+
+int launch_qkv_interleave(const void* dq, const void* dk, const void* dvt, void* out, int B, int T, int C, hipStream_t s) {
+    const int64_t total = (int64_t)B * T * C;
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(qkv_interleave_kernel, dim3((unsigned)(blocks > 65536 ? 65536 : blocks)), dim3(256), 0, s, (const __bf16*)dq,
+                       (const __bf16*)dk, (const __bf16*)dvt, (__bf16*)out, T, C, total);
+    return (int)hipGetLastError();
+}

@@ -91,7 +91,7 @@ struct Act {
 struct Workspace {
     float *coef, *emb0, *emb1, *emb, *temb;
     float2 *ab0, *ab1, *ab2;
-    float2 *mr0 = nullptr, *mr1 = nullptr;  // {mean, rstd} of norm0 / norm1, kept when a backward pass follows
+    float2 *mr0 = nullptr, *mr1 = nullptr, *mr2 = nullptr;  // {mean, rstd} of norm0 / norm1 / norm2, kept when a backward pass follows
     std::vector<Act> skip;  // encoder outputs
     Act xa, xb, h, xattn;
     void *sbuf, *aout, *pool;
@@ -465,7 +465,7 @@ int run_block(fg_edm* h, const Block& b, const Act& x1, int c1, const Act& x2, i
     HIP_TRY(conv_launch(h, 3, PRO_GN_SILU, RES_NONE, OUT_NHWC, d, s));
     x_mid.slots = slots;
     if (b.attn) {
-        HIP_TRY(launch_gn_finalize(x_mid.st, b.cout, slots, nullptr, 0, 0, h->P(b.norm2_w), h->P(b.norm2_b), kBlockEps, w.ab2, B, hw, s));
+        HIP_TRY(launch_gn_finalize(x_mid.st, b.cout, slots, nullptr, 0, 0, h->P(b.norm2_w), h->P(b.norm2_b), kBlockEps, w.ab2, B, hw, s, w.mr2));
         ConvArgs q{};
         q.src1 = x_mid.p; q.C1 = b.cout; q.Hs = q.Ws = q.H = q.W = b.res_out; q.B = B;
         q.ab = w.ab2; q.wpack = b.p_qkv; q.bias = b.qkv_bias; q.scale = 1.0f; q.Cout = 3 * b.cout;
@@ -1060,12 +1060,13 @@ int fg_edm_run_block(fg_edm* h, int index, const float* x1, int c1, const float*
 namespace {
 struct BwdScratch {
     void *g1, *aop, *da, *dh0, *dskip, *dxin, *wpk, *wg;
-    float2 *P, *S, *mr0, *mr1;
+    void *gmid = nullptr, *dq = nullptr, *dk = nullptr, *dvt = nullptr, *dqkv = nullptr, *att = nullptr;  // attention blocks only
+    float2 *P, *S, *mr0, *mr1, *mr2;
     float *dtemb, *wt;
     size_t wg_bytes;
 };
 int pad256(int c) { return (c + 255) / 256 * 256; }
-size_t plan_block_bwd(int B, int res_in, int res, int cin, int cout, Arena& A, BwdScratch& q) {
+size_t plan_block_bwd(int B, int res_in, int res, int cin, int cout, Arena& A, BwdScratch& q, bool attn = false) {
     const size_t npix = (size_t)B * res * res, npix_in = (size_t)B * res_in * res_in;
     const int cp = pad256(cin), cm = cin > cout ? cin : cout;
     q.g1 = A.take(npix * cout * 2);
@@ -1078,7 +1079,16 @@ size_t plan_block_bwd(int B, int res_in, int res, int cin, int cout, Arena& A, B
     q.S = A.get<float2>((size_t)B * 32);
     q.mr0 = A.get<float2>((size_t)B * 32);
     q.mr1 = A.get<float2>((size_t)B * 32);
-    q.dtemb = A.get<float>((size_t)B * cout);
+    q.mr2 = A.get<float2>((size_t)B * 32);
+    q.dtemb = A.get<float>((size_t)B * cout * 3);
+    if (attn) {
+        q.gmid = A.take(npix * cout * 2);
+        q.dq = A.take(npix * cout * 2);
+        q.dk = A.take(npix * cout * 2);
+        q.dvt = A.take(npix * cout * 2);
+        q.dqkv = A.take(npix * cout * 3 * 2);
+        q.att = A.take(attention_backward_scratch_bytes(B, res * res, cout));
+    }
     const size_t welems = (size_t)(cp > cout ? cp : cout) * (cin > cout ? cin : cout) * 9;
     q.wt = A.get<float>(welems);
     q.wpk = A.take(welems * 2);
@@ -1087,6 +1097,7 @@ size_t plan_block_bwd(int B, int res_in, int res, int cin, int cout, Arena& A, B
     for (auto& sh : shapes)
         if (conv_wgrad_supported(res, sh[0], sh[1], sh[2]))
             q.wg_bytes = std::max(q.wg_bytes, conv_wgrad_workspace_bytes(B, res, sh[0], sh[1], sh[2]));
+    if (attn) q.wg_bytes = std::max(q.wg_bytes, conv_wgrad_workspace_bytes(B, res, cout, 3 * cout, 1));
     q.wg = A.take(q.wg_bytes);
     return A.off;
 }
@@ -1109,7 +1120,6 @@ int conv_dgrad(fg_edm* h, const float* w_oihw, int cout, int cin, int ks, const 
 // accumulated.  The block's forward is recomputed here (activation checkpointing at block granularity).
 int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& a2, int c2, const float* emb, const float* temb,
                    const void* gout, void* dxin, float* demb, int B, Workspace& w, BwdScratch& q, hipStream_t s) {
-    if (b.attn) return fail(FG_EINVAL, "%s: backward of attention blocks is not implemented yet", b.key.c_str());
     const int res = b.res_out, res_in = b.res_in, hw = res * res, cin = b.cin, cout = b.cout, cp = pad256(cin);
     const int rm = b.down ? 1 : (b.up ? 2 : 0);
     if (!conv_wgrad_supported(res, cout, cout, 3) || !conv_wgrad_supported(res, cin, cout, 3))
@@ -1117,10 +1127,34 @@ int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& 
     const size_t npix = (size_t)B * hw;
     w.mr0 = q.mr0;
     w.mr1 = q.mr1;
+    w.mr2 = q.mr2;
     int rc = run_block(h, b, a1, c1, a2, c2, temb, w.xa, B, w, s);
-    w.mr0 = w.mr1 = nullptr;
+    w.mr0 = w.mr1 = w.mr2 = nullptr;
     if (rc) return rc;
-    // out = (conv1(act1) + skip) * sigma  =>  g1 = sigma * gout reaches conv1's output and the skip path alike
+    if (b.attn) {
+        // out = (proj(attention(qkv(norm2(x_mid)))) + x_mid) * sigma, EDM/network.py:290-298.  g2 = sigma * gout.
+        if (!q.att) return fail(FG_EINVAL, "%s: scratch was planned without the attention part", b.key.c_str());
+        const int C3 = 3 * cout;
+        HIP_TRY(launch_scale_bf16(gout, q.g1, kSkipScale, (int64_t)npix * cout, s));
+        HIP_TRY(launch_colsum(q.g1, cout, cout, q.dtemb, B, hw, 1.0f, s));
+        if (h->G(b.proj_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.proj_b), B, cout, s));
+        if (h->G(b.proj_w)) HIP_TRY(launch_conv_wgrad(w.aout, q.g1, h->G(b.proj_w), B, res, cout, cout, 1, 1, q.wg, s));
+        if ((rc = conv_dgrad(h, h->P(b.proj_w), cout, cout, 1, q.g1, q.da, B, res, q, s))) return rc;
+        HIP_TRY(launch_attention_backward(w.q, w.k, w.vt, q.da, q.dq, q.dk, q.dvt, q.att, B, hw, cout, s));
+        HIP_TRY(launch_qkv_interleave(q.dq, q.dk, q.dvt, q.dqkv, B, hw, cout, s));
+        HIP_TRY(launch_colsum(q.dqkv, C3, C3, q.dtemb, B, hw, 1.0f, s));
+        if (h->G(b.qkv_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.qkv_b), B, C3, s));
+        if (h->G(b.qkv_w)) {
+            HIP_TRY(launch_gn_act(1, w.xattn.p, cout, nullptr, 0, w.ab2, q.aop, B, res, 0, s));
+            HIP_TRY(launch_conv_wgrad(q.aop, q.dqkv, h->G(b.qkv_w), B, res, cout, C3, 1, 1, q.wg, s));
+        }
+        if ((rc = conv_dgrad(h, h->P(b.qkv_w), C3, cout, 1, q.dqkv, q.da, B, res, q, s))) return rc;
+        // norm2 (no activation); the residual x_mid -> out contributes g2 directly
+        HIP_TRY(launch_gn_bwd(1, w.xattn.p, cout, nullptr, 0, q.da, pad256(cout), w.ab2, q.mr2, h->P(b.norm2_w), q.P, q.S,
+                              h->G(b.norm2_w), h->G(b.norm2_b), q.g1, cout, 1.0f, q.gmid, B, res, 0, s));
+        gout = q.gmid;
+    }
+    // x_mid = (conv1(act1) + skip) * sigma  =>  g1 = sigma * gout reaches conv1's output and the skip path alike
     HIP_TRY(launch_scale_bf16(gout, q.g1, kSkipScale, (int64_t)npix * cout, s));
     HIP_TRY(launch_colsum(q.g1, cout, cout, q.dtemb, B, hw, 1.0f, s));
     if (h->G(b.conv1_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.conv1_b), B, cout, s));
@@ -1180,7 +1214,7 @@ size_t fg_edm_block_backward_workspace_bytes(const fg_edm* h, int index, int bat
     Workspace w;
     plan_workspace(h, batch, A, w);
     BwdScratch q;
-    plan_block_bwd(batch, b.res_in, b.res_out, b.cin, b.cout, A, q);
+    plan_block_bwd(batch, b.res_in, b.res_out, b.cin, b.cout, A, q, b.attn);
     A.take((size_t)batch * b.res_out * b.res_out * b.cout * 2);  // gout in bf16
     return A.off;
 }
@@ -1201,7 +1235,7 @@ int fg_edm_run_block_backward(fg_edm* h, int index, const float* x1, int c1, con
     Workspace w;
     plan_workspace(h, B, A, w);
     BwdScratch q;
-    plan_block_bwd(B, b.res_in, b.res_out, b.cin, b.cout, A, q);
+    plan_block_bwd(B, b.res_in, b.res_out, b.cin, b.cout, A, q, b.attn);
     const size_t npix = (size_t)B * b.res_out * b.res_out, npix_in = (size_t)B * b.res_in * b.res_in;
     void* gout = A.take(npix * b.cout * 2);
     if (A.off > workspace_bytes) return fail(FG_ENOMEM, "workspace too small: need %zu bytes, got %zu", A.off, workspace_bytes);

@@ -43,6 +43,11 @@ int launch_scale_bf16(const void* in, void* out, float scale, int64_t total, hip
 int launch_slice_to_f32(const void* in, int cs, int c_off, float* out, int C, int64_t npix, hipStream_t s);
 int launch_affine_bwd(const float* dtemb, const float* emb, const float* w, float* dw, float* demb, int B, int C, int K, hipStream_t s);
 int launch_dgrad_weights(const float* w, float* wt, int cout, int cin, int cin_pad, int taps, hipStream_t s);
+// attn_bwd.hip
+size_t attention_backward_scratch_bytes(int B, int T, int C);
+int launch_attention_backward(const void* q, const void* k, const void* vt, const void* dO, void* dq, void* dk, void* dvt,
+                              void* scratch, int B, int T, int C, hipStream_t s);
+int launch_qkv_interleave(const void* dq, const void* dk, const void* dvt, void* out, int B, int T, int C, hipStream_t s);
 // wgrad.hip: weight gradient of a 3x3 / 1x1 convolution (training step)
 int conv_wgrad_supported(int res, int cin, int cout, int ks);
 size_t conv_wgrad_workspace_bytes(int B, int res, int cin, int cout, int ks);

@@ -204,6 +204,9 @@ BWD_CASES = {
     "dec_cat384": ("32x32_block4_dec", 1),  # 384 -> 256 (12 channels per group), 1x1 skip
     "enc_down": ("16x16_down", 1),  # 32 -> 16: 2x2 average in conv0 and in the skip conv
     "dec_up": ("16x16_up_dec", 2),  # 8 -> 16: nearest up-sampling in conv0 and in the skip conv
+    "enc_attn": ("16x16_block1", 2),  # 256 -> 256 + attention, T = 256
+    "dec_in0": ("8x8_in0_dec", 2),  # attention, T = 64
+    "dec_cat_attn": ("16x16_block4_dec", 1),  # 512 -> 256 (concat) + attention
 }
 
 

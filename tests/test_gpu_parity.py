@@ -607,7 +607,8 @@ def test_conv_wgrad_rejects_bad_arguments():
 BWD_BLOCKS = {"enc_first": "32x32_block0", "enc_plain": "8x8_block1", "dec_cat512": "16x16_block1", "dec_cat384": "32x32_block4"}
 
 
-@pytest.mark.parametrize("case", ["enc_first", "enc_plain", "dec_cat512", "dec_cat384", "enc_down", "dec_up"])
+@pytest.mark.parametrize("case", ["enc_first", "enc_plain", "dec_cat512", "dec_cat384", "enc_down", "dec_up", "enc_attn", "dec_in0",
+                                  "dec_cat_attn"])
 def test_block_backward_against_reference_golden(nets, sd, golden_dir, case):
     """d/dx, d/demb and every parameter gradient of one UNetBlock (bf16 compute) against (1) autograd through the oracle in
     fp32 on the same operands — relative L2 <= 2e-2 per tensor (bf16 activations and activation gradients) — and (2) the
