@@ -301,6 +301,71 @@ __global__ void dgrad_weights_kernel(const float* __restrict__ w, float* __restr
     }
 }
 
+// ---- whole-network pieces ------------------------------------------------------------------------------------------------------
+// gradient entering the output head: dF = c_out[n] * dout (precond_output, EDM/network.py:798-805), NCHW fp32 -> NHWC bf16 padded
+// with zero channels to Cp (the matrix-core kernels' granularity)
+__global__ void head_grad_kernel(const float* __restrict__ dout, const float* __restrict__ c_out, __bf16* __restrict__ out, int C,
+                                 int Cp, int HW, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Cp);
+        const int64_t pix = i / Cp;
+        const int64_t n = pix / HW, p = pix - n * HW;
+        out[i] = c < C ? (__bf16)(c_out[n] * dout[(n * C + c) * HW + p]) : (__bf16)0.f;
+    }
+}
+// the stem conv's operand: c_in[n] * x_t (precond_input :771-773), NCHW fp32 -> NHWC bf16 padded to Cp channels
+__global__ void stem_operand_kernel(const float* __restrict__ x, const float* __restrict__ c_in, __bf16* __restrict__ out, int C,
+                                    int Cp, int HW, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Cp);
+        const int64_t pix = i / Cp;
+        const int64_t n = pix / HW, p = pix - n * HW;
+        out[i] = c < C ? (__bf16)(c_in[n] * x[(n * C + c) * HW + p]) : (__bf16)0.f;
+    }
+}
+// dst[o][i][t] += src[o][i][t] for o < O, i < I out of a padded [Os][Is][T] tensor
+__global__ void add_sub_tensor_kernel(const float* __restrict__ src, int Is, float* __restrict__ dst, int O, int I, int T) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= O * I * T) return;
+    const int t = idx % T, i = (idx / T) % I, o = idx / (T * I);
+    dst[idx] += src[((size_t)o * Is + i) * T + t];
+}
+// padded conv weight: dst[o][i][t] = o < O ? src[o][i][t] : 0 for o < Op
+__global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int O, int Op, int IT) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Op * IT) return;
+    dst[idx] = (idx / IT) < O ? src[idx] : 0.f;
+}
+__global__ void add_bf16_kernel(__bf16* __restrict__ dst, const __bf16* __restrict__ src, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+        dst[i] = (__bf16)((float)dst[i] + (float)src[i]);
+}
+// dst[p][c] (=|+=) src[p][off + c]
+__global__ void slice_bf16_kernel(const __bf16* __restrict__ src, int Cs, int off, __bf16* __restrict__ dst, int C, int64_t npix,
+                                  int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix * C; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = i / C;
+        const int c = (int)(i - p * C);
+        const float v = (float)src[p * Cs + off + c];
+        dst[i] = (__bf16)(accumulate ? (float)dst[i] + v : v);
+    }
+}
+// dpre = dy * silu'(pre)   (map_layer0 / map_layer1, EDM/network.py:520-521)
+__global__ void silu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dpre, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) dpre[i] = dy[i] * silu_grad(pre[i]);
+}
+// dW[c][k] += scale * sum_b dy[b][c] x[b][k]
+__global__ void linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, int B, int C,
+                                    int K, float scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * K) return;
+    const int c = i / K, k = i - c * K;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a = fmaf(dy[(size_t)b * C + c], x[(size_t)b * K + k], a);
+    dw[i] += a * scale;
+}
+
 inline unsigned ew_blocks(int64_t n) {
     const int64_t b = (n + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
@@ -376,5 +441,43 @@ int launch_affine_bwd(const float* dtemb, const float* emb, const float* w, floa
 }
 int launch_dgrad_weights(const float* w, float* wt, int cout, int cin, int cin_pad, int taps, hipStream_t s) {
     hipLaunchKernelGGL(dgrad_weights_kernel, dim3(ew_blocks((int64_t)cin_pad * cout * taps)), dim3(256), 0, s, w, wt, cout, cin, cin_pad, taps);
+    BWD_RET();
+}
+int launch_head_grad(const float* dout, const float* c_out, void* out, int B, int C, int Cp, int hw, hipStream_t s) {
+    const int64_t total = (int64_t)B * hw * Cp;
+    hipLaunchKernelGGL(head_grad_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dout, c_out, (__bf16*)out, C, Cp, hw, total);
+    BWD_RET();
+}
+int launch_stem_operand(const float* x, const float* c_in, void* out, int B, int C, int Cp, int hw, hipStream_t s) {
+    const int64_t total = (int64_t)B * hw * Cp;
+    hipLaunchKernelGGL(stem_operand_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, c_in, (__bf16*)out, C, Cp, hw, total);
+    BWD_RET();
+}
+int launch_add_sub_tensor(const float* src, int Is, float* dst, int O, int I, int T, hipStream_t s) {
+    hipLaunchKernelGGL(add_sub_tensor_kernel, dim3((O * I * T + 255) / 256), dim3(256), 0, s, src, Is, dst, O, I, T);
+    BWD_RET();
+}
+int launch_pad_rows(const float* src, float* dst, int O, int Op, int IT, hipStream_t s) {
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((Op * IT + 255) / 256), dim3(256), 0, s, src, dst, O, Op, IT);
+    BWD_RET();
+}
+int launch_add_bf16(void* dst, const void* src, int64_t total, hipStream_t s) {
+    hipLaunchKernelGGL(add_bf16_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, (__bf16*)dst, (const __bf16*)src, total);
+    BWD_RET();
+}
+int launch_slice_bf16(const void* src, int cs, int off, void* dst, int C, int64_t npix, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(slice_bf16_kernel, dim3(ew_blocks(npix * C)), dim3(256), 0, s, (const __bf16*)src, cs, off, (__bf16*)dst, C, npix, accumulate);
+    BWD_RET();
+}
+int launch_silu_bwd(const float* dy, const float* pre, float* dpre, int total, hipStream_t s) {
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, s, dy, pre, dpre, total);
+    BWD_RET();
+}
+// Linear backward: dw[C][K] += scale * dy^T x, db[C] += sum_b dy, dx[B][K] += dy w  (each optional)
+int launch_linear_bwd(const float* dy, const float* x, const float* w, float* dw, float* db, float* dx, int B, int C, int K,
+                      float scale, hipStream_t s) {
+    if (dw) hipLaunchKernelGGL(linear_wgrad_kernel, dim3((C * K + 255) / 256), dim3(256), 0, s, dy, x, dw, B, C, K, scale);
+    if (db) hipLaunchKernelGGL(batchsum_add_kernel, dim3((C + 255) / 256), dim3(256), 0, s, dy, db, B, C);
+    if (dx) hipLaunchKernelGGL(affine_dgrad_kernel, dim3((B * K + 255) / 256), dim3(256), 0, s, dy, w, dx, B, C, K);
     BWD_RET();
 }

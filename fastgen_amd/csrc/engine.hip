@@ -501,7 +501,7 @@ int run_mapping(fg_edm* h, const float* labels, int B, Workspace& w, hipStream_t
 // (SongUNet.forward feature taps, EDM/network.py:535-539) or nullptr; early: return after the encoder (:542-544).
 int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, const double* r, int r_stride,
                 const float* labels, float* out, int B, Workspace& w, hipStream_t s, float* const* feats = nullptr,
-                bool early = false) {
+                bool early = false, std::vector<Act>* dec_store = nullptr) {
     const fg_edm_config& c = h->cfg;
     HIP_TRY(launch_precond_coef(t, t_stride, c.r_timestep ? r : nullptr, r_stride, c.sigma_data, c.sigma_shift, 1e-6,
                                 c.drop_precond, w.coef, B, s));
@@ -533,13 +533,16 @@ int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, cons
     int sp = (int)h->enc.size();
     Act* pong[2] = {&w.xa, &w.xb};
     int cur = 0;
+    size_t di = 0;
     const float2* aux_ab = nullptr;
     for (const Block& b : h->dec) {
         if (b.kind == K_BLOCK) {
             const Act& x2 = b.skip_c ? w.skip[--sp] : none;
-            rc = run_block(h, b, *x, b.cin - b.skip_c, x2, b.skip_c, w.temb, *pong[cur], B, w, s);
+            // a backward pass follows: every block output is kept (dec_store) instead of ping-ponging two buffers
+            Act& dst = dec_store ? (*dec_store)[di++] : *pong[cur];
+            rc = run_block(h, b, *x, b.cin - b.skip_c, x2, b.skip_c, w.temb, dst, B, w, s);
             if (rc) return rc;
-            x = pong[cur];
+            x = &dst;
             cur ^= 1;
         } else if (b.kind == K_AUX_NORM) {
             if ((rc = norm_coeffs(h->dtype, *x, b.cin, none, 0, h->P(b.w), h->P(b.b), w.ab0, B, b.res_in * b.res_in, s))) return rc;
@@ -1066,7 +1069,16 @@ struct BwdScratch {
     size_t wg_bytes;
 };
 int pad256(int c) { return (c + 255) / 256 * 256; }
-size_t plan_block_bwd(int B, int res_in, int res, int cin, int cout, Arena& A, BwdScratch& q, bool attn = false) {
+// split-K scratch the weight-gradient kernel needs for one block's convolutions (the split count depends on every dimension)
+size_t block_wgrad_bytes(int B, int res, int cin, int cout, bool attn) {
+    size_t m = 0;
+    const int shapes[5][3] = {{cout, cout, 3}, {cin, cout, 3}, {cin, cout, 1}, {cout, 3 * cout, 1}, {cout, cout, 1}};
+    for (int i = 0; i < (attn ? 5 : 3); ++i)
+        if (conv_wgrad_supported(res, shapes[i][0], shapes[i][1], shapes[i][2]))
+            m = std::max(m, conv_wgrad_workspace_bytes(B, res, shapes[i][0], shapes[i][1], shapes[i][2]));
+    return m;
+}
+size_t plan_block_bwd(int B, int res_in, int res, int cin, int cout, Arena& A, BwdScratch& q, int attn_hw = 0, size_t wg_bytes = 0) {
     const size_t npix = (size_t)B * res * res, npix_in = (size_t)B * res_in * res_in;
     const int cp = pad256(cin), cm = cin > cout ? cin : cout;
     q.g1 = A.take(npix * cout * 2);
@@ -1081,23 +1093,18 @@ size_t plan_block_bwd(int B, int res_in, int res, int cin, int cout, Arena& A, B
     q.mr1 = A.get<float2>((size_t)B * 32);
     q.mr2 = A.get<float2>((size_t)B * 32);
     q.dtemb = A.get<float>((size_t)B * cout * 3);
-    if (attn) {
+    if (attn_hw) {
         q.gmid = A.take(npix * cout * 2);
         q.dq = A.take(npix * cout * 2);
         q.dk = A.take(npix * cout * 2);
         q.dvt = A.take(npix * cout * 2);
         q.dqkv = A.take(npix * cout * 3 * 2);
-        q.att = A.take(attention_backward_scratch_bytes(B, res * res, cout));
+        q.att = A.take(attention_backward_scratch_bytes(B, attn_hw, cout));
     }
     const size_t welems = (size_t)(cp > cout ? cp : cout) * (cin > cout ? cin : cout) * 9;
     q.wt = A.get<float>(welems);
     q.wpk = A.take(welems * 2);
-    q.wg_bytes = 0;
-    const int shapes[3][3] = {{cout, cout, 3}, {cin, cout, 3}, {cin, cout, 1}};
-    for (auto& sh : shapes)
-        if (conv_wgrad_supported(res, sh[0], sh[1], sh[2]))
-            q.wg_bytes = std::max(q.wg_bytes, conv_wgrad_workspace_bytes(B, res, sh[0], sh[1], sh[2]));
-    if (attn) q.wg_bytes = std::max(q.wg_bytes, conv_wgrad_workspace_bytes(B, res, cout, 3 * cout, 1));
+    q.wg_bytes = wg_bytes ? wg_bytes : block_wgrad_bytes(B, res, cin, cout, attn_hw != 0);
     q.wg = A.take(q.wg_bytes);
     return A.off;
 }
@@ -1112,6 +1119,15 @@ int conv_dgrad(fg_edm* h, const float* w_oihw, int cout, int cin, int ks, const 
     a.Hs = a.Ws = a.H = a.W = res; a.B = B;
     a.wpack = q.wpk; a.scale = 1.0f; a.out = out; a.Cout = cp;
     HIP_TRY(launch_conv_fused(1, ks, PRO_NONE, RES_NONE, OUT_NHWC, a, s));
+    return FG_OK;
+}
+
+// weight gradient with a host-side check of the split-K scratch (an undersized scratch would be an out-of-bounds write)
+int wgrad_checked(const void* act, const void* dy, float* dw, int B, int res, int cin, int cout, int ks, int accumulate, void* wg,
+                  size_t wg_bytes, hipStream_t s) {
+    const size_t need = conv_wgrad_workspace_bytes(B, res, cin, cout, ks);
+    if (need > wg_bytes) return fail(FG_ENOMEM, "weight-gradient scratch too small: %zu > %zu (res %d, %d -> %d, k%d)", need, wg_bytes, res, cin, cout, ks);
+    HIP_TRY(launch_conv_wgrad(act, dy, dw, B, res, cin, cout, ks, accumulate, wg, s));
     return FG_OK;
 }
 
@@ -1138,7 +1154,7 @@ int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& 
         HIP_TRY(launch_scale_bf16(gout, q.g1, kSkipScale, (int64_t)npix * cout, s));
         HIP_TRY(launch_colsum(q.g1, cout, cout, q.dtemb, B, hw, 1.0f, s));
         if (h->G(b.proj_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.proj_b), B, cout, s));
-        if (h->G(b.proj_w)) HIP_TRY(launch_conv_wgrad(w.aout, q.g1, h->G(b.proj_w), B, res, cout, cout, 1, 1, q.wg, s));
+        if (h->G(b.proj_w)) if ((rc = wgrad_checked(w.aout, q.g1, h->G(b.proj_w), B, res, cout, cout, 1, 1, q.wg, q.wg_bytes, s))) return rc;
         if ((rc = conv_dgrad(h, h->P(b.proj_w), cout, cout, 1, q.g1, q.da, B, res, q, s))) return rc;
         HIP_TRY(launch_attention_backward(w.q, w.k, w.vt, q.da, q.dq, q.dk, q.dvt, q.att, B, hw, cout, s));
         HIP_TRY(launch_qkv_interleave(q.dq, q.dk, q.dvt, q.dqkv, B, hw, cout, s));
@@ -1146,7 +1162,7 @@ int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& 
         if (h->G(b.qkv_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.qkv_b), B, C3, s));
         if (h->G(b.qkv_w)) {
             HIP_TRY(launch_gn_act(1, w.xattn.p, cout, nullptr, 0, w.ab2, q.aop, B, res, 0, s));
-            HIP_TRY(launch_conv_wgrad(q.aop, q.dqkv, h->G(b.qkv_w), B, res, cout, C3, 1, 1, q.wg, s));
+            if ((rc = wgrad_checked(q.aop, q.dqkv, h->G(b.qkv_w), B, res, cout, C3, 1, 1, q.wg, q.wg_bytes, s))) return rc;
         }
         if ((rc = conv_dgrad(h, h->P(b.qkv_w), C3, cout, 1, q.dqkv, q.da, B, res, q, s))) return rc;
         // norm2 (no activation); the residual x_mid -> out contributes g2 directly
@@ -1162,7 +1178,7 @@ int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& 
     // conv1
     if (h->G(b.conv1_w)) {
         HIP_TRY(launch_gn_act(0, w.h.p, cout, nullptr, 0, w.ab1, q.aop, B, res, 0, s));
-        HIP_TRY(launch_conv_wgrad(q.aop, q.g1, h->G(b.conv1_w), B, res, cout, cout, 3, 1, q.wg, s));
+        if ((rc = wgrad_checked(q.aop, q.g1, h->G(b.conv1_w), B, res, cout, cout, 3, 1, q.wg, q.wg_bytes, s))) return rc;
     }
     if ((rc = conv_dgrad(h, h->P(b.conv1_w), cout, cout, 3, q.g1, q.da, B, res, q, s))) return rc;
     // norm1 + silu
@@ -1176,7 +1192,7 @@ int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& 
     // conv0: its operand is silu(norm0(x)), resampled to the output resolution
     if (h->G(b.conv0_w)) {
         HIP_TRY(launch_gn_act(0, a1.p, c1, a2.p, c2, w.ab0, q.aop, B, res, rm, s));
-        HIP_TRY(launch_conv_wgrad(q.aop, q.dh0, h->G(b.conv0_w), B, res, cin, cout, 3, 1, q.wg, s));
+        if ((rc = wgrad_checked(q.aop, q.dh0, h->G(b.conv0_w), B, res, cin, cout, 3, 1, q.wg, q.wg_bytes, s))) return rc;
     }
     if ((rc = conv_dgrad(h, h->P(b.conv0_w), cout, cin, 3, q.dh0, q.da, B, res, q, s))) return rc;
     // skip path: its gradient joins dx_in inside the norm0 backward pass (both live at the output resolution)
@@ -1185,7 +1201,7 @@ int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& 
     if (b.has_skip) {
         if (h->G(b.skip_w)) {
             HIP_TRY(launch_gn_act(2, a1.p, c1, a2.p, c2, nullptr, q.aop, B, res, rm, s));
-            HIP_TRY(launch_conv_wgrad(q.aop, q.g1, h->G(b.skip_w), B, res, cin, cout, 1, 1, q.wg, s));
+            if ((rc = wgrad_checked(q.aop, q.g1, h->G(b.skip_w), B, res, cin, cout, 1, 1, q.wg, q.wg_bytes, s))) return rc;
         }
         if ((rc = conv_dgrad(h, h->P(b.skip_w), cout, cin, 1, q.g1, q.dskip, B, res, q, s))) return rc;
         add = q.dskip;
@@ -1195,7 +1211,210 @@ int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& 
                           add, ca, 1.0f, dxin, B, res_in, rm, s));
     return FG_OK;
 }
+
+// ---- whole network: forward keeping every block input, then the blocks in reverse ----------------------------------------------
+struct NetBwd {
+    std::vector<Act> dec_store;   // decoder block outputs
+    std::vector<void*> genc;      // gradient w.r.t. each encoder output (bf16)
+    void *ga, *gb;                // running gradient, ping-pong
+    void *dfp, *op32;             // padded head gradient [npix][128], padded stem operand [npix][32]
+    float *wtmp, *wpad, *vec;     // padded weight-gradient / weight scratch, small vector scratch
+    float *demb, *pre, *d1, *d0;  // embedding MLP
+    void* wgx;                    // split-K scratch of the head / stem weight gradients
+    size_t wgx_bytes;
+    BwdScratch q;
+};
+size_t plan_net_bwd(const fg_edm* h, int B, Arena& A, NetBwd& nb) {
+    const size_t tsz = 2;
+    size_t max_act = 0, max_in = 0;
+    int max_res = 0, max_cin = 0, attn_hw = 0;
+    size_t wg_max = 0;
+    const size_t st_elems = (size_t)B * 8 * 64;
+    nb.dec_store.clear();
+    nb.genc.clear();
+    for (const Block& b : h->enc) {
+        nb.genc.push_back(A.take((size_t)B * b.res_out * b.res_out * b.cout * tsz));
+        max_act = std::max(max_act, (size_t)b.res_out * b.res_out * b.cout);
+    }
+    for (const Block& b : h->dec) {
+        if (b.kind != K_BLOCK) continue;
+        Act a;
+        a.p = A.take((size_t)B * b.res_out * b.res_out * b.cout * tsz);
+        a.st = A.get<float2>(st_elems);
+        nb.dec_store.push_back(a);
+    }
+    for (const Block* b : h->blocks) {
+        max_act = std::max(max_act, (size_t)b->res_out * b->res_out * b->cout);
+        max_in = std::max(max_in, (size_t)b->res_in * b->res_in * b->cin);
+        max_res = std::max(max_res, std::max(b->res_in, b->res_out));
+        max_cin = std::max(max_cin, b->cin);
+        if (b->attn) attn_hw = std::max(attn_hw, b->res_out * b->res_out);
+        wg_max = std::max(wg_max, block_wgrad_bytes(B, b->res_out, b->cin, b->cout, b->attn));
+    }
+    nb.ga = A.take((size_t)B * std::max(max_act, max_in) * tsz);
+    nb.gb = A.take((size_t)B * std::max(max_act, max_in) * tsz);
+    const size_t npix = (size_t)B * h->cfg.img_resolution * h->cfg.img_resolution;
+    nb.dfp = A.take(npix * 128 * tsz);
+    nb.op32 = A.take(npix * 32 * tsz);
+    nb.wtmp = A.get<float>((size_t)128 * 256 * 9);
+    nb.wpad = A.get<float>((size_t)128 * 256 * 9);
+    nb.vec = A.get<float>(1024);
+    nb.demb = A.get<float>((size_t)B * h->emb_ch);
+    nb.pre = A.get<float>((size_t)B * h->emb_ch);
+    nb.d1 = A.get<float>((size_t)B * h->emb_ch);
+    nb.d0 = A.get<float>((size_t)B * std::max(h->cond_ch, h->emb_ch));
+    nb.wgx_bytes = std::max(conv_wgrad_workspace_bytes(B, h->cfg.img_resolution, 256, 128, 3),
+                            conv_wgrad_workspace_bytes(B, h->cfg.img_resolution, 32, 128, 3));
+    nb.wgx = A.take(nb.wgx_bytes);
+    plan_block_bwd(B, max_res, max_res, max_cin, 256, A, nb.q, attn_hw, wg_max);
+    return A.off;
+}
+
+int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* dout, float* out,
+                 int B, Workspace& w, NetBwd& nb, hipStream_t s) {
+    const fg_edm_config& c = h->cfg;
+    const int res = c.img_resolution, hw = res * res;
+    const size_t npix = (size_t)B * hw;
+    BwdScratch& q = nb.q;
+    int rc = run_forward(h, x_t, t, 1, r, 1, labels, out, B, w, s, nullptr, false, &nb.dec_store);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(nb.demb, 0, sizeof(float) * (size_t)B * h->emb_ch, s));
+    const Block *aux_norm = nullptr, *aux_conv = nullptr;
+    for (const Block& b : h->dec) {
+        if (b.kind == K_AUX_NORM) aux_norm = &b;
+        if (b.kind == K_AUX_CONV) aux_conv = &b;
+    }
+    if (!aux_norm || !aux_conv || aux_conv->cin != 256 || aux_conv->cout > 8 || h->enc[0].cout != 128 || h->enc[0].cin > 8)
+        return fail(FG_EINVAL, "backward: head / stem shape not covered (needs model_channels 128, 256-channel head)");
+    const Act none;
+    // ---- output head: F = aux_conv(silu(aux_norm(y))), out = c_skip x + c_out F ------------------------------------------------
+    const Act& y = nb.dec_store.back();
+    if ((rc = norm_coeffs(1, y, 256, none, 0, h->P(aux_norm->w), h->P(aux_norm->b), w.ab0, B, hw, s, q.mr0))) return rc;
+    HIP_TRY(launch_head_grad(dout, w.coef + 3 * (size_t)B, nb.dfp, B, aux_conv->cout, 128, hw, s));
+    if (h->G(aux_conv->b)) {
+        HIP_TRY(launch_colsum(nb.dfp, 128, 8, q.dtemb, B, hw, 1.0f, s));
+        HIP_TRY(hipMemsetAsync(nb.vec, 0, sizeof(float) * 8, s));
+        HIP_TRY(launch_batchsum_add(q.dtemb, nb.vec, B, 8, s));
+        HIP_TRY(launch_add_sub_tensor(nb.vec, 8, h->G(aux_conv->b), 1, aux_conv->cout, 1, s));
+    }
+    if (h->G(aux_conv->w)) {
+        HIP_TRY(launch_gn_act(0, y.p, 256, nullptr, 0, w.ab0, q.aop, B, res, 0, s));
+        if ((rc = wgrad_checked(q.aop, nb.dfp, nb.wtmp, B, res, 256, 128, 3, 0, nb.wgx, nb.wgx_bytes, s))) return rc;
+        HIP_TRY(launch_add_sub_tensor(nb.wtmp, 256, h->G(aux_conv->w), aux_conv->cout, 256, 9, s));
+    }
+    HIP_TRY(launch_pad_rows(h->P(aux_conv->w), nb.wpad, aux_conv->cout, 128, 256 * 9, s));
+    if ((rc = conv_dgrad(h, nb.wpad, 128, 256, 3, nb.dfp, q.da, B, res, q, s))) return rc;
+    void* g_cur = nb.ga;
+    void* g_alt = nb.gb;
+    HIP_TRY(launch_gn_bwd(0, y.p, 256, nullptr, 0, q.da, 256, w.ab0, q.mr0, h->P(aux_norm->w), q.P, q.S, h->G(aux_norm->w),
+                          h->G(aux_norm->b), nullptr, 0, 0.f, g_cur, B, res, 0, s));
+    // ---- decoder blocks in reverse ---------------------------------------------------------------------------------------
+    struct Rec {
+        const Block* b;
+        const Act* x;
+        const Act* x2;
+        int sk;
+    };
+    std::vector<Rec> recs;
+    {
+        int sp = (int)h->enc.size();
+        const Act* x = &w.skip.back();
+        size_t di = 0;
+        for (const Block& b : h->dec) {
+            if (b.kind != K_BLOCK) continue;
+            Rec rcd{&b, x, nullptr, -1};
+            if (b.skip_c) {
+                rcd.sk = --sp;
+                rcd.x2 = &w.skip[rcd.sk];
+            }
+            recs.push_back(rcd);
+            x = &nb.dec_store[di++];
+        }
+    }
+    for (int i = (int)recs.size() - 1; i >= 0; --i) {
+        const Block& b = *recs[i].b;
+        const int c2 = b.skip_c, c1 = b.cin - c2;
+        const size_t npin = (size_t)B * b.res_in * b.res_in;
+        if ((rc = block_backward(h, b, *recs[i].x, c1, c2 ? *recs[i].x2 : none, c2, w.emb, w.temb, g_cur, q.dxin, nb.demb, B, w, q, s)))
+            return rc;
+        HIP_TRY(launch_slice_bf16(q.dxin, b.cin, 0, g_alt, c1, (int64_t)npin, 0, s));
+        if (c2) HIP_TRY(launch_slice_bf16(q.dxin, b.cin, c1, nb.genc[recs[i].sk], c2, (int64_t)npin, 0, s));
+        std::swap(g_cur, g_alt);
+    }
+    // the decoder's first block read the last encoder output directly
+    {
+        const Block& last = h->enc.back();
+        HIP_TRY(launch_add_bf16(nb.genc.back(), g_cur, (int64_t)B * last.res_out * last.res_out * last.cout, s));
+    }
+    // ---- encoder blocks in reverse -------------------------------------------------------------------------------------------
+    for (int i = (int)h->enc.size() - 1; i >= 1; --i) {
+        const Block& b = h->enc[i];
+        if ((rc = block_backward(h, b, w.skip[i - 1], b.cin, none, 0, w.emb, w.temb, nb.genc[i], q.dxin, nb.demb, B, w, q, s))) return rc;
+        HIP_TRY(launch_add_bf16(nb.genc[i - 1], q.dxin, (int64_t)B * b.res_in * b.res_in * b.cin, s));
+    }
+    // ---- stem: conv(c_in * x_t) ---------------------------------------------------------------------------------------------------
+    {
+        const Block& b = h->enc[0];
+        if (h->G(b.b)) {
+            HIP_TRY(launch_colsum(nb.genc[0], b.cout, b.cout, q.dtemb, B, hw, 1.0f, s));
+            HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.b), B, b.cout, s));
+        }
+        if (h->G(b.w)) {
+            HIP_TRY(launch_stem_operand(x_t, w.coef, nb.op32, B, b.cin, 32, hw, s));
+            if ((rc = wgrad_checked(nb.op32, nb.genc[0], nb.wtmp, B, res, 32, b.cout, 3, 0, nb.wgx, nb.wgx_bytes, s))) return rc;
+            HIP_TRY(launch_add_sub_tensor(nb.wtmp, 32, h->G(b.w), b.cout, b.cin, 9, s));
+        }
+    }
+    // ---- embedding MLP: emb = silu(L1(silu(L0(emb0)))), emb0 = posemb + map_label(labels sqrt(L))  (:501-521) ------------------
+    {
+        const int E = h->emb_ch, N = h->cond_ch;
+        const int w1 = h->find("model.map_layer1.weight"), b1 = h->find("model.map_layer1.bias");
+        const int w0 = h->find("model.map_layer0.weight"), b0 = h->find("model.map_layer0.bias");
+        HIP_TRY(launch_linear(w.emb1, h->P(w1), h->P(b1), nb.pre, B, E, E, 0, s));
+        HIP_TRY(launch_silu_bwd(nb.demb, nb.pre, nb.d1, B * E, s));
+        HIP_TRY(hipMemsetAsync(nb.d0, 0, sizeof(float) * (size_t)B * E, s));
+        HIP_TRY(launch_linear_bwd(nb.d1, w.emb1, h->P(w1), h->G(w1), h->G(b1), nb.d0, B, E, E, 1.0f, s));
+        HIP_TRY(launch_linear(w.emb0, h->P(w0), h->P(b0), nb.pre, B, N, E, 0, s));
+        HIP_TRY(launch_silu_bwd(nb.d0, nb.pre, nb.d1, B * E, s));
+        HIP_TRY(hipMemsetAsync(nb.d0, 0, sizeof(float) * (size_t)B * N, s));
+        HIP_TRY(launch_linear_bwd(nb.d1, w.emb0, h->P(w0), h->G(w0), h->G(b0), nb.d0, B, E, N, 1.0f, s));
+        if (c.label_dim > 0) {
+            const int wl = h->find("model.map_label.weight"), bl = h->find("model.map_label.bias");
+            HIP_TRY(launch_linear_bwd(nb.d0, labels, nullptr, labels ? h->G(wl) : nullptr, h->G(bl), nullptr, B, N, c.label_dim,
+                                      std::sqrt((float)c.label_dim), s));
+        }
+    }
+    return FG_OK;
+}
 }  // namespace
+
+size_t fg_edm_backward_workspace_bytes(const fg_edm* h, int batch) {
+    if (!h || batch <= 0) return 0;
+    Arena A;
+    A.dry = true;
+    Workspace w;
+    plan_workspace(h, batch, A, w);
+    NetBwd nb;
+    return plan_net_bwd(h, batch, A, nb);
+}
+
+int fg_edm_backward(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* dout,
+                    float* out, int batch, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !x_t || !t || !dout || !out) return fail(FG_EINVAL, "null argument");
+    if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
+    if (!h->dtype) return fail(FG_EINVAL, "the backward pass runs in the bf16 compute mode only");
+    if (h->cfg.r_timestep && !r) return fail(FG_EINVAL, "r is required by an r_timestep network");
+    if (h->cfg.label_dim > 0 && !labels) return fail(FG_EINVAL, "labels are required by a class-conditional network");
+    if (batch <= 0 || !workspace || (((uintptr_t)workspace) & 255)) return fail(FG_EINVAL, "bad batch / workspace");
+    Arena A;
+    A.base = (char*)workspace;
+    Workspace w;
+    plan_workspace(h, batch, A, w);
+    NetBwd nb;
+    const size_t need = plan_net_bwd(h, batch, A, nb);
+    if (need > workspace_bytes) return fail(FG_ENOMEM, "workspace too small: need %zu bytes for batch %d, got %zu", need, batch, workspace_bytes);
+    return run_backward(h, x_t, t, r, labels, dout, out, batch, w, nb, (hipStream_t)stream);
+}
 
 int fg_edm_bind_grad(fg_edm* h, const char* name, float* grad, int64_t numel) {
     if (!h || !name) return fail(FG_EINVAL, "null argument");
@@ -1214,7 +1433,7 @@ size_t fg_edm_block_backward_workspace_bytes(const fg_edm* h, int index, int bat
     Workspace w;
     plan_workspace(h, batch, A, w);
     BwdScratch q;
-    plan_block_bwd(batch, b.res_in, b.res_out, b.cin, b.cout, A, q, b.attn);
+    plan_block_bwd(batch, b.res_in, b.res_out, b.cin, b.cout, A, q, b.attn ? b.res_out * b.res_out : 0);
     A.take((size_t)batch * b.res_out * b.res_out * b.cout * 2);  // gout in bf16
     return A.off;
 }
@@ -1235,7 +1454,7 @@ int fg_edm_run_block_backward(fg_edm* h, int index, const float* x1, int c1, con
     Workspace w;
     plan_workspace(h, B, A, w);
     BwdScratch q;
-    plan_block_bwd(B, b.res_in, b.res_out, b.cin, b.cout, A, q, b.attn);
+    plan_block_bwd(B, b.res_in, b.res_out, b.cin, b.cout, A, q, b.attn ? b.res_out * b.res_out : 0);
     const size_t npix = (size_t)B * b.res_out * b.res_out, npix_in = (size_t)B * b.res_in * b.res_in;
     void* gout = A.take(npix * b.cout * 2);
     if (A.off > workspace_bytes) return fail(FG_ENOMEM, "workspace too small: need %zu bytes, got %zu", A.off, workspace_bytes);

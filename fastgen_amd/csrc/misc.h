@@ -43,6 +43,15 @@ int launch_scale_bf16(const void* in, void* out, float scale, int64_t total, hip
 int launch_slice_to_f32(const void* in, int cs, int c_off, float* out, int C, int64_t npix, hipStream_t s);
 int launch_affine_bwd(const float* dtemb, const float* emb, const float* w, float* dw, float* demb, int B, int C, int K, hipStream_t s);
 int launch_dgrad_weights(const float* w, float* wt, int cout, int cin, int cin_pad, int taps, hipStream_t s);
+int launch_head_grad(const float* dout, const float* c_out, void* out, int B, int C, int Cp, int hw, hipStream_t s);
+int launch_stem_operand(const float* x, const float* c_in, void* out, int B, int C, int Cp, int hw, hipStream_t s);
+int launch_add_sub_tensor(const float* src, int Is, float* dst, int O, int I, int T, hipStream_t s);
+int launch_pad_rows(const float* src, float* dst, int O, int Op, int IT, hipStream_t s);
+int launch_add_bf16(void* dst, const void* src, int64_t total, hipStream_t s);
+int launch_slice_bf16(const void* src, int cs, int off, void* dst, int C, int64_t npix, int accumulate, hipStream_t s);
+int launch_silu_bwd(const float* dy, const float* pre, float* dpre, int total, hipStream_t s);
+int launch_linear_bwd(const float* dy, const float* x, const float* w, float* dw, float* db, float* dx, int B, int C, int K,
+                      float scale, hipStream_t s);
 // attn_bwd.hip
 size_t attention_backward_scratch_bytes(int B, int T, int C);
 int launch_attention_backward(const void* q, const void* k, const void* vt, const void* dO, void* dq, void* dk, void* dvt,

@@ -187,6 +187,15 @@ int fg_edm_run_block_backward(fg_edm* h, int index, const float* x1, int c1, con
                               const float* dout, float* dx1, float* dx2, float* demb, int batch, void* workspace,
                               size_t workspace_bytes, void* stream);
 
+/* Whole-network backward (bf16 compute mode): runs EDMPrecond.forward (-> out, as fg_edm_forward) keeping every block input,
+ * then differentiates it block by block in reverse (each block's forward is recomputed: activation checkpointing at block
+ * granularity).  dout [B,C,H,W] fp32 is dL/d(out).  Gradients of all bound parameters (fg_edm_bind_grad) are ACCUMULATED;
+ * the input x_t receives no gradient (the student's input is noise).  This is what autograd computes for the student /
+ * fake-score network in fastgen/methods/distribution_matching/dmd2.py. */
+size_t fg_edm_backward_workspace_bytes(const fg_edm* h, int batch);
+int fg_edm_backward(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* dout,
+                    float* out, int batch, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Samples to image bytes, the step after generator_fn in the reference's sample writer
  * (scripts/fid/compute_fid_from_ckpts.py:199): out[n,y,x,c] = uint8(clip(images[n,c,y,x] * 127.5 + 128, 0, 255)),
  * fp32 multiply then add, truncation; NaN -> 0.  images NCHW fp32, out NHWC bytes. */

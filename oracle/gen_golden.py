@@ -256,6 +256,40 @@ def block_backward_fixtures(edm_net):
     torch.save(fx, os.path.join(OUT, "blocks_backward.pt"))
 
 
+def full_backward_fixture(edm_net):
+    """Whole-network backward (SURVEY 8(f)1): the reference's EDMPrecond under autograd, full width, B = 2, seeded operands;
+    norm and a 512-entry strided sample of every parameter gradient (parameters the forward does not use have none)."""
+    cfg = edm_ref.CIFAR10
+    sd = edm_ref.random_state_dict(cfg, seed=1234)
+    net = ref_net(edm_net, cfg, sd)
+    for p in net.parameters():
+        p.requires_grad_(True)
+        p.grad = None
+    tt = torch.tensor([17.4981, 0.1726], dtype=torch.float64)
+    x = seeded((2, 3, 32, 32), 21) * tt.reshape(2, 1, 1, 1).float()
+    cond = torch.nn.functional.one_hot(torch.tensor([3, 7]), 10).float()
+    dout = seeded((2, 3, 32, 32), 401)
+    out = net(x, tt, condition=cond, fwd_pred_type="x0")
+    out.backward(dout)
+    # own restatement under autograd
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and "resample_filter" not in k) for k, v in sd.items()}
+    edm_ref.edm_precond_forward(sdg, cfg, x, tt, cond).backward(dout)
+    fx = {"sd_checksum": sd_checksum(sd), "out": out.detach().clone(), "t": tt, "cond": cond}
+    names = []
+    for n, p in net.named_parameters():
+        if p.grad is None:
+            assert sdg[n].grad is None or float(sdg[n].grad.abs().max()) == 0.0, n
+            continue
+        assert torch.allclose(sdg[n].grad, p.grad, rtol=1e-3, atol=1e-4 * float(p.grad.abs().max())), n
+        g = p.grad.reshape(-1)
+        fx[f"{n}/norm"] = g.double().norm().float()
+        fx[f"{n}/sample"] = g[:: max(1, g.numel() // 512)][:512].clone()
+        names.append(n)
+    with open(os.path.join(OUT, "full_backward_names.txt"), "w") as f:
+        f.write("\n".join(names) + "\n")
+    torch.save(fx, os.path.join(OUT, "full_backward_b2.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     edm_net, ns, model = _ref_import.import_reference()
@@ -263,6 +297,7 @@ def main():
     if sys.argv[1:] == ["backward"]:
         backward_fixture(edm_net)
         block_backward_fixtures(edm_net)
+        full_backward_fixture(edm_net)
         print("backward fixtures written to", OUT)
         return
     if sys.argv[1:] == ["train_schedule"]:
@@ -402,6 +437,7 @@ def main():
     train_schedule_fixture(ns)
     backward_fixture(edm_net)
     block_backward_fixtures(edm_net)
+    full_backward_fixture(edm_net)
     teacher_sample_fixture(edm_net)
 
     print("golden fixtures written to", OUT)
