@@ -66,6 +66,62 @@ def _init_value(name: str, shape) -> torch.Tensor:
     return w
 
 
+class _EDMForwardFn(torch.autograd.Function):
+    """EDMPrecond.forward with parameter gradients: forward = fg_edm_forward, backward = fg_edm_backward (the forward is
+    recomputed block by block inside it; nothing but the inputs is kept between the two calls).  The parameters are passed
+    as inputs so that autograd accumulates into their .grad and DDP hooks fire, as for the reference module."""
+
+    @staticmethod
+    def forward(ctx, net, x32, t64, r64, labels, *weights):
+        dev = x32.device
+        dt, h = net._engine(dev)
+        ws = net._workspace(dt, h, x32.shape[0], dev)
+        out = torch.empty_like(x32)
+        _lib.check(_lib.lib().fg_edm_forward(
+            h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
+            ctypes.c_void_p(r64.data_ptr() if r64 is not None else None),
+            ctypes.c_void_p(labels.data_ptr() if labels is not None else None), ctypes.c_void_p(out.data_ptr()), None,
+            x32.shape[0], ctypes.c_void_p(ws.data_ptr()), ws.numel(), net._stream(dev)))
+        ctx.net = net
+        ctx.save_for_backward(x32, t64, r64 if r64 is not None else torch.empty(0), labels if labels is not None else torch.empty(0))
+        ctx.has_r, ctx.has_labels = r64 is not None, labels is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        net = ctx.net
+        x32, t64, r64, labels = ctx.saved_tensors
+        dev, B = x32.device, x32.shape[0]
+        L = _lib.lib()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            dt, h = net._engine(dev)
+        assert dt == _lib.FG_DTYPE_BF16
+        named = net._named_weights()
+        grads = [torch.zeros(p.shape, dtype=torch.float32, device=dev) if p.requires_grad else None for _, p in named]
+        need = L.fg_edm_backward_workspace_bytes(h, B)
+        ws = net._ws.get("bwd")
+        if ws is None or ws.numel() < need or ws.device != dev:
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            net._ws["bwd"] = ws
+        d32 = dout.detach().to(torch.float32).contiguous()
+        scratch_out = torch.empty_like(x32)
+        try:
+            for (n, _), g in zip(named, grads):
+                if g is not None:
+                    _lib.check(L.fg_edm_bind_grad(h, n.encode(), ctypes.c_void_p(g.data_ptr()), g.numel()))
+            _lib.check(L.fg_edm_backward(
+                h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
+                ctypes.c_void_p(r64.data_ptr() if ctx.has_r else None), ctypes.c_void_p(labels.data_ptr() if ctx.has_labels else None),
+                ctypes.c_void_p(d32.data_ptr()), ctypes.c_void_p(scratch_out.data_ptr()), B, ctypes.c_void_p(ws.data_ptr()),
+                ws.numel(), net._stream(dev)))
+        finally:
+            for (n, _), g in zip(named, grads):
+                if g is not None:
+                    _lib.check(L.fg_edm_bind_grad(h, n.encode(), None, 0))
+        grads = [g.to(p.dtype) if g is not None else None for (_, p), g in zip(named, grads)]
+        return (None, None, None, None, None, *grads)
+
+
 class EDMPrecond(FastGenNetwork):
     def __init__(
         self,
@@ -226,11 +282,20 @@ class EDMPrecond(FastGenNetwork):
     def _stream(device) -> ctypes.c_void_p:
         return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
-    def _check_inference(self):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+    def _needs_grad(self) -> bool:
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    def _check_trainable_call(self, x_t, feature_indices, return_logvar):
+        """Autograd through the module is provided for the parameter gradients of the plain forward in the bf16 compute mode
+        (fg_edm_backward: what the DMD2 student / fake-score updates need, dmd2.py); everything else raises."""
+        if self._select_dtype() != _lib.FG_DTYPE_BF16:
             raise NotImplementedError(
-                "fastgen_amd.EDMPrecond computes the forward pass only (no autograd graph); call it under "
-                "torch.no_grad() / torch.inference_mode() as generator_fn does (fastgen/methods/model.py:405)")
+                "fastgen_amd.EDMPrecond: the backward pass runs in the bf16 compute mode only - call under "
+                "torch.autocast('cuda', dtype=torch.bfloat16) (or compute_dtype='bf16'), or under torch.no_grad() for inference")
+        if x_t.requires_grad:
+            raise NotImplementedError("fastgen_amd.EDMPrecond: gradients with respect to x_t are not implemented")
+        if len(feature_indices) or return_logvar:
+            raise NotImplementedError("fastgen_amd.EDMPrecond: feature taps / logvar are forward-only (call under torch.no_grad())")
 
     def _labels(self, condition, batch: int, device) -> Optional[torch.Tensor]:
         if isinstance(condition, dict) and "aug_condition" in condition:
@@ -306,7 +371,9 @@ class EDMPrecond(FastGenNetwork):
             raise TypeError(f"unexpected forward kwargs: {sorted(fwd_kwargs)}")
         if self.training and self.dropout:
             raise NotImplementedError("dropout in training mode is not implemented (call .eval())")
-        self._check_inference()
+        needs_grad = self._needs_grad()
+        if needs_grad:
+            self._check_trainable_call(x_t, feature_indices, return_logvar)
         if x_t.device.type != "cuda":
             raise RuntimeError("fastgen_amd runs on a HIP GPU only (no CPU path); got a tensor on " + str(x_t.device))
         if x_t.dim() != 4 or x_t.shape[1] != self.img_channels or x_t.shape[2] != self.img_resolution or x_t.shape[3] != self.img_resolution:
@@ -356,6 +423,9 @@ class EDMPrecond(FastGenNetwork):
             features = [f.to(x_t.dtype) for f in features]
             if return_features_early:
                 return features
+        elif needs_grad:
+            weights = [p_ for _, p_ in self._named_weights()]
+            out = _EDMForwardFn.apply(self, x32, t64, r64, labels, *weights)
         else:
             out = torch.empty_like(x32)
             _lib.check(L.fg_edm_forward(
@@ -407,7 +477,10 @@ class EDMPrecond(FastGenNetwork):
         ([steps-1,B,C,H,W], injected) or, if eps is None, with normals drawn on the device from `seed`;
         'ode' re-uses the implied noise (x0 loop) / integrates the average velocity (MeanFlow loop).
         loop: 'x0' | 'meanflow' (default: `fused_loop()`)."""
-        self._check_inference()
+        if self._needs_grad():
+            raise NotImplementedError(
+                "the fused sampler builds no autograd graph; call it under torch.no_grad() / torch.inference_mode() as "
+                "generator_fn does (fastgen/methods/model.py:405)")
         loop = loop or self.fused_loop()
         if loop is None or loop != self.fused_loop():
             raise NotImplementedError(

@@ -724,3 +724,41 @@ def test_network_backward_against_reference_golden(nets, sd, golden_dir):
     for n in ("model.map_augment.weight", "model.logvar_linear.weight", "model.logvar_linear.bias"):
         assert float(grads[n].abs().max()) == 0.0
     print("worst relative error:", worst)
+
+
+def test_module_autograd_through_the_hip_backward(nets, golden_dir):
+    """loss.backward() through the drop-in module: parameter .grad tensors come from fg_edm_backward and match the reference's
+    autograd (same fixture and tolerance as the C-ABI test); a second backward accumulates; unsupported requests raise."""
+    fx = load(golden_dir, "full_backward_b2.pt")
+    names = open(os.path.join(golden_dir, "full_backward_names.txt")).read().split()
+    net = nets["bf16"]
+    t, cond = fx["t"].to(dev()), fx["cond"].to(dev())
+    x = (seeded((2, 3, 32, 32), 21) * fx["t"].reshape(2, 1, 1, 1).float()).to(dev())
+    dout = seeded((2, 3, 32, 32), 401).to(dev())
+    params = dict(net.named_parameters())
+    try:
+        net.zero_grad(set_to_none=True)
+        out = net(x, t, condition=cond, fwd_pred_type="x0")
+        assert out.requires_grad
+        check(out, fx["out"], "bf16", "forward under autograd")
+        (out * dout).sum().backward()
+        for n in names[::7] + ["model.enc.32x32_conv.weight", "model.map_label.weight", "model.dec.32x32_aux_conv.weight"]:
+            g = params[n].grad.detach().cpu().reshape(-1)
+            smp = g[:: max(1, g.numel() // 512)][:512]
+            want = fx[f"{n}/sample"]
+            assert float((smp - want).norm() / want.norm().clamp_min(1e-20)) <= 5e-2, n
+        assert params["model.map_augment.weight"].grad is None or float(params["model.map_augment.weight"].grad.abs().max()) == 0.0
+        first = params["model.enc.16x16_block1.conv1.weight"].grad.clone()
+        (net(x, t, condition=cond, fwd_pred_type="x0") * dout).sum().backward()
+        second = params["model.enc.16x16_block1.conv1.weight"].grad
+        assert torch.allclose(second, 2 * first, rtol=1e-5, atol=1e-6 * float(first.abs().max()))  # deterministic and accumulated
+        with pytest.raises(NotImplementedError):
+            net(x.clone().requires_grad_(True), t, condition=cond)
+        with pytest.raises(NotImplementedError):
+            nets["fp32"](x, t, condition=cond)  # the backward pass exists in the bf16 mode only
+        # a conversion after the network stays differentiable (eps prediction from the x0 network)
+        net.zero_grad(set_to_none=True)
+        net(x, t, condition=cond, fwd_pred_type="eps").square().mean().backward()
+        assert torch.isfinite(params["model.dec.32x32_aux_conv.weight"].grad).all()
+    finally:
+        net.zero_grad(set_to_none=True)
