@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const __bf16* __restr
 
 // ---- out[n][c] (+)= scale * sum_p t[n,p,c]: bias and embedding-affine gradients -------------------------------------------
 __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ t, int Ct, int C, float* __restrict__ out, int HW,
-                                                     float scale) {
+                                                     float scale, int out_stride) {
     const int n = blockIdx.y, oct = threadIdx.x & 7, pl = threadIdx.x >> 3;
     const int c0 = blockIdx.x * 64 + oct * 8;
     __shared__ float s1[32][65];
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ 
     if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < C) {
         float a = 0.f;
         for (int r = 0; r < 32; ++r) a += s1[r][threadIdx.x];
-        out[(size_t)n * C + blockIdx.x * 64 + threadIdx.x] = a * scale;
+        out[(size_t)n * out_stride + blockIdx.x * 64 + threadIdx.x] = a * scale;
     }
 }
 
@@ -357,13 +357,24 @@ __global__ void silu_bwd_kernel(const float* __restrict__ dy, const float* __res
 }
 // dW[c][k] += scale * sum_b dy[b][c] x[b][k]
 __global__ void linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, int B, int C,
-                                    int K, float scale) {
+                                    int K, float scale, int dy_stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C * K) return;
     const int c = i / K, k = i - c * K;
     float a = 0.f;
-    for (int b = 0; b < B; ++b) a = fmaf(dy[(size_t)b * C + c], x[(size_t)b * K + k], a);
+    for (int b = 0; b < B; ++b) a = fmaf(dy[(size_t)b * dy_stride + c], x[(size_t)b * K + k], a);
     dw[i] += a * scale;
+}
+
+// out[c][r] = in[r][c] (fp32)
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < R && c0 + tx < Cc) tile[i][tx] = in[(size_t)(r0 + i) * Cc + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < Cc && r0 + tx < R) out[(size_t)(c0 + i) * R + r0 + tx] = tile[tx][i];
 }
 
 inline unsigned ew_blocks(int64_t n) {
@@ -413,9 +424,10 @@ int launch_gn_bwd(int mode, const void* x1, int c1, const void* x2, int c2, cons
     BWD_RET();
 }
 
-int launch_colsum(const void* t, int ct, int C, float* out, int B, int hw, float scale, hipStream_t s) {
+int launch_colsum(const void* t, int ct, int C, float* out, int B, int hw, float scale, hipStream_t s, int out_stride) {
     if (C % 8) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, (const __bf16*)t, ct, C, out, hw, scale);
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, (const __bf16*)t, ct, C, out, hw, scale,
+                       out_stride > 0 ? out_stride : C);
     BWD_RET();
 }
 int launch_batchsum_add(const float* in, float* out, int B, int C, hipStream_t s) {
@@ -475,9 +487,14 @@ int launch_silu_bwd(const float* dy, const float* pre, float* dpre, int total, h
 }
 // Linear backward: dw[C][K] += scale * dy^T x, db[C] += sum_b dy, dx[B][K] += dy w  (each optional)
 int launch_linear_bwd(const float* dy, const float* x, const float* w, float* dw, float* db, float* dx, int B, int C, int K,
-                      float scale, hipStream_t s) {
-    if (dw) hipLaunchKernelGGL(linear_wgrad_kernel, dim3((C * K + 255) / 256), dim3(256), 0, s, dy, x, dw, B, C, K, scale);
+                      float scale, hipStream_t s, int dy_stride) {
+    if ((db || dx) && dy_stride > 0 && dy_stride != C) return (int)hipErrorInvalidValue;  // only the weight part takes a stride
+    if (dw) hipLaunchKernelGGL(linear_wgrad_kernel, dim3((C * K + 255) / 256), dim3(256), 0, s, dy, x, dw, B, C, K, scale, dy_stride > 0 ? dy_stride : C);
     if (db) hipLaunchKernelGGL(batchsum_add_kernel, dim3((C + 255) / 256), dim3(256), 0, s, dy, db, B, C);
     if (dx) hipLaunchKernelGGL(affine_dgrad_kernel, dim3((B * K + 255) / 256), dim3(256), 0, s, dy, w, dx, B, C, K);
+    BWD_RET();
+}
+int launch_transpose_f32(const float* in, float* out, int R, int Cc, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, s, in, out, R, Cc);
     BWD_RET();
 }

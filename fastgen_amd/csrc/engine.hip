@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../include/fastgen_amd.h"
@@ -127,6 +128,15 @@ struct fg_edm {
     int temb_total = 0;
     bool packed = false;
     bool device_ready = false;
+    // data-gradient weights (transposed, flipped, packed), built on first use per weight version (fg_edm_pack_weights)
+    struct DgradW {
+        void* packed = nullptr;
+        uint64_t epoch = 0;
+    };
+    std::map<const float*, DgradW> dgrad_cache;
+    uint64_t pack_epoch = 0;
+    float* aff_wT = nullptr;  // [emb_ch][temb_total]: the stacked affine matrix transposed, for the batched embedding gradient
+    uint64_t aff_wT_epoch = 0;
     // owned device memory
     float* freqs = nullptr;      // [noise_ch/2]
     float* aff_w = nullptr;      // [temb_total][emb_ch]
@@ -751,6 +761,7 @@ int fg_edm_pack_weights(fg_edm* h, void* stream) {
         const bool unused = p.name == "model.map_augment.weight" || p.name.rfind("model.logvar_linear", 0) == 0;
         if (!p.ptr && !unused) return fail(FG_ENOTREADY, "parameter '%s' is not bound", p.name.c_str());
     }
+    ++h->pack_epoch;
     for (Block* b : h->blocks) {
         HIP_TRY(launch_pack_conv_weights(h->dtype, h->P(b->conv0_w), b->p_conv0, b->cout, b->cin, 3, 0, s));
         HIP_TRY(launch_pack_conv_weights(h->dtype, h->P(b->conv1_w), b->p_conv1, b->cout, b->cout, 3, 0, s));
@@ -1110,14 +1121,29 @@ size_t plan_block_bwd(int B, int res_in, int res, int cin, int cout, Arena& A, B
 }
 // data gradient of a conv = the forward conv kernel on dY with transposed, flipped weights; output [npix][pad256(cin)]
 int conv_dgrad(fg_edm* h, const float* w_oihw, int cout, int cin, int ks, const void* dy, void* out, int B, int res, BwdScratch& q,
-               hipStream_t s) {
+               hipStream_t s, bool cache = true) {
     const int cp = pad256(cin);
-    HIP_TRY(launch_dgrad_weights(w_oihw, q.wt, cout, cin, cp, ks * ks, s));
-    HIP_TRY(launch_pack_conv_weights(1, q.wt, q.wpk, cp, cout, ks, 0, s));
+    void* wpk = q.wpk;
+    if (cache) {  // parameters: packed once per weight version; scratch-built weights (the padded head) are not cached
+        fg_edm::DgradW& e = h->dgrad_cache[w_oihw];
+        if (!e.packed) {
+            int rc = dev_alloc(h, &e.packed, (size_t)cp * cout * ks * ks * 2);
+            if (rc) return rc;
+        }
+        if (e.epoch != h->pack_epoch) {
+            HIP_TRY(launch_dgrad_weights(w_oihw, q.wt, cout, cin, cp, ks * ks, s));
+            HIP_TRY(launch_pack_conv_weights(1, q.wt, e.packed, cp, cout, ks, 0, s));
+            e.epoch = h->pack_epoch;
+        }
+        wpk = e.packed;
+    } else {
+        HIP_TRY(launch_dgrad_weights(w_oihw, q.wt, cout, cin, cp, ks * ks, s));
+        HIP_TRY(launch_pack_conv_weights(1, q.wt, q.wpk, cp, cout, ks, 0, s));
+    }
     ConvArgs a{};
     a.src1 = dy; a.C1 = cout; a.C2 = 0;
     a.Hs = a.Ws = a.H = a.W = res; a.B = B;
-    a.wpack = q.wpk; a.scale = 1.0f; a.out = out; a.Cout = cp;
+    a.wpack = wpk; a.scale = 1.0f; a.out = out; a.Cout = cp;
     HIP_TRY(launch_conv_fused(1, ks, PRO_NONE, RES_NONE, OUT_NHWC, a, s));
     return FG_OK;
 }
@@ -1135,7 +1161,8 @@ int wgrad_checked(const void* act, const void* dy, float* dw, int B, int res, in
 // [B, res_out^2, cout]; dxin: bf16 [B, res_in^2, cin] (overwritten); demb [B, emb_ch] and the bound parameter gradients are
 // accumulated.  The block's forward is recomputed here (activation checkpointing at block granularity).
 int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& a2, int c2, const float* emb, const float* temb,
-                   const void* gout, void* dxin, float* demb, int B, Workspace& w, BwdScratch& q, hipStream_t s) {
+                   const void* gout, void* dxin, float* demb, int B, Workspace& w, BwdScratch& q, hipStream_t s,
+                   float* dtemb_all = nullptr) {
     const int res = b.res_out, res_in = b.res_in, hw = res * res, cin = b.cin, cout = b.cout, cp = pad256(cin);
     const int rm = b.down ? 1 : (b.up ? 2 : 0);
     if (!conv_wgrad_supported(res, cout, cout, 3) || !conv_wgrad_supported(res, cin, cout, 3))
@@ -1185,10 +1212,15 @@ int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& 
     HIP_TRY(launch_gn_bwd(0, w.h.p, cout, nullptr, 0, q.da, pad256(cout), w.ab1, q.mr1, h->P(b.norm1_w), q.P, q.S, h->G(b.norm1_w),
                           h->G(b.norm1_b), nullptr, 0, 0.f, q.dh0, B, res, 0, s));
     // bias of conv0 and the embedding affine see the pixel sum of dh0
-    HIP_TRY(launch_colsum(q.dh0, cout, cout, q.dtemb, B, hw, 1.0f, s));
-    if (h->G(b.conv0_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.conv0_b), B, cout, s));
-    if (h->G(b.aff_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.aff_b), B, cout, s));
-    HIP_TRY(launch_affine_bwd(q.dtemb, emb, h->P(b.aff_w), h->G(b.aff_w), demb, B, cout, h->emb_ch, s));
+    if (dtemb_all) {
+        // whole-network pass: parked in the stacked [B][temb_total] matrix; biases, affine weights and demb follow in one go
+        HIP_TRY(launch_colsum(q.dh0, cout, cout, dtemb_all + b.temb_off, B, hw, 1.0f, s, h->temb_total));
+    } else {
+        HIP_TRY(launch_colsum(q.dh0, cout, cout, q.dtemb, B, hw, 1.0f, s));
+        if (h->G(b.conv0_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.conv0_b), B, cout, s));
+        if (h->G(b.aff_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.aff_b), B, cout, s));
+        HIP_TRY(launch_affine_bwd(q.dtemb, emb, h->P(b.aff_w), h->G(b.aff_w), demb, B, cout, h->emb_ch, s));
+    }
     // conv0: its operand is silu(norm0(x)), resampled to the output resolution
     if (h->G(b.conv0_w)) {
         HIP_TRY(launch_gn_act(0, a1.p, c1, a2.p, c2, w.ab0, q.aop, B, res, rm, s));
@@ -1220,6 +1252,7 @@ struct NetBwd {
     void *dfp, *op32;             // padded head gradient [npix][128], padded stem operand [npix][32]
     float *wtmp, *wpad, *vec;     // padded weight-gradient / weight scratch, small vector scratch
     float *demb, *pre, *d1, *d0;  // embedding MLP
+    float *dtemb_all, *vec_all;   // [B][temb_total] pixel sums of every block's dh0, and their batch sum
     void* wgx;                    // split-K scratch of the head / stem weight gradients
     size_t wgx_bytes;
     BwdScratch q;
@@ -1263,6 +1296,8 @@ size_t plan_net_bwd(const fg_edm* h, int B, Arena& A, NetBwd& nb) {
     nb.pre = A.get<float>((size_t)B * h->emb_ch);
     nb.d1 = A.get<float>((size_t)B * h->emb_ch);
     nb.d0 = A.get<float>((size_t)B * std::max(h->cond_ch, h->emb_ch));
+    nb.dtemb_all = A.get<float>((size_t)B * h->temb_total);
+    nb.vec_all = A.get<float>((size_t)h->temb_total);
     nb.wgx_bytes = std::max(conv_wgrad_workspace_bytes(B, h->cfg.img_resolution, 256, 128, 3),
                             conv_wgrad_workspace_bytes(B, h->cfg.img_resolution, 32, 128, 3));
     nb.wgx = A.take(nb.wgx_bytes);
@@ -1278,7 +1313,6 @@ int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, 
     BwdScratch& q = nb.q;
     int rc = run_forward(h, x_t, t, 1, r, 1, labels, out, B, w, s, nullptr, false, &nb.dec_store);
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(nb.demb, 0, sizeof(float) * (size_t)B * h->emb_ch, s));
     const Block *aux_norm = nullptr, *aux_conv = nullptr;
     for (const Block& b : h->dec) {
         if (b.kind == K_AUX_NORM) aux_norm = &b;
@@ -1303,7 +1337,7 @@ int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, 
         HIP_TRY(launch_add_sub_tensor(nb.wtmp, 256, h->G(aux_conv->w), aux_conv->cout, 256, 9, s));
     }
     HIP_TRY(launch_pad_rows(h->P(aux_conv->w), nb.wpad, aux_conv->cout, 128, 256 * 9, s));
-    if ((rc = conv_dgrad(h, nb.wpad, 128, 256, 3, nb.dfp, q.da, B, res, q, s))) return rc;
+    if ((rc = conv_dgrad(h, nb.wpad, 128, 256, 3, nb.dfp, q.da, B, res, q, s, false))) return rc;
     void* g_cur = nb.ga;
     void* g_alt = nb.gb;
     HIP_TRY(launch_gn_bwd(0, y.p, 256, nullptr, 0, q.da, 256, w.ab0, q.mr0, h->P(aux_norm->w), q.P, q.S, h->G(aux_norm->w),
@@ -1335,7 +1369,7 @@ int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, 
         const Block& b = *recs[i].b;
         const int c2 = b.skip_c, c1 = b.cin - c2;
         const size_t npin = (size_t)B * b.res_in * b.res_in;
-        if ((rc = block_backward(h, b, *recs[i].x, c1, c2 ? *recs[i].x2 : none, c2, w.emb, w.temb, g_cur, q.dxin, nb.demb, B, w, q, s)))
+        if ((rc = block_backward(h, b, *recs[i].x, c1, c2 ? *recs[i].x2 : none, c2, w.emb, w.temb, g_cur, q.dxin, nb.demb, B, w, q, s, nb.dtemb_all)))
             return rc;
         HIP_TRY(launch_slice_bf16(q.dxin, b.cin, 0, g_alt, c1, (int64_t)npin, 0, s));
         if (c2) HIP_TRY(launch_slice_bf16(q.dxin, b.cin, c1, nb.genc[recs[i].sk], c2, (int64_t)npin, 0, s));
@@ -1349,7 +1383,7 @@ int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, 
     // ---- encoder blocks in reverse -------------------------------------------------------------------------------------------
     for (int i = (int)h->enc.size() - 1; i >= 1; --i) {
         const Block& b = h->enc[i];
-        if ((rc = block_backward(h, b, w.skip[i - 1], b.cin, none, 0, w.emb, w.temb, nb.genc[i], q.dxin, nb.demb, B, w, q, s))) return rc;
+        if ((rc = block_backward(h, b, w.skip[i - 1], b.cin, none, 0, w.emb, w.temb, nb.genc[i], q.dxin, nb.demb, B, w, q, s, nb.dtemb_all))) return rc;
         HIP_TRY(launch_add_bf16(nb.genc[i - 1], q.dxin, (int64_t)B * b.res_in * b.res_in * b.cin, s));
     }
     // ---- stem: conv(c_in * x_t) ---------------------------------------------------------------------------------------------------
@@ -1364,6 +1398,27 @@ int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, 
             if ((rc = wgrad_checked(nb.op32, nb.genc[0], nb.wtmp, B, res, 32, b.cout, 3, 0, nb.wgx, nb.wgx_bytes, s))) return rc;
             HIP_TRY(launch_add_sub_tensor(nb.wtmp, 32, h->G(b.w), b.cout, b.cin, 9, s));
         }
+    }
+    // ---- all 33 embedding affines at once (stacked as in the forward): biases, weights, and demb = dtemb_all @ aff_w ---------------
+    {
+        const int E = h->emb_ch, TT = h->temb_total;
+        HIP_TRY(hipMemsetAsync(nb.vec_all, 0, sizeof(float) * TT, s));
+        HIP_TRY(launch_batchsum_add(nb.dtemb_all, nb.vec_all, B, TT, s));
+        for (const Block* b : h->blocks) {
+            if (h->G(b->conv0_b)) HIP_TRY(launch_add_sub_tensor(nb.vec_all + b->temb_off, b->cout, h->G(b->conv0_b), 1, b->cout, 1, s));
+            if (h->G(b->aff_b)) HIP_TRY(launch_add_sub_tensor(nb.vec_all + b->temb_off, b->cout, h->G(b->aff_b), 1, b->cout, 1, s));
+            if (h->G(b->aff_w))
+                HIP_TRY(launch_linear_bwd(nb.dtemb_all + b->temb_off, w.emb, nullptr, h->G(b->aff_w), nullptr, nullptr, B, b->cout, E, 1.0f, s, TT));
+        }
+        if (!h->aff_wT) {
+            int rc2 = dev_alloc(h, (void**)&h->aff_wT, sizeof(float) * (size_t)E * TT);
+            if (rc2) return rc2;
+        }
+        if (h->aff_wT_epoch != h->pack_epoch) {
+            HIP_TRY(launch_transpose_f32(h->aff_w, h->aff_wT, TT, E, s));
+            h->aff_wT_epoch = h->pack_epoch;
+        }
+        HIP_TRY(launch_linear(nb.dtemb_all, h->aff_wT, nullptr, nb.demb, B, TT, E, 0, s));
     }
     // ---- embedding MLP: emb = silu(L1(silu(L0(emb0)))), emb0 = posemb + map_label(labels sqrt(L))  (:501-521) ------------------
     {

@@ -36,7 +36,8 @@ int launch_gn_act(int mode, const void* x1, int c1, const void* x2, int c2, cons
 int launch_gn_bwd(int mode, const void* x1, int c1, const void* x2, int c2, const void* dact, int cd, const float2* ab,
                   const float2* mr, const float* gamma, float2* P, float2* S, float* dgamma, float* dbeta, const void* add, int ca,
                   float add_scale, void* dx, int B, int res, int rm, hipStream_t s);  // res = the norm's (input) resolution
-int launch_colsum(const void* t, int ct, int C, float* out, int B, int hw, float scale, hipStream_t s);
+int launch_colsum(const void* t, int ct, int C, float* out, int B, int hw, float scale, hipStream_t s, int out_stride = 0);
+int launch_transpose_f32(const float* in, float* out, int R, int Cc, hipStream_t s);
 int launch_batchsum_add(const float* in, float* out, int B, int C, hipStream_t s);
 int launch_scale_to_bf16(const float* in, void* out, float scale, int64_t total, hipStream_t s);
 int launch_scale_bf16(const void* in, void* out, float scale, int64_t total, hipStream_t s);
@@ -51,7 +52,7 @@ int launch_add_bf16(void* dst, const void* src, int64_t total, hipStream_t s);
 int launch_slice_bf16(const void* src, int cs, int off, void* dst, int C, int64_t npix, int accumulate, hipStream_t s);
 int launch_silu_bwd(const float* dy, const float* pre, float* dpre, int total, hipStream_t s);
 int launch_linear_bwd(const float* dy, const float* x, const float* w, float* dw, float* db, float* dx, int B, int C, int K,
-                      float scale, hipStream_t s);
+                      float scale, hipStream_t s, int dy_stride = 0);
 // attn_bwd.hip
 size_t attention_backward_scratch_bytes(int B, int T, int C);
 int launch_attention_backward(const void* q, const void* k, const void* vt, const void* dO, void* dq, void* dk, void* dvt,
