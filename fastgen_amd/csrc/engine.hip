@@ -104,6 +104,18 @@ struct Workspace {
     uint64_t* seed;  // [2]
 };
 
+// What a block's backward pass reads besides the block's inputs; kept per block by a forward that a backward follows.
+struct BlockStash {
+    void* h = nullptr;                      // conv0 output
+    float2 *ab0 = nullptr, *ab1 = nullptr, *ab2 = nullptr, *mr0 = nullptr, *mr1 = nullptr, *mr2 = nullptr;
+    void *xattn = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *aout = nullptr;  // attention blocks
+};
+struct TrainStash {
+    std::vector<Act> dec_store;      // decoder block outputs (the encoder's live on the skip stack anyway)
+    std::vector<BlockStash> blocks;  // indexed like fg_edm::blocks
+    float2* aux_ab = nullptr;        // coefficients of aux_norm
+};
+
 struct GraphKey {
     int B = 0, steps = 0, type = 0, loop = 0;
     uint64_t zero_mask = 0;
@@ -430,6 +442,22 @@ int norm_coeffs(int dtype, const Act& x1, int c1, const Act& x2, int c2, const f
     return FG_OK;
 }
 
+// Point the per-block scratch of the workspace at a block's stash (its forward then leaves everything the backward reads there).
+void use_stash(Workspace& w, const BlockStash& st) {
+    w.h.p = st.h;
+    w.ab0 = st.ab0, w.ab1 = st.ab1, w.mr0 = st.mr0, w.mr1 = st.mr1;
+    if (st.xattn) {
+        w.xattn.p = st.xattn;
+        w.ab2 = st.ab2, w.mr2 = st.mr2;
+        w.q = st.q, w.k = st.k, w.vt = st.vt, w.aout = st.aout;
+    }
+}
+int block_index(const fg_edm* h, const Block* b) {
+    for (size_t i = 0; i < h->blocks.size(); ++i)
+        if (h->blocks[i] == b) return (int)i;
+    return -1;
+}
+
 // One UNetBlock (EDM/network.py:274-299) as 5-10 kernel launches.  `out.st` receives the block output's statistics.
 int run_block(fg_edm* h, const Block& b, const Act& x1, int c1, const Act& x2, int c2, const float* temb, Act& out, int B,
               Workspace& w, hipStream_t s) {
@@ -511,7 +539,7 @@ int run_mapping(fg_edm* h, const float* labels, int B, Workspace& w, hipStream_t
 // (SongUNet.forward feature taps, EDM/network.py:535-539) or nullptr; early: return after the encoder (:542-544).
 int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, const double* r, int r_stride,
                 const float* labels, float* out, int B, Workspace& w, hipStream_t s, float* const* feats = nullptr,
-                bool early = false, std::vector<Act>* dec_store = nullptr) {
+                bool early = false, TrainStash* ts = nullptr) {
     const fg_edm_config& c = h->cfg;
     HIP_TRY(launch_precond_coef(t, t_stride, c.r_timestep ? r : nullptr, r_stride, c.sigma_data, c.sigma_shift, 1e-6,
                                 c.drop_precond, w.coef, B, s));
@@ -531,6 +559,7 @@ int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, cons
                 w.skip[i].st = nullptr;  // no statistics: block0's norm0 takes the full-pass fallback
             }
         } else {
+            if (ts) use_stash(w, ts->blocks[block_index(h, &b)]);
             rc = run_block(h, b, *x, b.cin, none, 0, w.temb, w.skip[i], B, w, s);
             if (rc) return rc;
             if (feats && b.tap >= 0 && feats[b.tap])
@@ -548,13 +577,16 @@ int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, cons
     for (const Block& b : h->dec) {
         if (b.kind == K_BLOCK) {
             const Act& x2 = b.skip_c ? w.skip[--sp] : none;
-            // a backward pass follows: every block output is kept (dec_store) instead of ping-ponging two buffers
-            Act& dst = dec_store ? (*dec_store)[di++] : *pong[cur];
+            // a backward pass follows: every block output is kept instead of ping-ponging two buffers, and the block's
+            // intermediates land in its stash
+            Act& dst = ts ? ts->dec_store[di++] : *pong[cur];
+            if (ts) use_stash(w, ts->blocks[block_index(h, &b)]);
             rc = run_block(h, b, *x, b.cin - b.skip_c, x2, b.skip_c, w.temb, dst, B, w, s);
             if (rc) return rc;
             x = &dst;
             cur ^= 1;
         } else if (b.kind == K_AUX_NORM) {
+            if (ts) w.ab0 = ts->aux_ab, w.mr0 = nullptr;  // not a block's stash
             if ((rc = norm_coeffs(h->dtype, *x, b.cin, none, 0, h->P(b.w), h->P(b.b), w.ab0, B, b.res_in * b.res_in, s))) return rc;
             aux_ab = w.ab0;
         } else if (b.kind == K_AUX_CONV) {
@@ -1162,18 +1194,25 @@ int wgrad_checked(const void* act, const void* dy, float* dw, int B, int res, in
 // accumulated.  The block's forward is recomputed here (activation checkpointing at block granularity).
 int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& a2, int c2, const float* emb, const float* temb,
                    const void* gout, void* dxin, float* demb, int B, Workspace& w, BwdScratch& q, hipStream_t s,
-                   float* dtemb_all = nullptr) {
+                   float* dtemb_all = nullptr, const BlockStash* stash = nullptr) {
     const int res = b.res_out, res_in = b.res_in, hw = res * res, cin = b.cin, cout = b.cout, cp = pad256(cin);
     const int rm = b.down ? 1 : (b.up ? 2 : 0);
     if (!conv_wgrad_supported(res, cout, cout, 3) || !conv_wgrad_supported(res, cin, cout, 3))
         return fail(FG_EINVAL, "%s: shape not covered by the weight-gradient kernel", b.key.c_str());
     const size_t npix = (size_t)B * hw;
-    w.mr0 = q.mr0;
-    w.mr1 = q.mr1;
-    w.mr2 = q.mr2;
-    int rc = run_block(h, b, a1, c1, a2, c2, temb, w.xa, B, w, s);
-    w.mr0 = w.mr1 = w.mr2 = nullptr;
-    if (rc) return rc;
+    int rc = FG_OK;
+    if (stash) {
+        // the forward that preceded this call left the block's intermediates in its stash: nothing to recompute
+        use_stash(w, *stash);
+        q.mr0 = stash->mr0, q.mr1 = stash->mr1, q.mr2 = stash->mr2;
+    } else {
+        w.mr0 = q.mr0;
+        w.mr1 = q.mr1;
+        w.mr2 = q.mr2;
+        rc = run_block(h, b, a1, c1, a2, c2, temb, w.xa, B, w, s);
+        w.mr0 = w.mr1 = w.mr2 = nullptr;
+        if (rc) return rc;
+    }
     if (b.attn) {
         // out = (proj(attention(qkv(norm2(x_mid)))) + x_mid) * sigma, EDM/network.py:290-298.  g2 = sigma * gout.
         if (!q.att) return fail(FG_EINVAL, "%s: scratch was planned without the attention part", b.key.c_str());
@@ -1246,7 +1285,7 @@ int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& 
 
 // ---- whole network: forward keeping every block input, then the blocks in reverse ----------------------------------------------
 struct NetBwd {
-    std::vector<Act> dec_store;   // decoder block outputs
+    TrainStash ts;
     std::vector<void*> genc;      // gradient w.r.t. each encoder output (bf16)
     void *ga, *gb;                // running gradient, ping-pong
     void *dfp, *op32;             // padded head gradient [npix][128], padded stem operand [npix][32]
@@ -1263,8 +1302,29 @@ size_t plan_net_bwd(const fg_edm* h, int B, Arena& A, NetBwd& nb) {
     int max_res = 0, max_cin = 0, attn_hw = 0;
     size_t wg_max = 0;
     const size_t st_elems = (size_t)B * 8 * 64;
-    nb.dec_store.clear();
+    nb.ts.dec_store.clear();
+    nb.ts.blocks.clear();
     nb.genc.clear();
+    nb.ts.aux_ab = A.get<float2>((size_t)B * 256);
+    for (const Block* b : h->blocks) {
+        const size_t np = (size_t)B * b->res_out * b->res_out;
+        BlockStash st;
+        st.h = A.take(np * b->cout * tsz);
+        st.ab0 = A.get<float2>((size_t)B * b->cin);
+        st.ab1 = A.get<float2>((size_t)B * b->cout);
+        st.mr0 = A.get<float2>((size_t)B * 32);
+        st.mr1 = A.get<float2>((size_t)B * 32);
+        if (b->attn) {
+            st.ab2 = A.get<float2>((size_t)B * b->cout);
+            st.mr2 = A.get<float2>((size_t)B * 32);
+            st.xattn = A.take(np * b->cout * tsz);
+            st.q = A.take(np * b->cout * tsz);
+            st.k = A.take(np * b->cout * tsz);
+            st.vt = A.take(np * b->cout * tsz);
+            st.aout = A.take(np * b->cout * tsz);
+        }
+        nb.ts.blocks.push_back(st);
+    }
     for (const Block& b : h->enc) {
         nb.genc.push_back(A.take((size_t)B * b.res_out * b.res_out * b.cout * tsz));
         max_act = std::max(max_act, (size_t)b.res_out * b.res_out * b.cout);
@@ -1274,7 +1334,7 @@ size_t plan_net_bwd(const fg_edm* h, int B, Arena& A, NetBwd& nb) {
         Act a;
         a.p = A.take((size_t)B * b.res_out * b.res_out * b.cout * tsz);
         a.st = A.get<float2>(st_elems);
-        nb.dec_store.push_back(a);
+        nb.ts.dec_store.push_back(a);
     }
     for (const Block* b : h->blocks) {
         max_act = std::max(max_act, (size_t)b->res_out * b->res_out * b->cout);
@@ -1311,7 +1371,7 @@ int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, 
     const int res = c.img_resolution, hw = res * res;
     const size_t npix = (size_t)B * hw;
     BwdScratch& q = nb.q;
-    int rc = run_forward(h, x_t, t, 1, r, 1, labels, out, B, w, s, nullptr, false, &nb.dec_store);
+    int rc = run_forward(h, x_t, t, 1, r, 1, labels, out, B, w, s, nullptr, false, &nb.ts);
     if (rc) return rc;
     const Block *aux_norm = nullptr, *aux_conv = nullptr;
     for (const Block& b : h->dec) {
@@ -1322,7 +1382,8 @@ int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, 
         return fail(FG_EINVAL, "backward: head / stem shape not covered (needs model_channels 128, 256-channel head)");
     const Act none;
     // ---- output head: F = aux_conv(silu(aux_norm(y))), out = c_skip x + c_out F ------------------------------------------------
-    const Act& y = nb.dec_store.back();
+    const Act& y = nb.ts.dec_store.back();
+    w.ab0 = nb.ts.aux_ab;
     if ((rc = norm_coeffs(1, y, 256, none, 0, h->P(aux_norm->w), h->P(aux_norm->b), w.ab0, B, hw, s, q.mr0))) return rc;
     HIP_TRY(launch_head_grad(dout, w.coef + 3 * (size_t)B, nb.dfp, B, aux_conv->cout, 128, hw, s));
     if (h->G(aux_conv->b)) {
@@ -1362,14 +1423,15 @@ int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, 
                 rcd.x2 = &w.skip[rcd.sk];
             }
             recs.push_back(rcd);
-            x = &nb.dec_store[di++];
+            x = &nb.ts.dec_store[di++];
         }
     }
     for (int i = (int)recs.size() - 1; i >= 0; --i) {
         const Block& b = *recs[i].b;
         const int c2 = b.skip_c, c1 = b.cin - c2;
         const size_t npin = (size_t)B * b.res_in * b.res_in;
-        if ((rc = block_backward(h, b, *recs[i].x, c1, c2 ? *recs[i].x2 : none, c2, w.emb, w.temb, g_cur, q.dxin, nb.demb, B, w, q, s, nb.dtemb_all)))
+        if ((rc = block_backward(h, b, *recs[i].x, c1, c2 ? *recs[i].x2 : none, c2, w.emb, w.temb, g_cur, q.dxin, nb.demb, B, w, q, s, nb.dtemb_all,
+                                 &nb.ts.blocks[block_index(h, &b)])))
             return rc;
         HIP_TRY(launch_slice_bf16(q.dxin, b.cin, 0, g_alt, c1, (int64_t)npin, 0, s));
         if (c2) HIP_TRY(launch_slice_bf16(q.dxin, b.cin, c1, nb.genc[recs[i].sk], c2, (int64_t)npin, 0, s));
@@ -1383,7 +1445,9 @@ int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, 
     // ---- encoder blocks in reverse -------------------------------------------------------------------------------------------
     for (int i = (int)h->enc.size() - 1; i >= 1; --i) {
         const Block& b = h->enc[i];
-        if ((rc = block_backward(h, b, w.skip[i - 1], b.cin, none, 0, w.emb, w.temb, nb.genc[i], q.dxin, nb.demb, B, w, q, s, nb.dtemb_all))) return rc;
+        if ((rc = block_backward(h, b, w.skip[i - 1], b.cin, none, 0, w.emb, w.temb, nb.genc[i], q.dxin, nb.demb, B, w, q, s, nb.dtemb_all,
+                                 &nb.ts.blocks[block_index(h, &b)])))
+            return rc;
         HIP_TRY(launch_add_bf16(nb.genc[i - 1], q.dxin, (int64_t)B * b.res_in * b.res_in * b.cin, s));
     }
     // ---- stem: conv(c_in * x_t) ---------------------------------------------------------------------------------------------------
