@@ -114,6 +114,7 @@ struct TrainStash {
     std::vector<Act> dec_store;      // decoder block outputs (the encoder's live on the skip stack anyway)
     std::vector<BlockStash> blocks;  // indexed like fg_edm::blocks
     float2* aux_ab = nullptr;        // coefficients of aux_norm
+    float2* aux_mr = nullptr;        // its {mean, rstd}
 };
 
 struct GraphKey {
@@ -586,8 +587,8 @@ int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, cons
             x = &dst;
             cur ^= 1;
         } else if (b.kind == K_AUX_NORM) {
-            if (ts) w.ab0 = ts->aux_ab, w.mr0 = nullptr;  // not a block's stash
-            if ((rc = norm_coeffs(h->dtype, *x, b.cin, none, 0, h->P(b.w), h->P(b.b), w.ab0, B, b.res_in * b.res_in, s))) return rc;
+            if (ts) w.ab0 = ts->aux_ab, w.mr0 = ts->aux_mr;  // not a block's stash
+            if ((rc = norm_coeffs(h->dtype, *x, b.cin, none, 0, h->P(b.w), h->P(b.b), w.ab0, B, b.res_in * b.res_in, s, ts ? w.mr0 : nullptr))) return rc;
             aux_ab = w.ab0;
         } else if (b.kind == K_AUX_CONV) {
             if (b.p_aux)
@@ -1306,6 +1307,7 @@ size_t plan_net_bwd(const fg_edm* h, int B, Arena& A, NetBwd& nb) {
     nb.ts.blocks.clear();
     nb.genc.clear();
     nb.ts.aux_ab = A.get<float2>((size_t)B * 256);
+    nb.ts.aux_mr = A.get<float2>((size_t)B * 32);
     for (const Block* b : h->blocks) {
         const size_t np = (size_t)B * b->res_out * b->res_out;
         BlockStash st;
@@ -1366,13 +1368,13 @@ size_t plan_net_bwd(const fg_edm* h, int B, Arena& A, NetBwd& nb) {
 }
 
 int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* dout, float* out,
-                 int B, Workspace& w, NetBwd& nb, hipStream_t s) {
+                 int B, Workspace& w, NetBwd& nb, hipStream_t s, bool have_forward) {
     const fg_edm_config& c = h->cfg;
     const int res = c.img_resolution, hw = res * res;
     const size_t npix = (size_t)B * hw;
     BwdScratch& q = nb.q;
-    int rc = run_forward(h, x_t, t, 1, r, 1, labels, out, B, w, s, nullptr, false, &nb.ts);
-    if (rc) return rc;
+    int rc = FG_OK;
+    if (!have_forward && (rc = run_forward(h, x_t, t, 1, r, 1, labels, out, B, w, s, nullptr, false, &nb.ts))) return rc;
     const Block *aux_norm = nullptr, *aux_conv = nullptr;
     for (const Block& b : h->dec) {
         if (b.kind == K_AUX_NORM) aux_norm = &b;
@@ -1383,8 +1385,8 @@ int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, 
     const Act none;
     // ---- output head: F = aux_conv(silu(aux_norm(y))), out = c_skip x + c_out F ------------------------------------------------
     const Act& y = nb.ts.dec_store.back();
-    w.ab0 = nb.ts.aux_ab;
-    if ((rc = norm_coeffs(1, y, 256, none, 0, h->P(aux_norm->w), h->P(aux_norm->b), w.ab0, B, hw, s, q.mr0))) return rc;
+    w.ab0 = nb.ts.aux_ab;  // aux_norm's coefficients and {mean, rstd} were left there by the kept forward
+    q.mr0 = nb.ts.aux_mr;
     HIP_TRY(launch_head_grad(dout, w.coef + 3 * (size_t)B, nb.dfp, B, aux_conv->cout, 128, hw, s));
     if (h->G(aux_conv->b)) {
         HIP_TRY(launch_colsum(nb.dfp, 128, 8, q.dtemb, B, hw, 1.0f, s));
@@ -1517,9 +1519,26 @@ size_t fg_edm_backward_workspace_bytes(const fg_edm* h, int batch) {
     return plan_net_bwd(h, batch, A, nb);
 }
 
+int fg_edm_forward_train(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, float* out, int batch,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !x_t || !t || !out) return fail(FG_EINVAL, "null argument");
+    if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
+    if (!h->dtype) return fail(FG_EINVAL, "the backward pass runs in the bf16 compute mode only");
+    if (h->cfg.r_timestep && !r) return fail(FG_EINVAL, "r is required by an r_timestep network");
+    if (batch <= 0 || !workspace || (((uintptr_t)workspace) & 255)) return fail(FG_EINVAL, "bad batch / workspace");
+    Arena A;
+    A.base = (char*)workspace;
+    Workspace w;
+    plan_workspace(h, batch, A, w);
+    NetBwd nb;
+    const size_t need = plan_net_bwd(h, batch, A, nb);
+    if (need > workspace_bytes) return fail(FG_ENOMEM, "workspace too small: need %zu bytes for batch %d, got %zu", need, batch, workspace_bytes);
+    return run_forward(h, x_t, t, 1, r, 1, labels, out, batch, w, (hipStream_t)stream, nullptr, false, &nb.ts);
+}
+
 int fg_edm_backward(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* dout,
-                    float* out, int batch, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!h || !x_t || !t || !dout || !out) return fail(FG_EINVAL, "null argument");
+                    float* out, int have_forward, int batch, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !x_t || !t || !dout || (!out && !have_forward)) return fail(FG_EINVAL, "null argument");
     if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
     if (!h->dtype) return fail(FG_EINVAL, "the backward pass runs in the bf16 compute mode only");
     if (h->cfg.r_timestep && !r) return fail(FG_EINVAL, "r is required by an r_timestep network");
@@ -1532,7 +1551,7 @@ int fg_edm_backward(fg_edm* h, const float* x_t, const double* t, const double* 
     NetBwd nb;
     const size_t need = plan_net_bwd(h, batch, A, nb);
     if (need > workspace_bytes) return fail(FG_ENOMEM, "workspace too small: need %zu bytes for batch %d, got %zu", need, batch, workspace_bytes);
-    return run_backward(h, x_t, t, r, labels, dout, out, batch, w, nb, (hipStream_t)stream);
+    return run_backward(h, x_t, t, r, labels, dout, out, batch, w, nb, (hipStream_t)stream, have_forward != 0);
 }
 
 int fg_edm_bind_grad(fg_edm* h, const char* name, float* grad, int64_t numel) {

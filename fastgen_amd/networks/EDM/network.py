@@ -75,13 +75,17 @@ class _EDMForwardFn(torch.autograd.Function):
     def forward(ctx, net, x32, t64, r64, labels, *weights):
         dev = x32.device
         dt, h = net._engine(dev)
-        ws = net._workspace(dt, h, x32.shape[0], dev)
+        ws = net._train_workspace(h, x32.shape[0], dev)
         out = torch.empty_like(x32)
-        _lib.check(_lib.lib().fg_edm_forward(
+        _lib.check(_lib.lib().fg_edm_forward_train(
             h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
             ctypes.c_void_p(r64.data_ptr() if r64 is not None else None),
-            ctypes.c_void_p(labels.data_ptr() if labels is not None else None), ctypes.c_void_p(out.data_ptr()), None,
+            ctypes.c_void_p(labels.data_ptr() if labels is not None else None), ctypes.c_void_p(out.data_ptr()),
             x32.shape[0], ctypes.c_void_p(ws.data_ptr()), ws.numel(), net._stream(dev)))
+        # the training workspace now holds this call's block inputs / intermediates; any later training forward of the module
+        # replaces the token, and the backward of this call then recomputes its forward
+        ctx.token = net._train_token = object()
+        ctx.ws_ptr = ws.data_ptr()
         ctx.net = net
         ctx.save_for_backward(x32, t64, r64 if r64 is not None else torch.empty(0), labels if labels is not None else torch.empty(0))
         ctx.has_r, ctx.has_labels = r64 is not None, labels is not None
@@ -106,11 +110,8 @@ class _EDMForwardFn(torch.autograd.Function):
                 off += p.numel()
             else:
                 grads.append(None)
-        need = L.fg_edm_backward_workspace_bytes(h, B)
-        ws = net._ws.get("bwd")
-        if ws is None or ws.numel() < need or ws.device != dev:
-            ws = torch.empty(need, dtype=torch.uint8, device=dev)
-            net._ws["bwd"] = ws
+        ws = net._train_workspace(h, B, dev)
+        have_forward = int(getattr(net, "_train_token", None) is ctx.token and ws.data_ptr() == ctx.ws_ptr)
         d32 = dout.detach().to(torch.float32).contiguous()
         scratch_out = torch.empty_like(x32)
         try:
@@ -120,8 +121,8 @@ class _EDMForwardFn(torch.autograd.Function):
             _lib.check(L.fg_edm_backward(
                 h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
                 ctypes.c_void_p(r64.data_ptr() if ctx.has_r else None), ctypes.c_void_p(labels.data_ptr() if ctx.has_labels else None),
-                ctypes.c_void_p(d32.data_ptr()), ctypes.c_void_p(scratch_out.data_ptr()), B, ctypes.c_void_p(ws.data_ptr()),
-                ws.numel(), net._stream(dev)))
+                ctypes.c_void_p(d32.data_ptr()), ctypes.c_void_p(scratch_out.data_ptr()), have_forward, B,
+                ctypes.c_void_p(ws.data_ptr()), ws.numel(), net._stream(dev)))
         finally:
             for (n, _), g in zip(named, grads):
                 if g is not None:
@@ -284,6 +285,14 @@ class EDMPrecond(FastGenNetwork):
         if ws is None or ws.numel() < need or ws.device != device:
             ws = torch.empty(need, dtype=torch.uint8, device=device)
             self._ws[dt] = ws
+        return ws
+
+    def _train_workspace(self, h, batch: int, device) -> torch.Tensor:
+        need = _lib.lib().fg_edm_backward_workspace_bytes(h, batch)
+        ws = self._ws.get("bwd")
+        if ws is None or ws.numel() < need or ws.device != device:
+            ws = torch.empty(need, dtype=torch.uint8, device=device)
+            self._ws["bwd"] = ws
         return ws
 
     @staticmethod

@@ -194,7 +194,12 @@ int fg_edm_run_block_backward(fg_edm* h, int index, const float* x1, int c1, con
  * fake-score network in fastgen/methods/distribution_matching/dmd2.py. */
 size_t fg_edm_backward_workspace_bytes(const fg_edm* h, int batch);
 int fg_edm_backward(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* dout,
-                    float* out, int batch, void* workspace, size_t workspace_bytes, void* stream);
+                    float* out, int have_forward, int batch, void* workspace, size_t workspace_bytes, void* stream);
+/* The forward half on its own (-> out), leaving in `workspace` (sized by fg_edm_backward_workspace_bytes) what the backward
+ * reads.  A following fg_edm_backward(..., have_forward = 1, same batch, same workspace, same x_t / labels) skips its own
+ * forward (out may then be NULL); nothing else may write to that workspace in between. */
+int fg_edm_forward_train(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, float* out, int batch,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* Samples to image bytes, the step after generator_fn in the reference's sample writer
  * (scripts/fid/compute_fid_from_ckpts.py:199): out[n,y,x,c] = uint8(clip(images[n,c,y,x] * 127.5 + 128, 0, 255)),

@@ -689,7 +689,7 @@ def _net_backward(net, sd, x, t, cond, dout):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
             out = torch.empty_like(x, device=dev())
             xd, td, cd, dd = x.to(dev()), t.to(dev()), cond.to(dev()).contiguous(), dout.to(dev())
-            _lib.check(L.fg_edm_backward(h, xd.data_ptr(), td.data_ptr(), None, cd.data_ptr(), dd.data_ptr(), out.data_ptr(), B,
+            _lib.check(L.fg_edm_backward(h, xd.data_ptr(), td.data_ptr(), None, cd.data_ptr(), dd.data_ptr(), out.data_ptr(), 0, B,
                                          ws.data_ptr(), nbytes, None))
             torch.cuda.synchronize()
         finally:
@@ -752,6 +752,15 @@ def test_module_autograd_through_the_hip_backward(nets, golden_dir):
         (net(x, t, condition=cond, fwd_pred_type="x0") * dout).sum().backward()
         second = params["model.enc.16x16_block1.conv1.weight"].grad
         assert torch.allclose(second, 2 * first, rtol=1e-5, atol=1e-6 * float(first.abs().max()))  # deterministic and accumulated
+        # two forwards before the first backward: the older call's kept state is gone, its backward recomputes the forward
+        net.zero_grad(set_to_none=True)
+        o1 = net(x, t, condition=cond, fwd_pred_type="x0")
+        o2 = net(x * 0.5, t, condition=cond, fwd_pred_type="x0")
+        (o1 * dout).sum().backward()
+        again = params["model.enc.16x16_block1.conv1.weight"].grad.clone()
+        assert torch.allclose(again, first, rtol=1e-5, atol=1e-6 * float(first.abs().max()))
+        (o2 * dout).sum().backward()
+        assert torch.isfinite(params["model.enc.16x16_block1.conv1.weight"].grad).all()
         with pytest.raises(NotImplementedError):
             net(x.clone().requires_grad_(True), t, condition=cond)
         with pytest.raises(NotImplementedError):
