@@ -167,18 +167,24 @@ __global__ void gn_bwd_group_kernel(const float2* __restrict__ P, const float* _
 }
 
 // ---- dgamma[c] += sum_n P2, dbeta[c] += sum_n P1 (fixed order) ---------------------------------------------------------------
-__global__ void gn_bwd_param_kernel(const float2* __restrict__ P, float* __restrict__ dgamma, float* __restrict__ dbeta, int B,
-                                    int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// 64 channels x 4 batch lanes per workgroup: the batch loop is B/4 deep, combined in a fixed order
+__global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float2* __restrict__ P, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int B, int C) {
+    __shared__ float sg[4][64], sb[4][64];
+    const int cl = threadIdx.x & 63, nl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     float g = 0.f, b = 0.f;
-    for (int n = 0; n < B; ++n) {
-        const float2 p = P[(size_t)n * C + c];
-        b += p.x;
-        g += p.y;
+    if (c < C)
+        for (int n = nl; n < B; n += 4) {
+            const float2 p = P[(size_t)n * C + c];
+            b += p.x;
+            g += p.y;
+        }
+    sg[nl][cl] = g, sb[nl][cl] = b;
+    __syncthreads();
+    if (nl == 0 && c < C) {
+        if (dgamma) dgamma[c] += (sg[0][cl] + sg[1][cl]) + (sg[2][cl] + sg[3][cl]);
+        if (dbeta) dbeta[c] += (sb[0][cl] + sb[1][cl]) + (sb[2][cl] + sb[3][cl]);
     }
-    if (dgamma) dgamma[c] += g;
-    if (dbeta) dbeta[c] += b;
 }
 
 // ---- dx = a dy - rstd (S1 + xhat S2) / m  [+ add_scale * add]; dx is [B,HW,C] over the whole concat ---------------------------
@@ -244,12 +250,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ 
 }
 
 // out[c] += sum_n in[n][c]
-__global__ void batchsum_add_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// (two destinations: a block's conv1 and skip biases receive the same sum)
+__global__ __launch_bounds__(256) void batchsum_add_kernel(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ out2,
+                                                           int B, int C) {
+    __shared__ float sa[4][64];
+    const int cl = threadIdx.x & 63, nl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     float a = 0.f;
-    for (int n = 0; n < B; ++n) a += in[(size_t)n * C + c];
-    out[c] += a;
+    if (c < C)
+        for (int n = nl; n < B; n += 4) a += in[(size_t)n * C + c];
+    sa[nl][cl] = a;
+    __syncthreads();
+    if (nl == 0 && c < C) {
+        const float t = (sa[0][cl] + sa[1][cl]) + (sa[2][cl] + sa[3][cl]);
+        out[c] += t;
+        if (out2) out2[c] += t;
+    }
 }
 
 // fp32 -> bf16 with a scale (gradient entering the block: dOut * skip_scale)
@@ -414,7 +429,7 @@ int launch_gn_bwd(int mode, const void* x1, int c1, const void* x2, int c2, cons
     else
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<1>, rg, dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, P, res, rm);
     hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(B), dim3(32), 0, s, P, gamma, S, C);
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, s, P, dgamma, dbeta, B, C);
+    if (dgamma || dbeta) hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 63) / 64), dim3(256), 0, s, P, dgamma, dbeta, B, C);
     const int64_t total = (int64_t)B * hw * (C / 8);
     if (mode == 0)
         hipLaunchKernelGGL(gn_bwd_apply_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, S, A, ca, add_scale, (__bf16*)dx, total, res, rm);
@@ -430,8 +445,8 @@ int launch_colsum(const void* t, int ct, int C, float* out, int B, int hw, float
                        out_stride > 0 ? out_stride : C);
     BWD_RET();
 }
-int launch_batchsum_add(const float* in, float* out, int B, int C, hipStream_t s) {
-    hipLaunchKernelGGL(batchsum_add_kernel, dim3((C + 255) / 256), dim3(256), 0, s, in, out, B, C);
+int launch_batchsum_add(const float* in, float* out, int B, int C, hipStream_t s, float* out2) {
+    hipLaunchKernelGGL(batchsum_add_kernel, dim3((C + 63) / 64), dim3(256), 0, s, in, out, out2, B, C);
     BWD_RET();
 }
 int launch_scale_to_bf16(const float* in, void* out, float scale, int64_t total, hipStream_t s) {
@@ -490,7 +505,7 @@ int launch_linear_bwd(const float* dy, const float* x, const float* w, float* dw
                       float scale, hipStream_t s, int dy_stride) {
     if ((db || dx) && dy_stride > 0 && dy_stride != C) return (int)hipErrorInvalidValue;  // only the weight part takes a stride
     if (dw) hipLaunchKernelGGL(linear_wgrad_kernel, dim3((C * K + 255) / 256), dim3(256), 0, s, dy, x, dw, B, C, K, scale, dy_stride > 0 ? dy_stride : C);
-    if (db) hipLaunchKernelGGL(batchsum_add_kernel, dim3((C + 255) / 256), dim3(256), 0, s, dy, db, B, C);
+    if (db) hipLaunchKernelGGL(batchsum_add_kernel, dim3((C + 63) / 64), dim3(256), 0, s, dy, db, (float*)nullptr, B, C);
     if (dx) hipLaunchKernelGGL(affine_dgrad_kernel, dim3((B * K + 255) / 256), dim3(256), 0, s, dy, w, dx, B, C, K);
     BWD_RET();
 }

@@ -1240,8 +1240,11 @@ int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& 
     // x_mid = (conv1(act1) + skip) * sigma  =>  g1 = sigma * gout reaches conv1's output and the skip path alike
     HIP_TRY(launch_scale_bf16(gout, q.g1, kSkipScale, (int64_t)npix * cout, s));
     HIP_TRY(launch_colsum(q.g1, cout, cout, q.dtemb, B, hw, 1.0f, s));
-    if (h->G(b.conv1_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.conv1_b), B, cout, s));
-    if (b.has_skip && h->G(b.skip_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.skip_b), B, cout, s));
+    {
+        float* d1 = h->G(b.conv1_b);
+        float* d2 = b.has_skip ? h->G(b.skip_b) : nullptr;
+        if (d1 || d2) HIP_TRY(launch_batchsum_add(q.dtemb, d1 ? d1 : d2, B, cout, s, d1 ? d2 : nullptr));
+    }
     // conv1
     if (h->G(b.conv1_w)) {
         HIP_TRY(launch_gn_act(0, w.h.p, cout, nullptr, 0, w.ab1, q.aop, B, res, 0, s));

@@ -38,7 +38,7 @@ int launch_gn_bwd(int mode, const void* x1, int c1, const void* x2, int c2, cons
                   float add_scale, void* dx, int B, int res, int rm, hipStream_t s);  // res = the norm's (input) resolution
 int launch_colsum(const void* t, int ct, int C, float* out, int B, int hw, float scale, hipStream_t s, int out_stride = 0);
 int launch_transpose_f32(const float* in, float* out, int R, int Cc, hipStream_t s);
-int launch_batchsum_add(const float* in, float* out, int B, int C, hipStream_t s);
+int launch_batchsum_add(const float* in, float* out, int B, int C, hipStream_t s, float* out2 = nullptr);
 int launch_scale_to_bf16(const float* in, void* out, float scale, int64_t total, hipStream_t s);
 int launch_scale_bf16(const void* in, void* out, float scale, int64_t total, hipStream_t s);
 int launch_slice_to_f32(const void* in, int cs, int c_off, float* out, int C, int64_t npix, hipStream_t s);

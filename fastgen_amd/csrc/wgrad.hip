@@ -26,7 +26,7 @@ namespace {
 constexpr int WG_THREADS = 256;
 constexpr int WG_CO = 128;       // output channels per workgroup (4 waves x 32)
 constexpr int WG_CI = 32;        // input channels per workgroup
-constexpr int WG_TILE = 64;      // pixels per tile = 4 MFMA k-steps of 16
+constexpr int WG_TILE = 64;      // pixels per tile = 4 MFMA k-steps of 16 (128 = 8 rows for the 3x3 kernel at width >= 16)
 constexpr int WG_DYP = 2 * WG_CO + 64;  // dY tile row pitch in bytes: 4 consecutive rows tile the 64 banks (320 = 64 mod 256)
 constexpr int WG_AP = 2 * WG_CI;        // A tile bytes per (halo) pixel
 
@@ -57,14 +57,16 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const __bf16*
                                                                    int tiles_per_split) {
     constexpr int W = 1 << LOGW;
     constexpr int TW = (W >= 16) ? 16 : 8;    // tile width; a k-step is 16 pixels = one tile row (two rows at 8x8)
-    constexpr int TH = WG_TILE / TW;          // 4 or 8
+    constexpr bool ROLL = (KS == 3 && TW == 16);  // 8-row tiles with a rolling window of halo-row fragments
+    constexpr int TPX = ROLL ? 128 : WG_TILE;     // pixels per tile
+    constexpr int TH = TPX / TW;                  // 8, 4 (1x1 at width >= 16) or 8 (8x8 images)
     constexpr int PAD = KS / 2;
     constexpr int HW_ = TW + 2 * PAD, HH_ = TH + 2 * PAD;
     constexpr int HALO = HW_ * HH_;           // 108 (3x3 at W >= 16), 100 (3x3 at 8x8), 64 (1x1)
     constexpr int TAPS = KS * KS;
     constexpr int TCOLS = W / TW, TPI = (W / TH) * TCOLS;
 
-    __shared__ __attribute__((aligned(16))) char s_dy[WG_TILE * WG_DYP];
+    __shared__ __attribute__((aligned(16))) char s_dy[TPX * WG_DYP];
     __shared__ __attribute__((aligned(16))) char s_a[HALO * WG_AP];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const __bf16*
         const int row0 = (slot / TCOLS) * TH, col0 = (slot % TCOLS) * TW;
         // ---- park the tiles in LDS as they lie in memory ---------------------------------------------------------
 #pragma unroll
-        for (int i = 0; i < (WG_TILE * WG_CO * 2 / 16) / WG_THREADS; ++i) {  // 4 x 16 bytes per thread
+        for (int i = 0; i < (TPX * WG_CO * 2 / 16) / WG_THREADS; ++i) {  // 4 (8) x 16 bytes per thread
             const int c = tid + WG_THREADS * i;
             const int k = c >> 4, ch = c & 15;  // 16 chunks of 8 channels per pixel
             const int y = row0 + k / TW, x = col0 + k % TW;
@@ -107,9 +109,30 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const __bf16*
             *reinterpret_cast<uint4*>(s_a + hp * WG_AP + ch * 16) = v;
         }
         __syncthreads();
-        // ---- 4 k-steps x taps MFMAs ----------------------------------------------------------------------------------
+        // ---- k-steps x taps MFMAs ------------------------------------------------------------------------------------
+        if constexpr (ROLL) {
+            // Tap (ky, kx) of tile row s reads halo row s + ky shifted by kx: the same fragment serves (s, ky), (s+1, ky-1) and
+            // (s+2, ky-2).  Keep three halo rows x three shifts in registers (slot = halo row % 3); each k-step fetches only
+            // the row that enters (s + 2), early enough that the six MFMAs of rows s and s + 1 cover the LDS latency:
+            // 8 transposed reads per 9 MFMAs instead of 20 - the LDS read port was the bottleneck of the plain form.
+            Frag8<__bf16> F[3][3];
+            auto load_row = [&](int hr) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < WG_TILE / 16; ++s) {
+                for (int kx = 0; kx < 3; ++kx)
+                    F[hr % 3][kx] = tr_frag(a_lane + (hr * HW_ + kx) * WG_AP, a_lane + (hr * HW_ + kx + 4) * WG_AP);
+            };
+            load_row(0);
+            load_row(1);
+#pragma unroll
+            for (int s = 0; s < TH; ++s) {
+                load_row(s + 2);
+                const Frag8<__bf16> fa = tr_frag(dy_lane + (16 * s) * WG_DYP, dy_lane + (16 * s + 4) * WG_DYP);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) mma16(acc[tap], fa, F[(s + tap / 3) % 3][tap % 3]);
+            }
+        } else
+#pragma unroll
+        for (int s = 0; s < TPX / 16; ++s) {
             const Frag8<__bf16> fa = tr_frag(dy_lane + (16 * s) * WG_DYP, dy_lane + (16 * s + 4) * WG_DYP);
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
@@ -122,7 +145,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const __bf16*
         }
         __syncthreads();
     }
-    // ---- partial[split][co][ci][tap]: lane holds column ci = lane & 31, rows co = acc_row(i, lane >> 5) ------------------
+    // ---- partial[split][tap][co][ci] (ci contiguous: a lane group writes 128 consecutive bytes): lane holds column
+    // ci = lane & 31, rows co = acc_row(i, lane >> 5) ---------------------------------------------------------------------
     float* dst = partial + (size_t)split * Cout * Cin * TAPS;
     const int ci = ci0 + (lane & 31), h = lane >> 5;
 #pragma unroll
@@ -130,35 +154,38 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const __bf16*
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int co = cob + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
-            dst[((size_t)co * Cin + ci) * TAPS + tap] = acc[tap][i];
+            dst[((size_t)tap * Cout + co) * Cin + ci] = acc[tap][i];
         }
 }
 
-// dW (+)= sum over splits, fixed order
+// dW[co][ci][tap] (+)= sum over splits of partial[split][tap][co][ci], fixed order; thread i walks the partial layout
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, size_t n,
-                                                           int splits, int accumulate) {
+                                                           int splits, int accumulate, int CC, int taps) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float s = accumulate ? dw[i] : 0.f;
+    float s = 0.f;
     for (int k = 0; k < splits; ++k) s += partial[(size_t)k * n + i];
-    dw[i] = s;
+    const size_t tap = i / CC, cc = i - tap * CC;  // cc = co * Cin + ci
+    float* o = dw + cc * taps + tap;
+    *o = accumulate ? *o + s : s;
 }
 
-int tiles_per_image(int res) { return res >= 16 ? (res / 4) * (res / 16) : 1; }
+// tiles are 8 x 16 pixels for the 3x3 kernel at width >= 16, 4 x 16 for the 1x1 kernel, one image at 8x8
+int tiles_per_image(int res, int ks) { return res >= 16 ? (res / (ks == 3 ? 8 : 4)) * (res / 16) : 1; }
 
 }  // namespace
 
-int conv_wgrad_splits(int B, int res, int cin, int cout) {
+int conv_wgrad_splits(int B, int res, int cin, int cout, int ks) {
     const int blocks = (cin / WG_CI) * (cout / WG_CO);
-    const int ntiles = B * tiles_per_image(res);
-    int splits = (512 + blocks - 1) / blocks;  // about two workgroups per CU
-    if (splits > ntiles) splits = ntiles;
+    const int ntiles = B * tiles_per_image(res, ks);
+    int splits = (512 + blocks - 1) / blocks;  // about two workgroups per CU ...
+    if (splits > ntiles / 8) splits = ntiles / 8;  // ... but at least 8 tiles per split: the partials cost HBM traffic
     if (splits < 1) splits = 1;
     return splits;
 }
 
 size_t conv_wgrad_workspace_bytes(int B, int res, int cin, int cout, int ks) {
-    return (size_t)conv_wgrad_splits(B, res, cin, cout) * cout * cin * ks * ks * sizeof(float);
+    return (size_t)conv_wgrad_splits(B, res, cin, cout, ks) * cout * cin * ks * ks * sizeof(float);
 }
 
 int conv_wgrad_supported(int res, int cin, int cout, int ks) {
@@ -168,8 +195,8 @@ int conv_wgrad_supported(int res, int cin, int cout, int ks) {
 int launch_conv_wgrad(const void* act, const void* dy, float* dw, int B, int res, int cin, int cout, int ks, int accumulate,
                       void* workspace, hipStream_t s) {
     if (!conv_wgrad_supported(res, cin, cout, ks) || B <= 0) return (int)hipErrorInvalidValue;
-    const int splits = conv_wgrad_splits(B, res, cin, cout);
-    const int ntiles = B * tiles_per_image(res);
+    const int splits = conv_wgrad_splits(B, res, cin, cout, ks);
+    const int ntiles = B * tiles_per_image(res, ks);
     const int tps = (ntiles + splits - 1) / splits;
     dim3 grid(cin / WG_CI, splits, cout / WG_CO);
     const __bf16* a = (const __bf16*)act;
@@ -189,6 +216,7 @@ int launch_conv_wgrad(const void* act, const void* dy, float* dw, int B, int res
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const size_t n = (size_t)cout * cin * ks * ks;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, dw, n, splits, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, dw, n, splits, accumulate,
+                       cout * cin, ks * ks);
     return (int)hipGetLastError();
 }
