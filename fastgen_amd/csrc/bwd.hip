@@ -392,6 +392,28 @@ __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restr
         if (c0 + i < Cc && r0 + tx < R) out[(size_t)(c0 + i) * R + r0 + tx] = tile[tx][i];
 }
 
+// dst[n][p][c] (bf16 NHWC) += src[n][c][p] (fp32 NCHW): a feature tap's gradient joins the encoder output's gradient
+__global__ void add_nchw_to_nhwc_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int C, int HW, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t pix = i / C;
+        const int64_t n = pix / HW, p = pix - n * HW;
+        dst[i] = (__bf16)((float)dst[i] + src[(n * C + c) * HW + p]);
+    }
+}
+// dx[n][c][p] = c_in[n] * da[n][p][c] (+ c_skip[n] * dout[n][c][p]): gradient of the network input (precond_input / precond_output)
+__global__ void input_grad_kernel(const __bf16* __restrict__ da, int Cd, const float* __restrict__ c_in, const float* __restrict__ c_skip,
+                                  const float* __restrict__ dout, float* __restrict__ dx, int C, int HW, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = i % HW;
+        const int c = (int)((i / HW) % C);
+        const int64_t n = i / ((int64_t)HW * C);
+        float v = c_in[n] * (float)da[(n * HW + p) * Cd + c];
+        if (dout) v = fmaf(c_skip[n], dout[i], v);
+        dx[i] = v;
+    }
+}
+
 inline unsigned ew_blocks(int64_t n) {
     const int64_t b = (n + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
@@ -511,5 +533,16 @@ int launch_linear_bwd(const float* dy, const float* x, const float* w, float* dw
 }
 int launch_transpose_f32(const float* in, float* out, int R, int Cc, hipStream_t s) {
     hipLaunchKernelGGL(transpose_f32_kernel, dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, s, in, out, R, Cc);
+    BWD_RET();
+}
+int launch_add_nchw_to_nhwc(const float* src, void* dst, int B, int C, int hw, hipStream_t s) {
+    const int64_t total = (int64_t)B * C * hw;
+    hipLaunchKernelGGL(add_nchw_to_nhwc_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, src, (__bf16*)dst, C, hw, total);
+    BWD_RET();
+}
+int launch_input_grad(const void* da, int cd, const float* c_in, const float* c_skip, const float* dout, float* dx, int B, int C, int hw,
+                      hipStream_t s) {
+    const int64_t total = (int64_t)B * C * hw;
+    hipLaunchKernelGGL(input_grad_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)da, cd, c_in, c_skip, dout, dx, C, hw, total);
     BWD_RET();
 }

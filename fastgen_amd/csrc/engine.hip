@@ -1370,14 +1370,18 @@ size_t plan_net_bwd(const fg_edm* h, int B, Arena& A, NetBwd& nb) {
     return A.off;
 }
 
+// dout == nullptr: only the encoder is differentiated (the forward returned the feature taps early); dfeats[tap] (nullable, NCHW
+// fp32) joins the gradient of that tap's encoder output; dx_t (nullable) receives the gradient of the network input.
 int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* dout, float* out,
-                 int B, Workspace& w, NetBwd& nb, hipStream_t s, bool have_forward) {
+                 int B, Workspace& w, NetBwd& nb, hipStream_t s, bool have_forward, const float* const* dfeats = nullptr,
+                 float* dx_t = nullptr) {
     const fg_edm_config& c = h->cfg;
     const int res = c.img_resolution, hw = res * res;
     const size_t npix = (size_t)B * hw;
     BwdScratch& q = nb.q;
     int rc = FG_OK;
-    if (!have_forward && (rc = run_forward(h, x_t, t, 1, r, 1, labels, out, B, w, s, nullptr, false, &nb.ts))) return rc;
+    const bool early = dout == nullptr;
+    if (!have_forward && (rc = run_forward(h, x_t, t, 1, r, 1, labels, out, B, w, s, nullptr, early, &nb.ts))) return rc;
     const Block *aux_norm = nullptr, *aux_conv = nullptr;
     for (const Block& b : h->dec) {
         if (b.kind == K_AUX_NORM) aux_norm = &b;
@@ -1386,6 +1390,12 @@ int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, 
     if (!aux_norm || !aux_conv || aux_conv->cin != 256 || aux_conv->cout > 8 || h->enc[0].cout != 128 || h->enc[0].cin > 8)
         return fail(FG_EINVAL, "backward: head / stem shape not covered (needs model_channels 128, 256-channel head)");
     const Act none;
+    if (early) {
+        // nothing downstream of the encoder: the gradients start at the feature taps
+        for (size_t i = 0; i < h->enc.size(); ++i)
+            HIP_TRY(hipMemsetAsync(nb.genc[i], 0, (size_t)B * h->enc[i].res_out * h->enc[i].res_out * h->enc[i].cout * 2, s));
+        HIP_TRY(hipMemsetAsync(nb.dtemb_all, 0, sizeof(float) * (size_t)B * h->temb_total, s));  // decoder blocks contribute nothing
+    } else {
     // ---- output head: F = aux_conv(silu(aux_norm(y))), out = c_skip x + c_out F ------------------------------------------------
     const Act& y = nb.ts.dec_store.back();
     w.ab0 = nb.ts.aux_ab;  // aux_norm's coefficients and {mean, rstd} were left there by the kept forward
@@ -1447,6 +1457,13 @@ int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, 
         const Block& last = h->enc.back();
         HIP_TRY(launch_add_bf16(nb.genc.back(), g_cur, (int64_t)B * last.res_out * last.res_out * last.cout, s));
     }
+    }  // !early
+    // gradients arriving at the feature taps (the encoder's `block3` outputs, EDM/network.py:535-539)
+    if (dfeats)
+        for (size_t i = 0; i < h->enc.size(); ++i) {
+            const Block& b = h->enc[i];
+            if (b.tap >= 0 && dfeats[b.tap]) HIP_TRY(launch_add_nchw_to_nhwc(dfeats[b.tap], nb.genc[i], B, b.cout, b.res_out * b.res_out, s));
+        }
     // ---- encoder blocks in reverse -------------------------------------------------------------------------------------------
     for (int i = (int)h->enc.size() - 1; i >= 1; --i) {
         const Block& b = h->enc[i];
@@ -1466,6 +1483,11 @@ int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, 
             HIP_TRY(launch_stem_operand(x_t, w.coef, nb.op32, B, b.cin, 32, hw, s));
             if ((rc = wgrad_checked(nb.op32, nb.genc[0], nb.wtmp, B, res, 32, b.cout, 3, 0, nb.wgx, nb.wgx_bytes, s))) return rc;
             HIP_TRY(launch_add_sub_tensor(nb.wtmp, 32, h->G(b.w), b.cout, b.cin, 9, s));
+        }
+        if (dx_t) {
+            // d x_t = c_in * conv^T(g, W_stem)  (+ c_skip * dout through precond_output); drop_precond 'input' has c_in = 1
+            if ((rc = conv_dgrad(h, h->P(b.w), b.cout, b.cin, 3, nb.genc[0], q.da, B, res, q, s))) return rc;
+            HIP_TRY(launch_input_grad(q.da, 256, w.coef, w.coef + 2 * (size_t)B, dout, dx_t, B, b.cin, hw, s));
         }
     }
     // ---- all 33 embedding affines at once (stacked as in the forward): biases, weights, and demb = dtemb_all @ aff_w ---------------
@@ -1522,9 +1544,9 @@ size_t fg_edm_backward_workspace_bytes(const fg_edm* h, int batch) {
     return plan_net_bwd(h, batch, A, nb);
 }
 
-int fg_edm_forward_train(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, float* out, int batch,
-                         void* workspace, size_t workspace_bytes, void* stream) {
-    if (!h || !x_t || !t || !out) return fail(FG_EINVAL, "null argument");
+int fg_edm_forward_train(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, float* out,
+                         float* const* features, int batch, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !x_t || !t || (!out && !features)) return fail(FG_EINVAL, "null argument");
     if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
     if (!h->dtype) return fail(FG_EINVAL, "the backward pass runs in the bf16 compute mode only");
     if (h->cfg.r_timestep && !r) return fail(FG_EINVAL, "r is required by an r_timestep network");
@@ -1536,12 +1558,19 @@ int fg_edm_forward_train(fg_edm* h, const float* x_t, const double* t, const dou
     NetBwd nb;
     const size_t need = plan_net_bwd(h, batch, A, nb);
     if (need > workspace_bytes) return fail(FG_ENOMEM, "workspace too small: need %zu bytes for batch %d, got %zu", need, batch, workspace_bytes);
-    return run_forward(h, x_t, t, 1, r, 1, labels, out, batch, w, (hipStream_t)stream, nullptr, false, &nb.ts);
+    return run_forward(h, x_t, t, 1, r, 1, labels, out, batch, w, (hipStream_t)stream, features, out == nullptr, &nb.ts);
 }
 
 int fg_edm_backward(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* dout,
                     float* out, int have_forward, int batch, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!h || !x_t || !t || !dout || (!out && !have_forward)) return fail(FG_EINVAL, "null argument");
+    return fg_edm_backward_ex(h, x_t, t, r, labels, dout, nullptr, out, nullptr, have_forward, batch, workspace, workspace_bytes, stream);
+}
+
+int fg_edm_backward_ex(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* dout,
+                       const float* const* dfeatures, float* out, float* dx_t, int have_forward, int batch, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+    if (!h || !x_t || !t || (!dout && !dfeatures)) return fail(FG_EINVAL, "null argument");
+    if (dout && !out && !have_forward) return fail(FG_EINVAL, "out is required when the forward runs here");
     if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
     if (!h->dtype) return fail(FG_EINVAL, "the backward pass runs in the bf16 compute mode only");
     if (h->cfg.r_timestep && !r) return fail(FG_EINVAL, "r is required by an r_timestep network");
@@ -1554,7 +1583,7 @@ int fg_edm_backward(fg_edm* h, const float* x_t, const double* t, const double* 
     NetBwd nb;
     const size_t need = plan_net_bwd(h, batch, A, nb);
     if (need > workspace_bytes) return fail(FG_ENOMEM, "workspace too small: need %zu bytes for batch %d, got %zu", need, batch, workspace_bytes);
-    return run_backward(h, x_t, t, r, labels, dout, out, batch, w, nb, (hipStream_t)stream, have_forward != 0);
+    return run_backward(h, x_t, t, r, labels, dout, out, batch, w, nb, (hipStream_t)stream, have_forward != 0, dfeatures, dx_t);
 }
 
 int fg_edm_bind_grad(fg_edm* h, const char* name, float* grad, int64_t numel) {

@@ -53,6 +53,9 @@ int launch_slice_bf16(const void* src, int cs, int off, void* dst, int C, int64_
 int launch_silu_bwd(const float* dy, const float* pre, float* dpre, int total, hipStream_t s);
 int launch_linear_bwd(const float* dy, const float* x, const float* w, float* dw, float* db, float* dx, int B, int C, int K,
                       float scale, hipStream_t s, int dy_stride = 0);
+int launch_add_nchw_to_nhwc(const float* src, void* dst, int B, int C, int hw, hipStream_t s);
+int launch_input_grad(const void* da, int cd, const float* c_in, const float* c_skip, const float* dout, float* dx, int B, int C, int hw,
+                      hipStream_t s);
 // attn_bwd.hip
 size_t attention_backward_scratch_bytes(int B, int T, int C);
 int launch_attention_backward(const void* q, const void* k, const void* vt, const void* dO, void* dq, void* dk, void* dvt,

@@ -67,32 +67,44 @@ def _init_value(name: str, shape) -> torch.Tensor:
 
 
 class _EDMForwardFn(torch.autograd.Function):
-    """EDMPrecond.forward with parameter gradients: forward = fg_edm_forward, backward = fg_edm_backward (the forward is
-    recomputed block by block inside it; nothing but the inputs is kept between the two calls).  The parameters are passed
-    as inputs so that autograd accumulates into their .grad and DDP hooks fire, as for the reference module."""
+    """EDMPrecond.forward under autograd.  forward = fg_edm_forward_train (which leaves every block's inputs and intermediates
+    in the module's training workspace), backward = fg_edm_backward_ex.  Differentiable outputs: the prediction (unless the
+    feature taps are returned early) and the requested feature taps; differentiable inputs: the parameters (passed as inputs so
+    that autograd accumulates into their .grad and DDP hooks fire, as for the reference module) and x_t."""
 
     @staticmethod
-    def forward(ctx, net, x32, t64, r64, labels, *weights):
-        dev = x32.device
+    def forward(ctx, net, x32, t64, r64, labels, taps, early, *weights):
+        dev, B = x32.device, x32.shape[0]
+        L = _lib.lib()
         dt, h = net._engine(dev)
-        ws = net._train_workspace(h, x32.shape[0], dev)
-        out = torch.empty_like(x32)
-        _lib.check(_lib.lib().fg_edm_forward_train(
+        ws = net._train_workspace(h, B, dev)
+        out = None if early else torch.empty_like(x32)
+        ntap = L.fg_edm_num_feature_taps(h)
+        ptrs = (ctypes.c_void_p * max(ntap, 1))()
+        feats = []
+        ch, res = ctypes.c_int(), ctypes.c_int()
+        for i in taps:
+            _lib.check(L.fg_edm_feature_info(h, i, None, ctypes.byref(ch), ctypes.byref(res)))
+            f = torch.empty(B, ch.value, res.value, res.value, dtype=torch.float32, device=dev)
+            ptrs[i] = f.data_ptr()
+            feats.append(f)
+        _lib.check(L.fg_edm_forward_train(
             h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
             ctypes.c_void_p(r64.data_ptr() if r64 is not None else None),
-            ctypes.c_void_p(labels.data_ptr() if labels is not None else None), ctypes.c_void_p(out.data_ptr()),
-            x32.shape[0], ctypes.c_void_p(ws.data_ptr()), ws.numel(), net._stream(dev)))
-        # the training workspace now holds this call's block inputs / intermediates; any later training forward of the module
-        # replaces the token, and the backward of this call then recomputes its forward
+            ctypes.c_void_p(labels.data_ptr() if labels is not None else None),
+            ctypes.c_void_p(out.data_ptr() if out is not None else None), ptrs if taps else None,
+            B, ctypes.c_void_p(ws.data_ptr()), ws.numel(), net._stream(dev)))
+        # the training workspace now holds this call's state; any later training forward of the module replaces the token, and
+        # the backward of this call then recomputes its forward
         ctx.token = net._train_token = object()
         ctx.ws_ptr = ws.data_ptr()
-        ctx.net = net
+        ctx.net, ctx.taps, ctx.early, ctx.ntap = net, taps, early, ntap
         ctx.save_for_backward(x32, t64, r64 if r64 is not None else torch.empty(0), labels if labels is not None else torch.empty(0))
         ctx.has_r, ctx.has_labels = r64 is not None, labels is not None
-        return out
+        return tuple(([] if early else [out]) + feats)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, *douts):
         net = ctx.net
         x32, t64, r64, labels = ctx.saved_tensors
         dev, B = x32.device, x32.shape[0]
@@ -102,33 +114,52 @@ class _EDMForwardFn(torch.autograd.Function):
         assert dt == _lib.FG_DTYPE_BF16
         named = net._named_weights()
         # one zero-filled fp32 buffer, one view per trainable parameter (a fill per parameter costs 400+ launches)
-        flat = torch.zeros(sum(p.numel() for _, p in named if p.requires_grad), dtype=torch.float32, device=dev)
+        need_w = [p.requires_grad and ctx.needs_input_grad[7 + i] for i, (_, p) in enumerate(named)]
+        flat = torch.zeros(sum(p.numel() for (_, p), nw in zip(named, need_w) if nw), dtype=torch.float32, device=dev)
         grads, off = [], 0
-        for _, p in named:
-            if p.requires_grad:
+        for (_, p), nw in zip(named, need_w):
+            if nw:
                 grads.append(flat[off:off + p.numel()].view(p.shape))
                 off += p.numel()
             else:
                 grads.append(None)
         ws = net._train_workspace(h, B, dev)
         have_forward = int(getattr(net, "_train_token", None) is ctx.token and ws.data_ptr() == ctx.ws_ptr)
-        d32 = dout.detach().to(torch.float32).contiguous()
-        scratch_out = torch.empty_like(x32)
+        douts = list(douts)
+        d_out = None if ctx.early else douts.pop(0)
+        keep = []  # contiguous fp32 copies must outlive the call
+        d32 = None
+        if d_out is not None:
+            d32 = d_out.detach().to(torch.float32).contiguous()
+        elif not ctx.early:
+            d32 = torch.zeros_like(x32)  # only the feature taps carry gradient
+        dptrs = (ctypes.c_void_p * max(ctx.ntap, 1))()
+        any_feat = False
+        for i, g in zip(ctx.taps, douts):
+            if g is not None:
+                g32 = g.detach().to(torch.float32).contiguous()
+                keep.append(g32)
+                dptrs[i] = g32.data_ptr()
+                any_feat = True
+        dx = torch.empty_like(x32) if ctx.needs_input_grad[1] else None
+        scratch_out = None if ctx.early else torch.empty_like(x32)
         try:
             for (n, _), g in zip(named, grads):
                 if g is not None:
                     _lib.check(L.fg_edm_bind_grad(h, n.encode(), ctypes.c_void_p(g.data_ptr()), g.numel()))
-            _lib.check(L.fg_edm_backward(
+            _lib.check(L.fg_edm_backward_ex(
                 h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
                 ctypes.c_void_p(r64.data_ptr() if ctx.has_r else None), ctypes.c_void_p(labels.data_ptr() if ctx.has_labels else None),
-                ctypes.c_void_p(d32.data_ptr()), ctypes.c_void_p(scratch_out.data_ptr()), have_forward, B,
+                ctypes.c_void_p(d32.data_ptr() if d32 is not None else None), dptrs if (any_feat or ctx.early) else None,
+                ctypes.c_void_p(scratch_out.data_ptr() if scratch_out is not None else None),
+                ctypes.c_void_p(dx.data_ptr() if dx is not None else None), have_forward, B,
                 ctypes.c_void_p(ws.data_ptr()), ws.numel(), net._stream(dev)))
         finally:
             for (n, _), g in zip(named, grads):
                 if g is not None:
                     _lib.check(L.fg_edm_bind_grad(h, n.encode(), None, 0))
         grads = [g.to(p.dtype) if g is not None else None for (_, p), g in zip(named, grads)]
-        return (None, None, None, None, None, *grads)
+        return (None, dx, None, None, None, None, None, *grads)
 
 
 class EDMPrecond(FastGenNetwork):
@@ -299,20 +330,20 @@ class EDMPrecond(FastGenNetwork):
     def _stream(device) -> ctypes.c_void_p:
         return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
-    def _needs_grad(self) -> bool:
-        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+    def _needs_grad(self, x_t: Optional[torch.Tensor] = None) -> bool:
+        return torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
+                                            or (x_t is not None and x_t.requires_grad))
 
-    def _check_trainable_call(self, x_t, feature_indices, return_logvar):
-        """Autograd through the module is provided for the parameter gradients of the plain forward in the bf16 compute mode
-        (fg_edm_backward: what the DMD2 student / fake-score updates need, dmd2.py); everything else raises."""
+    def _check_trainable_call(self, return_logvar):
+        """Autograd through the module (fg_edm_backward_ex): gradients of the prediction and of the feature taps with respect to
+        the parameters and to x_t, in the bf16 compute mode - what the DMD2 student / fake-score updates and its GAN branch need
+        (dmd2.py).  Everything else raises."""
         if self._select_dtype() != _lib.FG_DTYPE_BF16:
             raise NotImplementedError(
                 "fastgen_amd.EDMPrecond: the backward pass runs in the bf16 compute mode only - call under "
                 "torch.autocast('cuda', dtype=torch.bfloat16) (or compute_dtype='bf16'), or under torch.no_grad() for inference")
-        if x_t.requires_grad:
-            raise NotImplementedError("fastgen_amd.EDMPrecond: gradients with respect to x_t are not implemented")
-        if len(feature_indices) or return_logvar:
-            raise NotImplementedError("fastgen_amd.EDMPrecond: feature taps / logvar are forward-only (call under torch.no_grad())")
+        if return_logvar:
+            raise NotImplementedError("fastgen_amd.EDMPrecond: logvar is forward-only (call under torch.no_grad())")
 
     def _labels(self, condition, batch: int, device) -> Optional[torch.Tensor]:
         if isinstance(condition, dict) and "aug_condition" in condition:
@@ -388,15 +419,15 @@ class EDMPrecond(FastGenNetwork):
             raise TypeError(f"unexpected forward kwargs: {sorted(fwd_kwargs)}")
         if self.training and self.dropout:
             raise NotImplementedError("dropout in training mode is not implemented (call .eval())")
-        needs_grad = self._needs_grad()
+        needs_grad = self._needs_grad(x_t)
         if needs_grad:
-            self._check_trainable_call(x_t, feature_indices, return_logvar)
+            self._check_trainable_call(return_logvar)
         if x_t.device.type != "cuda":
             raise RuntimeError("fastgen_amd runs on a HIP GPU only (no CPU path); got a tensor on " + str(x_t.device))
         if x_t.dim() != 4 or x_t.shape[1] != self.img_channels or x_t.shape[2] != self.img_resolution or x_t.shape[3] != self.img_resolution:
             raise ValueError(f"x_t must be [B,{self.img_channels},{self.img_resolution},{self.img_resolution}], got {tuple(x_t.shape)}")
         B, dev = x_t.shape[0], x_t.device
-        x32 = x_t.detach().to(torch.float32).contiguous()
+        x32 = (x_t if needs_grad and x_t.requires_grad else x_t.detach()).to(torch.float32).contiguous()
         t64 = torch.atleast_1d(t.detach()).to(device=dev, dtype=torch.float64)
         if t64.numel() == 1 and B > 1:
             t64 = t64.expand(B)
@@ -416,7 +447,19 @@ class EDMPrecond(FastGenNetwork):
         ws = self._workspace(dt, h, B, dev)
         L = _lib.lib()
         features: List[torch.Tensor] = []
-        if len(feature_indices):
+        if needs_grad:
+            ntap = L.fg_edm_num_feature_taps(h)
+            taps = tuple(i for i in range(ntap) if i in feature_indices)
+            if return_features_early:
+                assert len(taps) == len(feature_indices), f"{len(taps)} != {len(feature_indices)}"
+            res = _EDMForwardFn.apply(self, x32, t64, r64, labels, taps, bool(return_features_early),
+                                      *[p_ for _, p_ in self._named_weights()])
+            res = list(res)
+            out = None if return_features_early else res.pop(0)
+            features = [f.to(x_t.dtype) for f in res]
+            if return_features_early:
+                return features
+        elif len(feature_indices):
             # tap i = the i-th encoder block named *block3* (EDM/network.py:535-539); indices beyond the taps are ignored by
             # the reference's loop and trip its length assert only when returning early (:543)
             ntap = L.fg_edm_num_feature_taps(h)
@@ -440,9 +483,6 @@ class EDMPrecond(FastGenNetwork):
             features = [f.to(x_t.dtype) for f in features]
             if return_features_early:
                 return features
-        elif needs_grad:
-            weights = [p_ for _, p_ in self._named_weights()]
-            out = _EDMForwardFn.apply(self, x32, t64, r64, labels, *weights)
         else:
             out = torch.empty_like(x32)
             _lib.check(L.fg_edm_forward(

@@ -198,8 +198,16 @@ int fg_edm_backward(fg_edm* h, const float* x_t, const double* t, const double* 
 /* The forward half on its own (-> out), leaving in `workspace` (sized by fg_edm_backward_workspace_bytes) what the backward
  * reads.  A following fg_edm_backward(..., have_forward = 1, same batch, same workspace, same x_t / labels) skips its own
  * forward (out may then be NULL); nothing else may write to that workspace in between. */
-int fg_edm_forward_train(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, float* out, int batch,
-                         void* workspace, size_t workspace_bytes, void* stream);
+int fg_edm_forward_train(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, float* out,
+                         float* const* features, int batch, void* workspace, size_t workspace_bytes, void* stream);
+/* fg_edm_backward with the gradient paths DMD2's GAN branch uses (dmd2.py:137-146: the frozen teacher's feature taps feed the
+ * discriminator, whose loss is differentiated back to the teacher's INPUT): dfeatures[tap] (array as in fg_edm_forward_features,
+ * entries nullable, NCHW fp32) joins the gradient of that encoder output; dout == NULL means the forward returned the taps early
+ * and only the encoder is differentiated; dx_t (nullable, [B,C,H,W] fp32) receives dL/dx_t.  features / out of
+ * fg_edm_forward_train follow fg_edm_forward_features (out == NULL: early return). */
+int fg_edm_backward_ex(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* dout,
+                       const float* const* dfeatures, float* out, float* dx_t, int have_forward, int batch, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* Samples to image bytes, the step after generator_fn in the reference's sample writer
  * (scripts/fid/compute_fid_from_ckpts.py:199): out[n,y,x,c] = uint8(clip(images[n,c,y,x] * 127.5 + 128, 0, 255)),

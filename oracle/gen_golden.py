@@ -287,6 +287,46 @@ def full_backward_fixture(edm_net):
         names.append(n)
     with open(os.path.join(OUT, "full_backward_names.txt"), "w") as f:
         f.write("\n".join(names) + "\n")
+    # ---- the gradient paths of DMD2's GAN branch (dmd2.py:137-146): feature taps and the network input ---------------------
+    probe = ["model.enc.32x32_block3.conv1.weight", "model.enc.16x16_block0.norm0.weight", "model.enc.8x8_block3.skip.weight"
+             if "model.enc.8x8_block3.skip.weight" in dict(net.named_parameters()) else "model.enc.8x8_block3.conv0.weight",
+             "model.map_layer0.weight", "model.enc.32x32_conv.weight"]
+
+    def clear():
+        for p in net.parameters():
+            p.grad = None
+
+    def shapes(i):
+        return [(2, 256, 32, 32), (2, 256, 16, 16), (2, 256, 8, 8)][i]
+
+    # (a) d out / d x_t
+    clear()
+    xg = x.clone().requires_grad_(True)
+    net(xg, tt, condition=cond, fwd_pred_type="x0").backward(dout)
+    fx["gan/dx_out"] = xg.grad.clone()
+    # (b) taps returned early, all three, gradients into x_t and the encoder
+    clear()
+    xg = x.clone().requires_grad_(True)
+    feats = net(xg, tt, condition=cond, return_features_early=True, feature_indices={0, 1, 2})
+    dfs = [seeded(shapes(i), 410 + i) for i in range(3)]
+    torch.autograd.backward(feats, dfs)
+    fx["gan/dx_early"] = xg.grad.clone()
+    for n in probe:
+        g = dict(net.named_parameters())[n].grad.reshape(-1)
+        fx[f"gan/early/{n}/norm"] = g.double().norm().float()
+        fx[f"gan/early/{n}/sample"] = g[:: max(1, g.numel() // 512)][:512].clone()
+    assert dict(net.named_parameters())["model.dec.8x8_in0.conv0.weight"].grad is None
+    for i, f in enumerate(feats):
+        fx[f"gan/feat{i}/sample"] = f.detach().reshape(-1)[:: f.numel() // 512][:512].clone()
+    # (c) prediction and the bottleneck tap together
+    clear()
+    xg = x.clone().requires_grad_(True)
+    o, fe = net(xg, tt, condition=cond, feature_indices={2}, fwd_pred_type="x0")
+    torch.autograd.backward([o, fe[0]], [dout, dfs[2]])
+    fx["gan/dx_both"] = xg.grad.clone()
+    g = dict(net.named_parameters())[probe[0]].grad.reshape(-1)
+    fx["gan/both/probe0/sample"] = g[:: max(1, g.numel() // 512)][:512].clone()
+    fx["gan/probe_names"] = probe
     torch.save(fx, os.path.join(OUT, "full_backward_b2.pt"))
 
 

@@ -762,12 +762,63 @@ def test_module_autograd_through_the_hip_backward(nets, golden_dir):
         (o2 * dout).sum().backward()
         assert torch.isfinite(params["model.enc.16x16_block1.conv1.weight"].grad).all()
         with pytest.raises(NotImplementedError):
-            net(x.clone().requires_grad_(True), t, condition=cond)
-        with pytest.raises(NotImplementedError):
             nets["fp32"](x, t, condition=cond)  # the backward pass exists in the bf16 mode only
         # a conversion after the network stays differentiable (eps prediction from the x0 network)
         net.zero_grad(set_to_none=True)
         net(x, t, condition=cond, fwd_pred_type="eps").square().mean().backward()
         assert torch.isfinite(params["model.dec.32x32_aux_conv.weight"].grad).all()
     finally:
+        net.zero_grad(set_to_none=True)
+
+
+def test_module_autograd_feature_taps_and_input_gradient(nets, golden_dir):
+    """The gradient paths of DMD2's GAN branch (dmd2.py:137-146): the frozen teacher's feature taps feed the discriminator and
+    the loss is differentiated back to the teacher's INPUT.  d out / d x_t, early-returned taps -> x_t and encoder parameters,
+    and prediction + bottleneck tap together, against the reference's autograd (tests/golden/full_backward_b2.pt, 'gan/*').
+    Tolerance: relative L2 <= 5e-2 (bf16 activations and gradients)."""
+    fx = load(golden_dir, "full_backward_b2.pt")
+    net = nets["bf16"]
+    t, cond = fx["t"].to(dev()), fx["cond"].to(dev())
+    x0 = seeded((2, 3, 32, 32), 21) * fx["t"].reshape(2, 1, 1, 1).float()
+    dout = seeded((2, 3, 32, 32), 401).to(dev())
+    dfs = [seeded(s, 410 + i).to(dev()) for i, s in enumerate([(2, 256, 32, 32), (2, 256, 16, 16), (2, 256, 8, 8)])]
+    params = dict(net.named_parameters())
+
+    def rel(a, b):
+        return float((a.detach().cpu().float() - b).norm() / b.norm())
+
+    def smp(g):
+        g = g.detach().cpu().reshape(-1)
+        return g[:: max(1, g.numel() // 512)][:512]
+
+    try:
+        # (a) frozen network, gradient with respect to the input only
+        net.requires_grad_(False)
+        xg = x0.clone().to(dev()).requires_grad_(True)
+        net(xg, t, condition=cond, fwd_pred_type="x0").backward(dout)
+        assert rel(xg.grad, fx["gan/dx_out"]) <= 5e-2, rel(xg.grad, fx["gan/dx_out"])
+        assert all(p.grad is None for p in net.parameters())
+        # (b) taps returned early
+        net.requires_grad_(True)
+        net.zero_grad(set_to_none=True)
+        xg = x0.clone().to(dev()).requires_grad_(True)
+        feats = net(xg, t, condition=cond, return_features_early=True, feature_indices={0, 1, 2})
+        assert [tuple(f.shape) for f in feats] == [(2, 256, 32, 32), (2, 256, 16, 16), (2, 256, 8, 8)]
+        for i, f in enumerate(feats):
+            assert rel(smp(f), fx[f"gan/feat{i}/sample"]) <= 1e-2
+        torch.autograd.backward(feats, dfs)
+        assert rel(xg.grad, fx["gan/dx_early"]) <= 5e-2, rel(xg.grad, fx["gan/dx_early"])
+        for n in fx["gan/probe_names"]:
+            assert rel(smp(params[n].grad), fx[f"gan/early/{n}/sample"]) <= 5e-2, n
+        g = params["model.dec.8x8_in0.conv0.weight"].grad  # nothing downstream of the encoder took part
+        assert g is None or float(g.abs().max()) == 0.0
+        # (c) prediction and the bottleneck tap together
+        net.zero_grad(set_to_none=True)
+        xg = x0.clone().to(dev()).requires_grad_(True)
+        o, fe = net(xg, t, condition=cond, feature_indices={2}, fwd_pred_type="x0")
+        torch.autograd.backward([o, fe[0]], [dout, dfs[2]])
+        assert rel(xg.grad, fx["gan/dx_both"]) <= 5e-2
+        assert rel(smp(params[fx["gan/probe_names"][0]].grad), fx["gan/both/probe0/sample"]) <= 5e-2
+    finally:
+        net.requires_grad_(True)
         net.zero_grad(set_to_none=True)
