@@ -1574,7 +1574,6 @@ int fg_edm_backward_ex(fg_edm* h, const float* x_t, const double* t, const doubl
     if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
     if (!h->dtype) return fail(FG_EINVAL, "the backward pass runs in the bf16 compute mode only");
     if (h->cfg.r_timestep && !r) return fail(FG_EINVAL, "r is required by an r_timestep network");
-    if (h->cfg.label_dim > 0 && !labels) return fail(FG_EINVAL, "labels are required by a class-conditional network");
     if (batch <= 0 || !workspace || (((uintptr_t)workspace) & 255)) return fail(FG_EINVAL, "bad batch / workspace");
     Arena A;
     A.base = (char*)workspace;

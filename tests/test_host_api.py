@@ -354,3 +354,38 @@ def test_schedule_mirrors_equal_oracle_on_random_inputs():
                 assert torch.allclose(s.convert_model_output(xt, fl, t, "flow", "x0"), x, atol=1e-4 * max(1.0, tv))
 
     prop()
+
+
+def test_training_abi_argument_checks_without_gpu():
+    """The training-side entry points validate their arguments on the host before any kernel is launched (an undersized
+    scratch or a wrong shape must be an error code, never an out-of-bounds access)."""
+    L = _lib.lib()
+    cfg = _lib.fg_edm_config.from_buffer_copy(EDMPrecond(**KW)._cfg)
+    cfg.compute_dtype = _lib.FG_DTYPE_BF16
+    h = ctypes.c_void_p()
+    _lib.check(L.fg_edm_create(ctypes.byref(cfg), ctypes.byref(h)))
+    try:
+        with pytest.raises(_lib.FastGenAMDError, match="unknown parameter"):
+            _lib.check(L.fg_edm_bind_grad(h, b"model.no_such.weight", None, 0))
+        buf = (ctypes.c_float * 4)()
+        with pytest.raises(_lib.FastGenAMDError, match="gradient elements"):
+            _lib.check(L.fg_edm_bind_grad(h, b"model.enc.32x32_conv.bias", ctypes.cast(buf, ctypes.c_void_p), 4))
+        _lib.check(L.fg_edm_bind_grad(h, b"model.enc.32x32_conv.bias", None, 0))  # unbinding is always accepted
+        assert L.fg_edm_backward_workspace_bytes(h, 0) == 0
+        assert L.fg_edm_backward_workspace_bytes(h, 4) > L.fg_edm_workspace_bytes(h, 4)
+        assert L.fg_edm_block_backward_workspace_bytes(h, 999, 2) == 0
+        one = ctypes.cast(buf, ctypes.c_void_p)
+        with pytest.raises(_lib.FastGenAMDError, match="not packed"):
+            _lib.check(L.fg_edm_backward(h, one, one, None, one, one, one, 0, 2, one, 1 << 20, None))
+        with pytest.raises(_lib.FastGenAMDError, match="not packed"):
+            _lib.check(L.fg_edm_run_block_backward(h, 0, one, 128, None, 0, one, one, one, None, one, 2, one, 1 << 20, None))
+        # the stand-alone weight-gradient op: shapes outside the kernel's tiling are rejected, sizes are reported
+        assert L.fg_op_conv_wgrad_workspace_bytes(4, 32, 256, 256, 3) > 0
+        assert L.fg_op_conv_wgrad_workspace_bytes(4, 32, 256, 200, 3) == 0
+        assert L.fg_op_conv_wgrad_workspace_bytes(4, 24, 256, 256, 3) == 0
+        with pytest.raises(_lib.FastGenAMDError, match="unsupported shape"):
+            _lib.check(L.fg_op_conv_wgrad(one, one, one, 4, 32, 256, 256, 5, 0, one, 1 << 30, None))
+        with pytest.raises(_lib.FastGenAMDError, match="workspace too small"):
+            _lib.check(L.fg_op_conv_wgrad(one, one, one, 4, 32, 256, 256, 3, 0, one, 16, None))
+    finally:
+        L.fg_edm_destroy(h)
