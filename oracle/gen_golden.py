@@ -330,6 +330,35 @@ def full_backward_fixture(edm_net):
     torch.save(fx, os.path.join(OUT, "full_backward_b2.pt"))
 
 
+def meanflow_backward_fixture(edm_net):
+    """Backward of the MeanFlow CIFAR-10 network (r_timestep embedding, no preconditioning, unconditional, flow prediction;
+    configs/experiments/EDM/config_mf_cifar10.py) under autograd: what its finite-difference training mode differentiates
+    (mean_flow.py:162-218).  Norm + 512-entry sample of every parameter gradient and the input gradient, B = 2."""
+    cfg = edm_ref.CIFAR10_MEANFLOW
+    sd = edm_ref.random_state_dict(cfg, seed=4321)
+    net = ref_net(edm_net, cfg, sd)
+    for p in net.parameters():
+        p.requires_grad_(True)
+        p.grad = None
+    tt = torch.tensor([0.83, 0.31], dtype=torch.float64)
+    rr = torch.tensor([0.40, 0.0], dtype=torch.float64)
+    x = seeded((2, 3, 32, 32), 61).requires_grad_(True)
+    dout = seeded((2, 3, 32, 32), 62)
+    out = net(x, tt, r=rr)
+    out.backward(dout)
+    fx = {"sd_checksum": sd_checksum(sd), "out": out.detach().clone(), "t": tt, "r": rr, "dx": x.grad.clone()}
+    names = []
+    for n, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.reshape(-1)
+        fx[f"{n}/norm"] = g.double().norm().float()
+        fx[f"{n}/sample"] = g[:: max(1, g.numel() // 512)][:512].clone()
+        names.append(n)
+    fx["names"] = names
+    torch.save(fx, os.path.join(OUT, "meanflow_backward_b2.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     edm_net, ns, model = _ref_import.import_reference()
@@ -338,6 +367,7 @@ def main():
         backward_fixture(edm_net)
         block_backward_fixtures(edm_net)
         full_backward_fixture(edm_net)
+        meanflow_backward_fixture(edm_net)
         print("backward fixtures written to", OUT)
         return
     if sys.argv[1:] == ["train_schedule"]:
@@ -478,6 +508,7 @@ def main():
     backward_fixture(edm_net)
     block_backward_fixtures(edm_net)
     full_backward_fixture(edm_net)
+    meanflow_backward_fixture(edm_net)
     teacher_sample_fixture(edm_net)
 
     print("golden fixtures written to", OUT)
