@@ -858,3 +858,39 @@ def test_meanflow_network_backward_against_reference_golden(mf_nets, golden_dir)
         assert errs[len(errs) // 2][0] <= 4e-2
     finally:
         net.zero_grad(set_to_none=True)
+
+
+def test_module_under_distributed_data_parallel(nets, golden_dir):
+    """The reference trains with DDP (trainer.ddp=True, fastgen/utils/distributed/ddp.py): the drop-in module must survive the
+    wrapper - parameters registered, gradient hooks fired for every parameter (the ones the forward never reads receive zeros,
+    so no find_unused_parameters is needed), gradients identical to the bare module.  One rank here; the collective itself is
+    torch's."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    fx = load(golden_dir, "full_backward_b2.pt")
+    net = nets["bf16"]
+    t, cond = fx["t"].to(dev()), fx["cond"].to(dev())
+    x = (seeded((2, 3, 32, 32), 21) * fx["t"].reshape(2, 1, 1, 1).float()).to(dev())
+    dout = seeded((2, 3, 32, 32), 401).to(dev())
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        created = True
+    try:
+        net.zero_grad(set_to_none=True)
+        (net(x, t, condition=cond, fwd_pred_type="x0") * dout).sum().backward()
+        bare = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        net.zero_grad(set_to_none=True)
+        ddp = DDP(net, device_ids=[0])
+        (ddp(x, t, condition=cond, fwd_pred_type="x0") * dout).sum().backward()
+        got = {n: p.grad for n, p in net.named_parameters()}
+        assert all(g is not None for g in got.values())  # every hook fired
+        for n, g in bare.items():
+            assert torch.equal(got[n], g), n
+    finally:
+        net.zero_grad(set_to_none=True)
+        if created:
+            dist.destroy_process_group()
