@@ -1154,7 +1154,7 @@ size_t plan_block_bwd(int B, int res_in, int res, int cin, int cout, Arena& A, B
 }
 // data gradient of a conv = the forward conv kernel on dY with transposed, flipped weights; output [npix][pad256(cin)]
 int conv_dgrad(fg_edm* h, const float* w_oihw, int cout, int cin, int ks, const void* dy, void* out, int B, int res, BwdScratch& q,
-               hipStream_t s, bool cache = true) {
+               hipStream_t s, bool cache = true, float oscale = 1.0f) {
     const int cp = pad256(cin);
     void* wpk = q.wpk;
     if (cache) {  // parameters: packed once per weight version; scratch-built weights (the padded head) are not cached
@@ -1176,17 +1176,17 @@ int conv_dgrad(fg_edm* h, const float* w_oihw, int cout, int cin, int ks, const 
     ConvArgs a{};
     a.src1 = dy; a.C1 = cout; a.C2 = 0;
     a.Hs = a.Ws = a.H = a.W = res; a.B = B;
-    a.wpack = wpk; a.scale = 1.0f; a.out = out; a.Cout = cp;
+    a.wpack = wpk; a.scale = oscale; a.out = out; a.Cout = cp;
     HIP_TRY(launch_conv_fused(1, ks, PRO_NONE, RES_NONE, OUT_NHWC, a, s));
     return FG_OK;
 }
 
 // weight gradient with a host-side check of the split-K scratch (an undersized scratch would be an out-of-bounds write)
 int wgrad_checked(const void* act, const void* dy, float* dw, int B, int res, int cin, int cout, int ks, int accumulate, void* wg,
-                  size_t wg_bytes, hipStream_t s) {
+                  size_t wg_bytes, hipStream_t s, float scale = 1.0f) {
     const size_t need = conv_wgrad_workspace_bytes(B, res, cin, cout, ks);
     if (need > wg_bytes) return fail(FG_ENOMEM, "weight-gradient scratch too small: %zu > %zu (res %d, %d -> %d, k%d)", need, wg_bytes, res, cin, cout, ks);
-    HIP_TRY(launch_conv_wgrad(act, dy, dw, B, res, cin, cout, ks, accumulate, wg, s));
+    HIP_TRY(launch_conv_wgrad(act, dy, dw, B, res, cin, cout, ks, accumulate, wg, s, scale));
     return FG_OK;
 }
 
@@ -1214,15 +1214,17 @@ int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& 
         w.mr0 = w.mr1 = w.mr2 = nullptr;
         if (rc) return rc;
     }
+    // The gradient reaching a block's output is used as is; the residual scale sigma = sqrt(1/2) of
+    // out = (branch + skip) * sigma travels as a factor into every consumer (no scaled copy, one bf16 rounding less).
+    const float sg = kSkipScale;
     if (b.attn) {
-        // out = (proj(attention(qkv(norm2(x_mid)))) + x_mid) * sigma, EDM/network.py:290-298.  g2 = sigma * gout.
+        // out = (proj(attention(qkv(norm2(x_mid)))) + x_mid) * sigma, EDM/network.py:290-298
         if (!q.att) return fail(FG_EINVAL, "%s: scratch was planned without the attention part", b.key.c_str());
         const int C3 = 3 * cout;
-        HIP_TRY(launch_scale_bf16(gout, q.g1, kSkipScale, (int64_t)npix * cout, s));
-        HIP_TRY(launch_colsum(q.g1, cout, cout, q.dtemb, B, hw, 1.0f, s));
+        HIP_TRY(launch_colsum(gout, cout, cout, q.dtemb, B, hw, sg, s));
         if (h->G(b.proj_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.proj_b), B, cout, s));
-        if (h->G(b.proj_w)) if ((rc = wgrad_checked(w.aout, q.g1, h->G(b.proj_w), B, res, cout, cout, 1, 1, q.wg, q.wg_bytes, s))) return rc;
-        if ((rc = conv_dgrad(h, h->P(b.proj_w), cout, cout, 1, q.g1, q.da, B, res, q, s))) return rc;
+        if (h->G(b.proj_w) && (rc = wgrad_checked(w.aout, gout, h->G(b.proj_w), B, res, cout, cout, 1, 1, q.wg, q.wg_bytes, s, sg))) return rc;
+        if ((rc = conv_dgrad(h, h->P(b.proj_w), cout, cout, 1, gout, q.da, B, res, q, s, true, sg))) return rc;
         HIP_TRY(launch_attention_backward(w.q, w.k, w.vt, q.da, q.dq, q.dk, q.dvt, q.att, B, hw, cout, s));
         HIP_TRY(launch_qkv_interleave(q.dq, q.dk, q.dvt, q.dqkv, B, hw, cout, s));
         HIP_TRY(launch_colsum(q.dqkv, C3, C3, q.dtemb, B, hw, 1.0f, s));
@@ -1232,14 +1234,13 @@ int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& 
             if ((rc = wgrad_checked(q.aop, q.dqkv, h->G(b.qkv_w), B, res, cout, C3, 1, 1, q.wg, q.wg_bytes, s))) return rc;
         }
         if ((rc = conv_dgrad(h, h->P(b.qkv_w), C3, cout, 1, q.dqkv, q.da, B, res, q, s))) return rc;
-        // norm2 (no activation); the residual x_mid -> out contributes g2 directly
+        // norm2 (no activation); the residual x_mid -> out contributes sigma * gout directly
         HIP_TRY(launch_gn_bwd(1, w.xattn.p, cout, nullptr, 0, q.da, pad256(cout), w.ab2, q.mr2, h->P(b.norm2_w), q.P, q.S,
-                              h->G(b.norm2_w), h->G(b.norm2_b), q.g1, cout, 1.0f, q.gmid, B, res, 0, s));
+                              h->G(b.norm2_w), h->G(b.norm2_b), gout, cout, sg, q.gmid, B, res, 0, s));
         gout = q.gmid;
     }
-    // x_mid = (conv1(act1) + skip) * sigma  =>  g1 = sigma * gout reaches conv1's output and the skip path alike
-    HIP_TRY(launch_scale_bf16(gout, q.g1, kSkipScale, (int64_t)npix * cout, s));
-    HIP_TRY(launch_colsum(q.g1, cout, cout, q.dtemb, B, hw, 1.0f, s));
+    // x_mid = (conv1(act1) + skip) * sigma: sigma * gout reaches conv1's output and the skip path alike
+    HIP_TRY(launch_colsum(gout, cout, cout, q.dtemb, B, hw, sg, s));
     {
         float* d1 = h->G(b.conv1_b);
         float* d2 = b.has_skip ? h->G(b.skip_b) : nullptr;
@@ -1248,9 +1249,9 @@ int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& 
     // conv1
     if (h->G(b.conv1_w)) {
         HIP_TRY(launch_gn_act(0, w.h.p, cout, nullptr, 0, w.ab1, q.aop, B, res, 0, s));
-        if ((rc = wgrad_checked(q.aop, q.g1, h->G(b.conv1_w), B, res, cout, cout, 3, 1, q.wg, q.wg_bytes, s))) return rc;
+        if ((rc = wgrad_checked(q.aop, gout, h->G(b.conv1_w), B, res, cout, cout, 3, 1, q.wg, q.wg_bytes, s, sg))) return rc;
     }
-    if ((rc = conv_dgrad(h, h->P(b.conv1_w), cout, cout, 3, q.g1, q.da, B, res, q, s))) return rc;
+    if ((rc = conv_dgrad(h, h->P(b.conv1_w), cout, cout, 3, gout, q.da, B, res, q, s, true, sg))) return rc;
     // norm1 + silu
     HIP_TRY(launch_gn_bwd(0, w.h.p, cout, nullptr, 0, q.da, pad256(cout), w.ab1, q.mr1, h->P(b.norm1_w), q.P, q.S, h->G(b.norm1_w),
                           h->G(b.norm1_b), nullptr, 0, 0.f, q.dh0, B, res, 0, s));
@@ -1271,19 +1272,21 @@ int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& 
     }
     if ((rc = conv_dgrad(h, h->P(b.conv0_w), cout, cin, 3, q.dh0, q.da, B, res, q, s))) return rc;
     // skip path: its gradient joins dx_in inside the norm0 backward pass (both live at the output resolution)
-    const void* add = q.g1;
+    const void* add = gout;
     int ca = cout;
+    float add_scale = sg;
     if (b.has_skip) {
         if (h->G(b.skip_w)) {
             HIP_TRY(launch_gn_act(2, a1.p, c1, a2.p, c2, nullptr, q.aop, B, res, rm, s));
-            if ((rc = wgrad_checked(q.aop, q.g1, h->G(b.skip_w), B, res, cin, cout, 1, 1, q.wg, q.wg_bytes, s))) return rc;
+            if ((rc = wgrad_checked(q.aop, gout, h->G(b.skip_w), B, res, cin, cout, 1, 1, q.wg, q.wg_bytes, s, sg))) return rc;
         }
-        if ((rc = conv_dgrad(h, h->P(b.skip_w), cout, cin, 1, q.g1, q.dskip, B, res, q, s))) return rc;
+        if ((rc = conv_dgrad(h, h->P(b.skip_w), cout, cin, 1, gout, q.dskip, B, res, q, s, true, sg))) return rc;
         add = q.dskip;
         ca = cp;
+        add_scale = 1.0f;
     }
     HIP_TRY(launch_gn_bwd(0, a1.p, c1, a2.p, c2, q.da, cp, w.ab0, q.mr0, h->P(b.norm0_w), q.P, q.S, h->G(b.norm0_w), h->G(b.norm0_b),
-                          add, ca, 1.0f, dxin, B, res_in, rm, s));
+                          add, ca, add_scale, dxin, B, res_in, rm, s));
     return FG_OK;
 }
 

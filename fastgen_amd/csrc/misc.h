@@ -65,7 +65,7 @@ int launch_qkv_interleave(const void* dq, const void* dk, const void* dvt, void*
 int conv_wgrad_supported(int res, int cin, int cout, int ks);
 size_t conv_wgrad_workspace_bytes(int B, int res, int cin, int cout, int ks);
 int launch_conv_wgrad(const void* act, const void* dy, float* dw, int B, int res, int cin, int cout, int ks, int accumulate,
-                      void* workspace, hipStream_t s);
+                      void* workspace, hipStream_t s, float scale = 1.0f);  // dw (+)= scale * sum
 int launch_images_to_u8(const float* x, uint8_t* out, int64_t B, int C, int HW, hipStream_t s);
 int launch_act_to_nchw(int dtype, const void* in, float* out, int B, int C, int HW, hipStream_t s);  // HW, C multiples of 32
 int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, hipStream_t s);

@@ -160,11 +160,12 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const __bf16*
 
 // dW[co][ci][tap] (+)= sum over splits of partial[split][tap][co][ci], fixed order; thread i walks the partial layout
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, size_t n,
-                                                           int splits, int accumulate, int CC, int taps) {
+                                                           int splits, int accumulate, int CC, int taps, float scale) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
     for (int k = 0; k < splits; ++k) s += partial[(size_t)k * n + i];
+    s *= scale;
     const size_t tap = i / CC, cc = i - tap * CC;  // cc = co * Cin + ci
     float* o = dw + cc * taps + tap;
     *o = accumulate ? *o + s : s;
@@ -193,7 +194,7 @@ int conv_wgrad_supported(int res, int cin, int cout, int ks) {
 }
 
 int launch_conv_wgrad(const void* act, const void* dy, float* dw, int B, int res, int cin, int cout, int ks, int accumulate,
-                      void* workspace, hipStream_t s) {
+                      void* workspace, hipStream_t s, float scale) {
     if (!conv_wgrad_supported(res, cin, cout, ks) || B <= 0) return (int)hipErrorInvalidValue;
     const int splits = conv_wgrad_splits(B, res, cin, cout, ks);
     const int ntiles = B * tiles_per_image(res, ks);
@@ -217,6 +218,6 @@ int launch_conv_wgrad(const void* act, const void* dy, float* dw, int B, int res
     if (e != hipSuccess) return (int)e;
     const size_t n = (size_t)cout * cin * ks * ks;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, dw, n, splits, accumulate,
-                       cout * cin, ks * ks);
+                       cout * cin, ks * ks, scale);
     return (int)hipGetLastError();
 }
