@@ -149,3 +149,19 @@ int launch_qkv_interleave(const void* dq, const void* dk, const void* dvt, void*
                        (const __bf16*)dk, (const __bf16*)dvt, (__bf16*)out, T, C, total);
     return (int)hipGetLastError();
 }
+
+// the same two helpers for other small dense layers (disc.hip): batch = 1 matrices, all dimensions multiples of 32 (K: 16)
+int launch_nt_gemm(const void* A, const void* Bm, void* C, int M, int N, int K, float scale, int out_bf16, hipStream_t s) {
+    if ((M % 32) || (N % 32) || (K % 16)) return (int)hipErrorInvalidValue;
+    if (out_bf16)
+        nt_gemm<true>(A, Bm, C, 1, M, N, K, scale, s);
+    else
+        nt_gemm<false>(A, Bm, C, 1, M, N, K, scale, s);
+    return (int)hipGetLastError();
+}
+int launch_transpose_bf16(const void* in, void* out, int R, int Cc, hipStream_t s) {
+    if ((R % 32) || (Cc % 32)) return (int)hipErrorInvalidValue;
+    transpose(in, out, 1, R, Cc, s);
+    return (int)hipGetLastError();
+}
+

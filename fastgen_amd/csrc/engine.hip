@@ -1666,6 +1666,21 @@ int fg_op_x0_to_eps(const float* xt, const float* x0, double t, int schedule, fl
     HIP_TRY(launch_x0_to_eps(xt, x0, t, nullptr, 0, schedule, 1e-6, out, total, (hipStream_t)stream));
     return FG_OK;
 }
+int fg_disc_edm_num_params(int res) { return disc_num_params(res); }
+size_t fg_disc_edm_workspace_bytes(int res, int batch) { return disc_workspace_bytes(res, batch); }
+int fg_disc_edm_run(const float* feat, int res, const float* const* params, float* logits, const float* dlogits, float* dfeat,
+                    float* const* grads, int batch, void* workspace, size_t workspace_bytes, void* stream) {
+    const int np = disc_num_params(res);
+    if (!np) return fail(FG_EINVAL, "fg_disc_edm_run: resolution %d unsupported (8, 16, 32)", res);
+    if (!feat || !params || !logits || batch <= 0 || !workspace || (((uintptr_t)workspace) & 255))
+        return fail(FG_EINVAL, "fg_disc_edm_run: bad argument");
+    for (int i = 0; i < np; ++i)
+        if (!params[i]) return fail(FG_EINVAL, "fg_disc_edm_run: parameter %d is null", i);
+    if (workspace_bytes < disc_workspace_bytes(res, batch))
+        return fail(FG_ENOMEM, "fg_disc_edm_run: workspace too small (%zu < %zu bytes)", workspace_bytes, disc_workspace_bytes(res, batch));
+    HIP_TRY(disc_run(feat, res, params, logits, dlogits, dfeat, grads, batch, workspace, (hipStream_t)stream));
+    return FG_OK;
+}
 size_t fg_op_conv_wgrad_workspace_bytes(int batch, int res, int cin, int cout, int ks) {
     return conv_wgrad_supported(res, cin, cout, ks) && batch > 0 ? conv_wgrad_workspace_bytes(batch, res, cin, cout, ks) : 0;
 }

@@ -61,6 +61,13 @@ size_t attention_backward_scratch_bytes(int B, int T, int C);
 int launch_attention_backward(const void* q, const void* k, const void* vt, const void* dO, void* dq, void* dk, void* dvt,
                               void* scratch, int B, int T, int C, hipStream_t s);
 int launch_qkv_interleave(const void* dq, const void* dk, const void* dvt, void* out, int B, int T, int C, hipStream_t s);
+int launch_nt_gemm(const void* A, const void* Bm, void* C, int M, int N, int K, float scale, int out_bf16, hipStream_t s);
+int launch_transpose_bf16(const void* in, void* out, int R, int Cc, hipStream_t s);
+// disc.hip: Discriminator_EDM heads (networks/discriminators.py:62-137)
+int disc_num_params(int res);
+size_t disc_workspace_bytes(int res, int B);
+int disc_run(const float* feat, int res, const float* const* params, float* logits, const float* dlogits, float* dfeat,
+             float* const* grads, int B, void* ws, hipStream_t s);
 // wgrad.hip: weight gradient of a 3x3 / 1x1 convolution (training step)
 int conv_wgrad_supported(int res, int cin, int cout, int ks);
 size_t conv_wgrad_workspace_bytes(int B, int res, int cin, int cout, int ks);

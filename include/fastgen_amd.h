@@ -209,6 +209,16 @@ int fg_edm_backward_ex(fg_edm* h, const float* x_t, const double* t, const doubl
                        const float* const* dfeatures, float* out, float* dx_t, int have_forward, int batch, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* One head of Discriminator_EDM (networks/discriminators.py:62-137) on a [B,256,res,res] NCHW fp32 feature tap, res in {8,16,32}:
+ * strided 4x4 convs + GroupNorm + SiLU down to 1x1, then a 1x1 conv to one logit per image.  params: fg_disc_edm_num_params(res)
+ * device pointers in the reference's module order ({conv.weight, conv.bias, gn.weight, gn.bias} per strided conv, then the 1x1
+ * conv's weight and bias), fp32, reference shapes.  dlogits == NULL: forward only.  Otherwise also the backward of the same call:
+ * dfeat (nullable, overwritten) and grads (nullable array / entries; same order and shapes as params; accumulated). */
+int fg_disc_edm_num_params(int res);
+size_t fg_disc_edm_workspace_bytes(int res, int batch);
+int fg_disc_edm_run(const float* feat, int res, const float* const* params, float* logits, const float* dlogits, float* dfeat,
+                    float* const* grads, int batch, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Samples to image bytes, the step after generator_fn in the reference's sample writer
  * (scripts/fid/compute_fid_from_ckpts.py:199): out[n,y,x,c] = uint8(clip(images[n,c,y,x] * 127.5 + 128, 0, 255)),
  * fp32 multiply then add, truncation; NaN -> 0.  images NCHW fp32, out NHWC bytes. */

@@ -514,3 +514,21 @@ def conv_weight_grad(act: torch.Tensor, dy: torch.Tensor, ks: int) -> torch.Tens
         torch.nn.functional.conv2d(act, w, padding=ks // 2).backward(dy)
     return w.grad.detach()
 
+
+def discriminator_edm(sd: Dict[str, Tensor], feats, in_res) -> Tensor:
+    """Discriminator_EDM.forward (fastgen/networks/discriminators.py:62-137): per tapped resolution a head of strided 4x4 convs,
+    each followed by GroupNorm(32, eps 1e-5) + SiLU, down to 1x1, then a 1x1 conv to one logit; logits concatenated per head.
+    sd uses the reference's keys (`discriminator_heads.{i}.{j}.weight|bias`)."""
+    logits = []
+    for i, (res, x) in enumerate(zip(in_res, feats)):
+        j, r = 0, res
+        pre = f"discriminator_heads.{i}."
+        while r > 4:  # stride-2 convs down to 4x4 (the reference's loop to 8x8 plus its fixed 8 -> 4 layer)
+            x = F.conv2d(x, sd[f"{pre}{j}.weight"], sd[f"{pre}{j}.bias"], stride=2, padding=1)
+            x = F.silu(F.group_norm(x, 32, sd[f"{pre}{j + 1}.weight"], sd[f"{pre}{j + 1}.bias"], eps=1e-5))
+            j, r = j + 3, r // 2
+        x = F.conv2d(x, sd[f"{pre}{j}.weight"], sd[f"{pre}{j}.bias"], stride=4, padding=0)
+        x = F.silu(F.group_norm(x, 32, sd[f"{pre}{j + 1}.weight"], sd[f"{pre}{j + 1}.bias"], eps=1e-5))
+        x = F.conv2d(x, sd[f"{pre}{j + 3}.weight"], sd[f"{pre}{j + 3}.bias"])
+        logits.append(x.reshape(-1, 1))
+    return torch.cat(logits, dim=1)

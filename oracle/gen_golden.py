@@ -359,6 +359,46 @@ def meanflow_backward_fixture(edm_net):
     torch.save(fx, os.path.join(OUT, "meanflow_backward_b2.pt"))
 
 
+def discriminator_fixture():
+    """`Discriminator_EDM` (fastgen/networks/discriminators.py:62-137) recorded from the reference: logits, the gradient with
+    respect to the feature maps and every parameter gradient (norm + 512-entry sample), for the default bottleneck head and
+    for all three heads; weights from the reference's own default init under a fixed seed, stored as a seed (regenerated by the
+    same constructor call in the test would need the reference - so the state dict itself is stored for the small default head
+    and as a seed recipe (N(0, 0.02) re-randomisation) for the three-head case)."""
+    import importlib
+
+    disc_mod = importlib.import_module("fastgen.networks.discriminators")
+    fx = {}
+    for tag, idx, bs in (("default", None, 4), ("all", {0, 1, 2}, 2)):
+        torch.manual_seed(500)
+        d = disc_mod.Discriminator_EDM(feature_indices=idx)
+        # deterministic, seed-reproducible parameters: every tensor ~ N(0, s), gains around 1
+        g = torch.Generator().manual_seed(501)
+        with torch.no_grad():
+            for n, p in d.named_parameters():
+                if p.ndim == 1 and n.endswith("weight"):
+                    p.copy_(1 + 0.1 * torch.randn(p.shape, generator=g))
+                elif p.ndim == 1:
+                    p.copy_(0.1 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(torch.randn(p.shape, generator=g) / (p[0].numel() ** 0.5))
+        feats = [seeded((bs, 256, r, r), 510 + r).requires_grad_(True) for r in d.in_res]
+        logits = d(feats)
+        dl = seeded(tuple(logits.shape), 520)
+        logits.backward(dl)
+        fx[f"{tag}/keys"] = list(d.state_dict().keys())
+        fx[f"{tag}/in_res"] = torch.tensor(d.in_res)
+        fx[f"{tag}/bs"] = torch.tensor(bs)
+        fx[f"{tag}/logits"] = logits.detach().clone()
+        for r, f in zip(d.in_res, feats):
+            sm = summarise(f.grad)
+            fx[f"{tag}/dfeat{r}/norm"], fx[f"{tag}/dfeat{r}/sample"] = sm["norm"], sm["sample"]
+        for n, p in d.named_parameters():
+            sm = summarise(p.grad)
+            fx[f"{tag}/{n}/norm"], fx[f"{tag}/{n}/sample"] = sm["norm"], sm["sample"][:512].clone()
+    torch.save(fx, os.path.join(OUT, "discriminator_edm.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     edm_net, ns, model = _ref_import.import_reference()
@@ -368,6 +408,7 @@ def main():
         block_backward_fixtures(edm_net)
         full_backward_fixture(edm_net)
         meanflow_backward_fixture(edm_net)
+        discriminator_fixture()
         print("backward fixtures written to", OUT)
         return
     if sys.argv[1:] == ["train_schedule"]:
@@ -509,6 +550,7 @@ def main():
     block_backward_fixtures(edm_net)
     full_backward_fixture(edm_net)
     meanflow_backward_fixture(edm_net)
+    discriminator_fixture()
     teacher_sample_fixture(edm_net)
 
     print("golden fixtures written to", OUT)

@@ -913,3 +913,44 @@ def test_network_backward_is_additive_over_the_batch(nets, sd):
         acc = g1 if acc is None else {k: acc[k] + v for k, v in g1.items()}
     worst = max((float((g3[k] - acc[k]).norm() / acc[k].norm().clamp_min(1e-20)), k) for k in acc if float(acc[k].abs().max()) > 0)
     assert worst[0] <= 2e-3, worst
+
+
+# ---- Discriminator_EDM heads --------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,idx", [("default", None), ("all", {0, 1, 2})])
+def test_discriminator_edm_against_reference_golden(golden_dir, tag, idx):
+    """Logits, feature-map gradients and every parameter gradient of the HIP Discriminator_EDM against the values recorded from
+    the reference module under autograd (tests/golden/discriminator_edm.pt) and against the oracle's autograd in full:
+    bf16 activations -> relative L2 <= 2e-2; logits to 3e-2 of their spread."""
+    from tests.test_oracle_golden import _seeded_discriminator
+
+    fx = load(golden_dir, "discriminator_edm.pt")
+    d = _seeded_discriminator(idx).to(dev())
+    bs = int(fx[f"{tag}/bs"])
+    feats_cpu = [seeded((bs, 256, r, r), 510 + r) for r in d.in_res]
+    dl = seeded(tuple(fx[f"{tag}/logits"].shape), 520)
+    # oracle in full
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in d.state_dict().items()}
+    fo = [f.clone().requires_grad_(True) for f in feats_cpu]
+    with torch.enable_grad():
+        R.discriminator_edm(sd, fo, d.in_res).backward(dl)
+    # HIP
+    feats = [f.to(dev()).requires_grad_(True) for f in feats_cpu]
+    logits = d(feats)
+    assert logits.shape == (bs, len(d.in_res))
+    want = fx[f"{tag}/logits"]
+    assert float((logits.detach().cpu() - want).abs().max()) <= 3e-2 * float(want.std() + want.abs().mean())
+    logits.backward(dl.to(dev()))
+    for f, o in zip(feats, fo):
+        assert float((f.grad.cpu() - o.grad).norm() / o.grad.norm()) <= 2e-2
+    for k, p in d.named_parameters():
+        rel = float((p.grad.cpu() - sd[k].grad).norm() / sd[k].grad.norm().clamp_min(1e-20))
+        assert rel <= 2e-2, (k, rel)
+        assert abs(float(p.grad.double().norm()) / float(fx[f"{tag}/{k}/norm"]) - 1) <= 2e-2, k
+    # forward only, no graph; CPU tensors are refused
+    with torch.no_grad():
+        again = d([f.detach() for f in feats])
+    assert torch.equal(again, logits.detach())
+    with pytest.raises(RuntimeError):
+        d([f.detach().cpu() for f in feats])
+    with pytest.raises(ValueError):
+        d([feats[0].detach()] * (len(d.in_res) + 1))

@@ -238,3 +238,43 @@ def test_conv_weight_grad_matches_reference_autograd(golden_dir):
         assert (got - want).abs().max() <= 1e-4 * want.abs().max()
         # the bias gradient is the plain sum of dy over batch and pixels
         assert torch.allclose(dy.sum((0, 2, 3)), fx[f"k{ks}/bias_grad"], rtol=1e-5, atol=1e-4)
+
+
+def _seeded_discriminator(idx):
+    """The module with the parameters of tests/golden/discriminator_edm.pt: drawn in named_parameters() order from one
+    generator (oracle/gen_golden.py discriminator_fixture).  The constructor is plain torch and runs without a GPU."""
+    from fastgen_amd.networks.discriminators import Discriminator_EDM
+
+    d = Discriminator_EDM(feature_indices=idx)
+    g = torch.Generator().manual_seed(501)
+    with torch.no_grad():
+        for n, p in d.named_parameters():
+            if p.ndim == 1 and n.endswith("weight"):
+                p.copy_(1 + 0.1 * torch.randn(p.shape, generator=g))
+            elif p.ndim == 1:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) / (p[0].numel() ** 0.5))
+    return d
+
+
+@pytest.mark.parametrize("tag,idx", [("default", None), ("all", {0, 1, 2})])
+def test_discriminator_oracle_and_module_tree_match_reference(golden_dir, tag, idx):
+    """State-dict keys of the drop-in module equal the reference's, and the oracle's forward / autograd reproduce the logits and
+    gradients recorded from the reference's Discriminator_EDM (fp32, 1e-4)."""
+    fx = torch.load(os.path.join(golden_dir, "discriminator_edm.pt"), weights_only=True)
+    d = _seeded_discriminator(idx)
+    assert list(d.state_dict().keys()) == fx[f"{tag}/keys"]
+    assert d.in_res == fx[f"{tag}/in_res"].tolist()
+    bs = int(fx[f"{tag}/bs"])
+    sd = {k: v.clone().requires_grad_(True) for k, v in d.state_dict().items()}
+    feats = [torch.randn((bs, 256, r, r), generator=torch.Generator().manual_seed(510 + r)).requires_grad_(True) for r in d.in_res]
+    with torch.enable_grad():
+        logits = R.discriminator_edm(sd, feats, d.in_res)
+        assert torch.allclose(logits, fx[f"{tag}/logits"], rtol=1e-4, atol=1e-5)
+        dl = torch.randn(tuple(logits.shape), generator=torch.Generator().manual_seed(520))
+        logits.backward(dl)
+    for r, f in zip(d.in_res, feats):
+        assert abs(float(f.grad.double().norm()) / float(fx[f"{tag}/dfeat{r}/norm"]) - 1) <= 1e-4
+    for k, v in sd.items():
+        assert abs(float(v.grad.double().norm()) / float(fx[f"{tag}/{k}/norm"]) - 1) <= 1e-4, k
