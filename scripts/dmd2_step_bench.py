@@ -8,16 +8,16 @@ fake score) running on the fastgen_amd module, synthetic data.  Mirrors the stru
   fake-score/disc step: student fwd (no grad); fake score fwd+bwd (denoising loss); teacher encoder twice (fake / real taps, no
                         grad); discriminator fwd+bwd
 
-The discriminator (0.1 % of the FLOPs) is a torch module restating `Discriminator_EDM` for the bottleneck tap
-(networks/discriminators.py:62-137); optimizers are torch.optim.AdamW.  Not a product path: a measurement script.
+The discriminator is fastgen_amd's Discriminator_EDM (networks/discriminators.py:62-137, bottleneck head); optimizers are
+torch.optim.AdamW.  A measurement script: the losses are the reference's formulas written with torch ops.
 Usage: python scripts/dmd2_step_bench.py [batch ...]   (default 64 256; the config's per-GPU batch on 8 GPUs is 256)"""
 import sys
 import time
 
 import torch
 import torch.nn.functional as F
-from torch import nn
 
+from fastgen_amd.networks.discriminators import Discriminator_EDM
 from fastgen_amd.networks.EDM.network import EDMPrecond
 
 KW = dict(img_resolution=32, img_channels=3, label_dim=10, model_type="SongUNet", augment_dim=9, model_channels=128,
@@ -33,8 +33,7 @@ def make(seed, train):
 
 
 student, teacher, fake = make(1, True), make(2, False), make(3, True)
-disc = nn.Sequential(nn.Conv2d(256, 256, 4, 2, 1), nn.GroupNorm(32, 256), nn.SiLU(), nn.Conv2d(256, 256, 4, 4, 0),
-                     nn.GroupNorm(32, 256), nn.SiLU(), nn.Conv2d(256, 1, 1)).to(dev)
+disc = Discriminator_EDM().to(dev)  # the bottleneck head (the reference's default feature_indices)
 opt_s = torch.optim.AdamW(student.parameters(), lr=1e-5)
 opt_f = torch.optim.AdamW(fake.parameters(), lr=1e-5)
 opt_d = torch.optim.AdamW(disc.parameters(), lr=1e-5)
@@ -55,7 +54,7 @@ def student_step(B, noise, cond, eps, t):
     with torch.no_grad():
         fake_x0 = fake(xt, t, condition=cond, fwd_pred_type="x0")
     teacher_x0, feat = teacher(xt, t, condition=cond, feature_indices={2}, fwd_pred_type="x0")
-    gan_gen = F.softplus(-disc(feat[0]).reshape(-1, 1)).mean()
+    gan_gen = F.softplus(-disc([feat[0]])).mean()
     loss = vsd_loss(gen, teacher_x0.detach(), fake_x0) + 1e-3 * gan_gen
     opt_s.zero_grad(set_to_none=True)
     loss.backward()
@@ -71,7 +70,7 @@ def fake_score_step(B, noise, cond, eps, t, real):
     with torch.no_grad():
         fake_feat = teacher(xt, t, condition=cond, return_features_early=True, feature_indices={2})
         real_feat = teacher(sched.forward_process(real, eps, t), t, condition=cond, return_features_early=True, feature_indices={2})
-    loss_d = F.softplus(disc(fake_feat[0])).mean() + F.softplus(-disc(real_feat[0])).mean()
+    loss_d = F.softplus(disc([fake_feat[0]])).mean() + F.softplus(-disc([real_feat[0]])).mean()
     opt_f.zero_grad(set_to_none=True)
     opt_d.zero_grad(set_to_none=True)
     (loss_f + loss_d).backward()
