@@ -193,8 +193,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const __bf16* __restr
                                                            int C2, const __bf16* __restrict__ dact, int Cd,
                                                            const float2* __restrict__ ab, const float2* __restrict__ mr,
                                                            const float2* __restrict__ S, const __bf16* __restrict__ add, int Ca,
-                                                           float add_scale, __bf16* __restrict__ dx, int64_t total_oct, int res,
-                                                           int rm) {
+                                                           float add_scale, __bf16* __restrict__ dx, int dxs, __bf16* __restrict__ dx2,
+                                                           int dxs2, int accumulate, int64_t total_oct, int res, int rm) {
+    // destination: channels [0, C1) -> dx (pixel stride dxs), channels [C1, C) -> dx2 (pixel stride dxs2); accumulate: +=
     const int C = C1 + C2, OC = C >> 3, HW = res * res;
     const int groups = min(32, C / 4), cpg = C / groups;
     const float inv_m = 1.0f / ((float)cpg * (float)HW);
@@ -219,7 +220,14 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const __bf16* __restr
             if (add) r = fmaf(add_scale, av[j], r);
             o[j] = r;
         }
-        store8bf(dx + pix * C + c0, o);
+        __bf16* dst = (c0 < C1) ? dx + pix * dxs + c0 : dx2 + pix * dxs2 + (c0 - C1);
+        if (accumulate) {
+            float old[8];
+            load8bf(dst, old);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += old[j];
+        }
+        store8bf(dst, o);
     }
 }
 
@@ -440,8 +448,12 @@ int launch_gn_act(int mode, const void* x1, int c1, const void* x2, int c2, cons
 // GroupNorm(+SiLU) backward.  P: [B][C] float2 scratch, S: [B][groups] float2 scratch.  dgamma / dbeta are accumulated.
 int launch_gn_bwd(int mode, const void* x1, int c1, const void* x2, int c2, const void* dact, int cd, const float2* ab,
                   const float2* mr, const float* gamma, float2* P, float2* S, float* dgamma, float* dbeta, const void* add, int ca,
-                  float add_scale, void* dx, int B, int res, int rm, hipStream_t s) {
+                  float add_scale, void* dx, int B, int res, int rm, hipStream_t s, void* dx2, int accumulate) {
     const int C = c1 + c2, hw = res * res;
+    // default destination: one [B, hw, C] tensor; with dx2 the two halves of the concat go to their own (dense) tensors
+    __bf16* d1 = (__bf16*)dx;
+    __bf16* d2 = dx2 ? (__bf16*)dx2 : d1 + c1;
+    const int s1 = dx2 ? c1 : C, s2 = dx2 ? c2 : C;
     if ((c1 % 8) || (c2 % 8) || C < 16) return (int)hipErrorInvalidValue;
     const int groups = C / 4 < 32 ? C / 4 : 32;
     dim3 rg((C + 63) / 64, B);
@@ -454,9 +466,9 @@ int launch_gn_bwd(int mode, const void* x1, int c1, const void* x2, int c2, cons
     if (dgamma || dbeta) hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 63) / 64), dim3(256), 0, s, P, dgamma, dbeta, B, C);
     const int64_t total = (int64_t)B * hw * (C / 8);
     if (mode == 0)
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, S, A, ca, add_scale, (__bf16*)dx, total, res, rm);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, S, A, ca, add_scale, d1, s1, d2, s2, accumulate, total, res, rm);
     else
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, S, A, ca, add_scale, (__bf16*)dx, total, res, rm);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, S, A, ca, add_scale, d1, s1, d2, s2, accumulate, total, res, rm);
     (void)groups;
     BWD_RET();
 }

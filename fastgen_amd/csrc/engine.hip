@@ -1195,7 +1195,9 @@ int wgrad_checked(const void* act, const void* dy, float* dw, int B, int res, in
 // accumulated.  The block's forward is recomputed here (activation checkpointing at block granularity).
 int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& a2, int c2, const float* emb, const float* temb,
                    const void* gout, void* dxin, float* demb, int B, Workspace& w, BwdScratch& q, hipStream_t s,
-                   float* dtemb_all = nullptr, const BlockStash* stash = nullptr) {
+                   float* dtemb_all = nullptr, const BlockStash* stash = nullptr, void* dxin2 = nullptr, int dx_accumulate = 0) {
+    // dxin2 != nullptr: the gradients of the two concat sources go to their own dense tensors (dxin: [.., c1], dxin2: [.., c2]);
+    // dx_accumulate: added to what dxin (/ dxin2) hold
     const int res = b.res_out, res_in = b.res_in, hw = res * res, cin = b.cin, cout = b.cout, cp = pad256(cin);
     const int rm = b.down ? 1 : (b.up ? 2 : 0);
     if (!conv_wgrad_supported(res, cout, cout, 3) || !conv_wgrad_supported(res, cin, cout, 3))
@@ -1286,7 +1288,7 @@ int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& 
         add_scale = 1.0f;
     }
     HIP_TRY(launch_gn_bwd(0, a1.p, c1, a2.p, c2, q.da, cp, w.ab0, q.mr0, h->P(b.norm0_w), q.P, q.S, h->G(b.norm0_w), h->G(b.norm0_b),
-                          add, ca, add_scale, dxin, B, res_in, rm, s));
+                          add, ca, add_scale, dxin, B, res_in, rm, s, dxin2, dx_accumulate));
     return FG_OK;
 }
 
@@ -1448,11 +1450,11 @@ int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, 
         const Block& b = *recs[i].b;
         const int c2 = b.skip_c, c1 = b.cin - c2;
         const size_t npin = (size_t)B * b.res_in * b.res_in;
-        if ((rc = block_backward(h, b, *recs[i].x, c1, c2 ? *recs[i].x2 : none, c2, w.emb, w.temb, g_cur, q.dxin, nb.demb, B, w, q, s, nb.dtemb_all,
-                                 &nb.ts.blocks[block_index(h, &b)])))
+        // the x part of the input gradient becomes the next (earlier) block's incoming gradient, the skip part that encoder output's
+        if ((rc = block_backward(h, b, *recs[i].x, c1, c2 ? *recs[i].x2 : none, c2, w.emb, w.temb, g_cur, g_alt, nb.demb, B, w, q, s, nb.dtemb_all,
+                                 &nb.ts.blocks[block_index(h, &b)], c2 ? nb.genc[recs[i].sk] : nullptr, 0)))
             return rc;
-        HIP_TRY(launch_slice_bf16(q.dxin, b.cin, 0, g_alt, c1, (int64_t)npin, 0, s));
-        if (c2) HIP_TRY(launch_slice_bf16(q.dxin, b.cin, c1, nb.genc[recs[i].sk], c2, (int64_t)npin, 0, s));
+        (void)npin;
         std::swap(g_cur, g_alt);
     }
     // the decoder's first block read the last encoder output directly
@@ -1470,10 +1472,10 @@ int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, 
     // ---- encoder blocks in reverse -------------------------------------------------------------------------------------------
     for (int i = (int)h->enc.size() - 1; i >= 1; --i) {
         const Block& b = h->enc[i];
-        if ((rc = block_backward(h, b, w.skip[i - 1], b.cin, none, 0, w.emb, w.temb, nb.genc[i], q.dxin, nb.demb, B, w, q, s, nb.dtemb_all,
-                                 &nb.ts.blocks[block_index(h, &b)])))
+        // accumulated straight into the previous encoder output's gradient (which already holds the decoder's share)
+        if ((rc = block_backward(h, b, w.skip[i - 1], b.cin, none, 0, w.emb, w.temb, nb.genc[i], nb.genc[i - 1], nb.demb, B, w, q, s, nb.dtemb_all,
+                                 &nb.ts.blocks[block_index(h, &b)], nullptr, 1)))
             return rc;
-        HIP_TRY(launch_add_bf16(nb.genc[i - 1], q.dxin, (int64_t)B * b.res_in * b.res_in * b.cin, s));
     }
     // ---- stem: conv(c_in * x_t) ---------------------------------------------------------------------------------------------------
     {

@@ -35,7 +35,8 @@ int launch_gn_act(int mode, const void* x1, int c1, const void* x2, int c2, cons
                   hipStream_t s);  // res = output resolution; rm 0 none, 1 down (avg 2x2), 2 up (nearest)
 int launch_gn_bwd(int mode, const void* x1, int c1, const void* x2, int c2, const void* dact, int cd, const float2* ab,
                   const float2* mr, const float* gamma, float2* P, float2* S, float* dgamma, float* dbeta, const void* add, int ca,
-                  float add_scale, void* dx, int B, int res, int rm, hipStream_t s);  // res = the norm's (input) resolution
+                  float add_scale, void* dx, int B, int res, int rm, hipStream_t s, void* dx2 = nullptr, int accumulate = 0);
+                  // res = the norm's (input) resolution; dx2: separate dense tensor for the second concat source; accumulate: +=
 int launch_colsum(const void* t, int ct, int C, float* out, int B, int hw, float scale, hipStream_t s, int out_stride = 0);
 int launch_transpose_f32(const float* in, float* out, int R, int Cc, hipStream_t s);
 int launch_batchsum_add(const float* in, float* out, int B, int C, hipStream_t s, float* out2 = nullptr);
