@@ -959,3 +959,37 @@ def test_discriminator_edm_against_reference_golden(golden_dir, tag, idx):
         d([f.detach().cpu() for f in feats])
     with pytest.raises(ValueError):
         d([feats[0].detach()] * (len(d.in_res) + 1))
+
+
+def test_backward_sees_updated_weights(sd):
+    """An optimizer step changes the parameters in place: the next forward / backward must use the new values everywhere,
+    including the cached data-gradient weights and the transposed affine matrix (both rebuilt per weight version).  Checked
+    against a fresh module that was constructed with the updated values."""
+    def build(state):
+        n = EDMPrecond(compute_dtype="bf16", **KW)
+        n.load_state_dict(state, strict=True)
+        return n.to(dev()).eval()
+
+    g = torch.Generator().manual_seed(5)
+    t = torch.tensor([1.3, 22.0], dtype=torch.float64, device=dev())
+    x = (torch.randn((2, 3, 32, 32), generator=g) * 5).to(dev())
+    cond = torch.nn.functional.one_hot(torch.tensor([2, 8]), 10).float().to(dev())
+    dout = torch.randn((2, 3, 32, 32), generator=g).to(dev())
+    probe = ["model.enc.32x32_block1.conv0.weight", "model.dec.16x16_block2.affine.weight", "model.enc.32x32_conv.weight",
+             "model.dec.32x32_block2.skip.weight"]
+    net = build(sd)
+    (net(x, t, condition=cond) * dout).sum().backward()   # builds every cache with the old weights
+    before = {k: dict(net.named_parameters())[k].grad.clone() for k in probe}
+    with torch.no_grad():  # "optimizer step": every parameter moves
+        gg = torch.Generator().manual_seed(6)
+        for _, p in net.named_parameters():
+            p.add_(0.05 * p.abs().mean() * torch.randn(p.shape, generator=gg).to(dev()))
+    net.zero_grad(set_to_none=True)
+    (net(x, t, condition=cond) * dout).sum().backward()
+    fresh = build({k: v.detach().cpu() for k, v in net.state_dict().items()})
+    (fresh(x, t, condition=cond) * dout).sum().backward()
+    pf = dict(fresh.named_parameters())
+    for k in probe:
+        got, want = dict(net.named_parameters())[k].grad, pf[k].grad
+        assert torch.equal(got, want), k                      # same kernels, same inputs: bit-identical
+        assert not torch.equal(got, before[k]), k             # and the update was seen
