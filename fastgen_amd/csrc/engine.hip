@@ -1554,6 +1554,10 @@ int fg_edm_forward_train(fg_edm* h, const float* x_t, const double* t, const dou
     if (!h || !x_t || !t || (!out && !features)) return fail(FG_EINVAL, "null argument");
     if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
     if (!h->dtype) return fail(FG_EINVAL, "the backward pass runs in the bf16 compute mode only");
+    if (features)
+        for (const Block& b : h->enc)
+            if (b.tap >= 0 && features[b.tap] && ((b.cout % 32) || ((b.res_out * b.res_out) % 32)))
+                return fail(FG_EINVAL, "feature tap %d: channels and pixels must be multiples of 32", b.tap);
     if (h->cfg.r_timestep && !r) return fail(FG_EINVAL, "r is required by an r_timestep network");
     if (batch <= 0 || !workspace || (((uintptr_t)workspace) & 255)) return fail(FG_EINVAL, "bad batch / workspace");
     Arena A;
