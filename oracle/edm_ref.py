@@ -532,3 +532,15 @@ def discriminator_edm(sd: Dict[str, Tensor], feats, in_res) -> Tensor:
         x = F.conv2d(x, sd[f"{pre}{j + 3}.weight"], sd[f"{pre}{j + 3}.bias"])
         logits.append(x.reshape(-1, 1))
     return torch.cat(logits, dim=1)
+
+
+def edm_precond_jvp(sd, cfg: SongUNetConfig, x_t: Tensor, t: Tensor, condition, vx: Tensor, vt: Tensor, r: Optional[Tensor] = None,
+                    vr: Optional[Tensor] = None):
+    """(output, directional derivative) of EDMPrecond.forward along the tangents (vx, vt[, vr]) of (x_t, t[, r]): what
+    `torch.func.jvp(net_wrapper, (x_t, t, r), tangents)` computes in MeanFlowModel._jvp / sCM (consistency_model/mean_flow.py:
+    240-250, sCM.py:179), with the reference's hand-written AttentionOp.jvp (EDM/network.py:186-196) - here plain forward-mode
+    AD through the functional restatement.  t / r and their tangents are given in x_t's dtype, as the reference's tangents are."""
+    if r is None:
+        return torch.func.jvp(lambda a, b: edm_precond_forward(sd, cfg, a, b, condition), (x_t, t), (vx, vt))
+    return torch.func.jvp(lambda a, b, c: edm_precond_forward(sd, cfg, a, b, condition, r=c), (x_t, t, r), (vx, vt, vr))
+

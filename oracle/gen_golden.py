@@ -399,10 +399,44 @@ def discriminator_fixture():
     torch.save(fx, os.path.join(OUT, "discriminator_edm.pt"))
 
 
+def jvp_fixture(edm_net):
+    """Forward-mode derivative of the network, recorded with the reference's own call
+    `torch.func.jvp(net_wrapper, (x_t, t, r), tangents)` (consistency_model/mean_flow.py:240-250): the MeanFlow CIFAR-10 network
+    with tangents (v, 1, 0), and the preconditioned DMD2 network with tangents (v, vt)."""
+    fx = {}
+    cfg = edm_ref.CIFAR10_MEANFLOW
+    sd = edm_ref.random_state_dict(cfg, seed=4321)
+    net = ref_net(edm_net, cfg, sd)
+    x, v = seeded((2, 3, 32, 32), 71), seeded((2, 3, 32, 32), 72)
+    t, r = torch.tensor([0.83, 0.31]), torch.tensor([0.40, 0.0])
+    with torch.no_grad():
+        out, jv = torch.func.jvp(lambda a, b, c: net(a, b, r=c), (x, t, r), (v, torch.ones_like(t), torch.zeros_like(r)))
+    oo, oj = edm_ref.edm_precond_jvp(sd, cfg, x, t, None, v, torch.ones_like(t), r=r, vr=torch.zeros_like(r))
+    assert torch.allclose(oo, out, rtol=1e-4, atol=1e-5) and torch.allclose(oj, jv, rtol=1e-3, atol=1e-4 * float(jv.abs().max()))
+    fx.update({"mf/out": out.clone(), "mf/jvp": jv.clone(), "mf/t": t, "mf/r": r})
+    cfg = edm_ref.CIFAR10
+    sd = edm_ref.random_state_dict(cfg, seed=1234)
+    net = ref_net(edm_net, cfg, sd)
+    t = torch.tensor([17.4981, 0.1726])
+    vt = torch.tensor([1.0, -0.05])
+    x = seeded((2, 3, 32, 32), 21) * t.reshape(2, 1, 1, 1)
+    cond = torch.nn.functional.one_hot(torch.tensor([3, 7]), 10).float()
+    with torch.no_grad():
+        out, jv = torch.func.jvp(lambda a, b: net(a, b, condition=cond, fwd_pred_type="x0"), (x, t), (v, vt))
+    oo, oj = edm_ref.edm_precond_jvp(sd, cfg, x, t, cond, v, vt)
+    assert torch.allclose(oo, out, rtol=1e-4, atol=1e-5) and torch.allclose(oj, jv, rtol=1e-3, atol=1e-4 * float(jv.abs().max()))
+    fx.update({"edm/out": out.clone(), "edm/jvp": jv.clone(), "edm/t": t, "edm/vt": vt, "edm/cond": cond})
+    torch.save(fx, os.path.join(OUT, "jvp_b2.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     edm_net, ns, model = _ref_import.import_reference()
     torch.manual_seed(0)
+    if sys.argv[1:] == ["jvp"]:
+        jvp_fixture(edm_net)
+        print("jvp fixture written to", OUT)
+        return
     if sys.argv[1:] == ["backward"]:
         backward_fixture(edm_net)
         block_backward_fixtures(edm_net)
@@ -551,6 +585,7 @@ def main():
     full_backward_fixture(edm_net)
     meanflow_backward_fixture(edm_net)
     discriminator_fixture()
+    jvp_fixture(edm_net)
     teacher_sample_fixture(edm_net)
 
     print("golden fixtures written to", OUT)

@@ -278,3 +278,20 @@ def test_discriminator_oracle_and_module_tree_match_reference(golden_dir, tag, i
         assert abs(float(f.grad.double().norm()) / float(fx[f"{tag}/dfeat{r}/norm"]) - 1) <= 1e-4
     for k, v in sd.items():
         assert abs(float(v.grad.double().norm()) / float(fx[f"{tag}/{k}/norm"]) - 1) <= 1e-4, k
+
+
+def test_oracle_jvp_matches_reference_func_jvp(golden_dir, full_sd, mf_sd):
+    """Forward-mode derivative of the oracle against `torch.func.jvp` through the reference's modules (with its hand-written
+    AttentionOp.jvp), tests/golden/jvp_b2.pt: the MeanFlow network with tangents (v, 1, 0) and the preconditioned network."""
+    fx = torch.load(os.path.join(golden_dir, "jvp_b2.pt"), weights_only=True)
+    v = torch.randn((2, 3, 32, 32), generator=torch.Generator().manual_seed(72))
+    x = torch.randn((2, 3, 32, 32), generator=torch.Generator().manual_seed(71))
+    t, r = fx["mf/t"], fx["mf/r"]
+    out, jv = R.edm_precond_jvp(mf_sd, R.CIFAR10_MEANFLOW, x, t, None, v, torch.ones_like(t), r=r, vr=torch.zeros_like(r))
+    assert torch.allclose(out, fx["mf/out"], rtol=1e-4, atol=1e-5)
+    assert float((jv - fx["mf/jvp"]).norm() / fx["mf/jvp"].norm()) <= 1e-4
+    t = fx["edm/t"]
+    x = torch.randn((2, 3, 32, 32), generator=torch.Generator().manual_seed(21)) * t.reshape(2, 1, 1, 1)
+    out, jv = R.edm_precond_jvp(full_sd, R.CIFAR10, x, t, fx["edm/cond"], v, fx["edm/vt"])
+    assert torch.allclose(out, fx["edm/out"], rtol=1e-4, atol=1e-5)
+    assert float((jv - fx["edm/jvp"]).norm() / fx["edm/jvp"].norm()) <= 1e-4
