@@ -96,6 +96,13 @@ __global__ void qkv_interleave_kernel(const __bf16* __restrict__ dq, const __bf1
     }
 }
 
+__global__ void add_inplace_f32_kernel(float* __restrict__ a, const float* __restrict__ b, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) a[i] += b[i];
+}
+__global__ void add_to_bf16_kernel(const float* __restrict__ a, const float* __restrict__ b, __bf16* __restrict__ out, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) out[i] = (__bf16)(a[i] + b[i]);
+}
+
 template <bool OB>
 void nt_gemm(const void* A, const void* Bm, void* C, int batch, int M, int N, int K, float scale, hipStream_t s) {
     hipLaunchKernelGGL(nt_gemm_kernel<OB>, dim3(N / 32, M / 32, batch), dim3(64), 0, s, (const __bf16*)A, (const __bf16*)Bm, C, M, N, K, scale);
@@ -139,6 +146,53 @@ int launch_attention_backward(const void* q, const void* k, const void* vt, cons
     nt_gemm<true>(dS, kT, dq, B, T, C, T, sc, s);    // dq[q][c] = sum_k dS[q][k] k[k][c]
     nt_gemm<true>(dST, qT, dk, B, T, C, T, sc, s);   // dk[k][c] = sum_q dS[q][k] q[q][c]
     nt_gemm<true>(dOT, PT, dvt, B, C, T, T, 1.0f, s);  // dv^T[c][k] = sum_q dO[q][c] P[q][k]
+    return (int)hipGetLastError();
+}
+
+// Forward-mode derivative of the attention (the reference's AttentionOp.jvp, EDM/network.py:186-196, followed by the tangent of
+// the value product): Sd = (qd k^T + q kd^T) / sqrt(C), Pd = P o (Sd - rowsum(P o Sd)), od = Pd v + P vd.
+// q, k, qd, kd, od: [B][T][C]; vt, vtd: [B][C][T]; bf16.  Same scratch size as the backward.
+int launch_attention_jvp(const void* q, const void* k, const void* vt, const void* qd, const void* kd, const void* vtd, void* od,
+                         void* scratch, int B, int T, int C, hipStream_t s) {
+    if ((T != 64 && T != 256) || (C % 32)) return (int)hipErrorInvalidValue;
+    char* p = (char*)scratch;
+    auto take = [&](size_t bytes) {
+        void* r = p;
+        p += (bytes + 255) & ~(size_t)255;
+        return r;
+    };
+    const size_t tc = (size_t)B * T * C * 2, tt2 = (size_t)B * T * T * 2, tt4 = (size_t)B * T * T * 4;
+    void *t0 = take(tc), *t1 = take(tc), *t2 = take(tc), *t3 = take(tc);  // scratch sized like the backward's 4 transposes
+    void *P = take(tt2), *Pd = take(tt2), *u0 = take(tt2), *u1 = take(tt2);
+    float *S = (float*)take(tt4), *Sd = (float*)take(tt4);
+    (void)t2, (void)t3, (void)u0, (void)u1;
+    const float sc = 1.0f / sqrtf((float)C);
+    nt_gemm<false>(q, k, S, B, T, T, C, 1.0f, s);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((size_t)B * T)), dim3(T), 0, s, S, (__bf16*)P, T, sc);
+    // Sd: two products into the two fp32 buffers, summed by the (reused) dS kernel's input: S <- qd k^T, Sd <- q kd^T
+    nt_gemm<false>(qd, k, S, B, T, T, C, sc, s);
+    nt_gemm<false>(q, kd, Sd, B, T, T, C, sc, s);
+    {
+        const int64_t total = (int64_t)B * T * T;
+        const int64_t blocks = (total + 255) / 256;
+        hipLaunchKernelGGL(add_inplace_f32_kernel, dim3((unsigned)(blocks > 65536 ? 65536 : blocks)), dim3(256), 0, s, Sd, S, total);
+    }
+    hipLaunchKernelGGL(attn_ds_kernel, dim3((unsigned)((size_t)B * T)), dim3(T), 0, s, (const __bf16*)P, Sd, (__bf16*)Pd, T);
+    // od[q][c] = sum_k Pd[q][k] v[k][c] + P[q][k] vd[k][c]: B operands are vt / vtd ([c][k], contraction-contiguous) as they lie
+    float* o0 = S;   // [B][T][C] fp32 fits in the [B][T][T] buffers when C <= T; otherwise use the transposes' space
+    float* o1 = Sd;
+    if (C > T) {
+        o0 = (float*)t0;  // 4 * tc bytes = 2 fp32 [B][T][C] tensors
+        o1 = (float*)t2;
+    }
+    nt_gemm<false>(Pd, vt, o0, B, T, C, T, 1.0f, s);
+    nt_gemm<false>(P, vtd, o1, B, T, C, T, 1.0f, s);
+    {
+        const int64_t total = (int64_t)B * T * C;
+        const int64_t blocks = (total + 255) / 256;
+        hipLaunchKernelGGL(add_to_bf16_kernel, dim3((unsigned)(blocks > 65536 ? 65536 : blocks)), dim3(256), 0, s, o0, o1, (__bf16*)od, total);
+    }
+    (void)t1;
     return (int)hipGetLastError();
 }
 

@@ -160,8 +160,9 @@ __global__ void gn_bwd_group_kernel(const float2* __restrict__ P, const float* _
     float s1 = 0.f, s2 = 0.f;
     for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
         const float2 p = P[(size_t)n * C + c];
-        s1 = fmaf(gamma[c], p.x, s1);
-        s2 = fmaf(gamma[c], p.y, s2);
+        const float gm = gamma ? gamma[c] : 1.0f;  // unweighted sums for the forward-mode (JVP) use
+        s1 = fmaf(gm, p.x, s1);
+        s2 = fmaf(gm, p.y, s2);
     }
     S[(size_t)n * groups + g] = make_float2(s1, s2);
 }
@@ -422,6 +423,114 @@ __global__ void input_grad_kernel(const __bf16* __restrict__ da, int Cd, const f
     }
 }
 
+// ---- forward-mode (JVP) pieces: tangents of (x_t, t, r) pushed through the network (mean_flow.py:240-250, sCM.py:179) -------------
+// GroupNorm(+SiLU) tangent: with P = {sum_p xd, sum_p xd*xhat} per (n, c) and S their UNWEIGHTED group sums,
+//   yd = a (xd - (S1 + xhat S2) / m),  actd = silu'(a x + b) yd (MODE 0) | yd (MODE 1);   xd [B,HW,Cd] covers the concat.
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_jvp_apply_kernel(const __bf16* __restrict__ x1, int C1, const __bf16* __restrict__ x2,
+                                                           int C2, const __bf16* __restrict__ xd, int Cd,
+                                                           const float2* __restrict__ ab, const float2* __restrict__ mr,
+                                                           const float2* __restrict__ S, __bf16* __restrict__ out, int64_t total_oct,
+                                                           int HW) {
+    const int C = C1 + C2, OC = C >> 3;
+    const int groups = min(32, C / 4), cpg = C / groups;
+    const float inv_m = 1.0f / ((float)cpg * (float)HW);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_oct; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(i % OC) * 8;
+        const size_t pix = (size_t)(i / OC);
+        const int n = (int)(pix / HW);
+        float xv[8], dv[8], o[8];
+        load8bf(cat_ptr(x1, C1, x2, C2, pix, c0), xv);
+        load8bf(xd + pix * Cd + c0, dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j, g = c / cpg;
+            const float2 t = ab[(size_t)n * C + c];
+            const float2 m = mr[(size_t)n * groups + g];
+            const float2 s = S[(size_t)n * groups + g];
+            const float xhat = (xv[j] - m.x) * m.y;
+            float r = t.x * (dv[j] - fmaf(xhat, s.y, s.x) * inv_m);
+            if (MODE == 0) r *= silu_grad(fmaf(xv[j], t.x, t.y));
+            o[j] = r;
+        }
+        store8bf(out + pix * C + c0, o);
+    }
+}
+// Preconditioning coefficients and their t-derivatives (EDM/network.py:755-805): ct[0..7][B] = c_in, dc_in, dc_noise, dr_noise,
+// c_skip, dc_skip, c_out, dc_out (the d* already multiplied by the tangents vt / vr).  drop bit 0: no input preconditioning
+// (noise labels are t, r themselves); bit 1: none on the output.
+__global__ void jvp_coef_kernel(const double* __restrict__ t, const double* __restrict__ r, const float* __restrict__ vt,
+                                const float* __restrict__ vr, double sigma_data, double sigma_shift, int drop, float* __restrict__ ct, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double tv = t[b], dv = vt ? (double)vt[b] : 0.0, rv = r ? r[b] : 0.0, drv = (r && vr) ? (double)vr[b] : 0.0;
+    const double s2 = sigma_data * sigma_data;
+    if (drop & 1) {
+        ct[b] = 1.f, ct[B + b] = 0.f, ct[2 * B + b] = (float)dv, ct[3 * B + b] = (float)drv;
+    } else {
+        const double q = s2 + tv * tv;
+        ct[b] = (float)(1.0 / sqrt(q));
+        ct[B + b] = (float)(-tv / (q * sqrt(q)) * dv);
+        ct[2 * B + b] = tv > 1e-6 ? (float)(dv / (4.0 * tv)) : 0.f;  // c_noise = ln(clamp(t, 1e-6)) / 4
+        ct[3 * B + b] = rv > 1e-6 ? (float)(drv / (4.0 * rv)) : 0.f;
+    }
+    if (drop & 2) {
+        ct[4 * B + b] = 0.f, ct[5 * B + b] = 0.f, ct[6 * B + b] = 1.f, ct[7 * B + b] = 0.f;
+    } else {
+        const double ts = tv - sigma_shift, q = ts * ts + s2;
+        ct[4 * B + b] = (float)(s2 / q);
+        ct[5 * B + b] = (float)(-2.0 * ts * s2 / (q * q) * dv);
+        ct[6 * B + b] = (float)(ts * sigma_data / sqrt(q));
+        ct[7 * B + b] = (float)(sigma_data * s2 / (q * sqrt(q)) * dv);
+    }
+}
+// tangent of the mapping network's input (positional embeddings of c_noise and r_noise; the label part has none), [B][N]
+__global__ void jvp_embed_kernel(const float* __restrict__ c_noise, const float* __restrict__ r_noise, const float* __restrict__ dc,
+                                 const float* __restrict__ dr, const float* __restrict__ freqs, float* __restrict__ out, int B, int N,
+                                 int noise_ch) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * N) return;
+    const int b = idx / N, j = idx % N, half = noise_ch / 2, jj = j % noise_ch;
+    const float lab = (j < noise_ch) ? c_noise[b] : r_noise[b];
+    const float dl = (j < noise_ch) ? dc[b] : dr[b];
+    const float f = freqs[jj % half], ang = lab * f;
+    out[idx] = (jj < half) ? cosf(ang) * f * dl : -sinf(ang) * f * dl;
+}
+// xd_in = c_in vx + dc_in x  (NCHW fp32, per image)
+__global__ void jvp_input_kernel(const float* __restrict__ vx, const float* __restrict__ x, const float* __restrict__ c_in,
+                                 const float* __restrict__ dc_in, float* __restrict__ out, int CHW, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / CHW;
+        out[i] = fmaf(c_in[n], vx[i], dc_in[n] * x[i]);
+    }
+}
+// jvp[n][c][p] = c_out Fd + dc_out F + c_skip vx + dc_skip x,  F = (out - c_skip x) / c_out (the network's raw output);
+// Fd is NHWC bf16 with channel stride Cf
+__global__ void jvp_output_kernel(const __bf16* __restrict__ fd, int Cf, const float* __restrict__ out, const float* __restrict__ x,
+                                  const float* __restrict__ vx, const float* __restrict__ ct, float* __restrict__ jvp, int B, int C, int HW,
+                                  int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = i % HW;
+        const int c = (int)((i / HW) % C);
+        const int64_t n = i / ((int64_t)HW * C);
+        const float cs = ct[4 * B + n], dcs = ct[5 * B + n], co = ct[6 * B + n], dco = ct[7 * B + n];
+        const float F = co != 0.f ? (out[i] - cs * x[i]) / co : 0.f;
+        jvp[i] = fmaf(co, (float)fd[(n * HW + p) * Cf + c], dco * F) + fmaf(cs, vx[i], dcs * x[i]);
+    }
+}
+__global__ void fill_f32_kernel(float* __restrict__ p, float v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void fill_f2_kernel(float2* __restrict__ p, float2 v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+// out = bf16(a + b) over fp32 operands (attention tangent: Pd V + P Vd)
+__global__ void add_f32_to_bf16_kernel(const float* __restrict__ a, const float* __restrict__ b, __bf16* __restrict__ out, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) out[i] = (__bf16)(a[i] + b[i]);
+}
+
 inline unsigned ew_blocks(int64_t n) {
     const int64_t b = (n + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
@@ -556,5 +665,53 @@ int launch_input_grad(const void* da, int cd, const float* c_in, const float* c_
                       hipStream_t s) {
     const int64_t total = (int64_t)B * C * hw;
     hipLaunchKernelGGL(input_grad_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)da, cd, c_in, c_skip, dout, dx, C, hw, total);
+    BWD_RET();
+}
+// GroupNorm(+SiLU) tangent of xd (dense [B, hw, C] over the concat) -> out [B, hw, C]; P / S scratch as in launch_gn_bwd
+int launch_gn_jvp(int mode, const void* x1, int c1, const void* x2, int c2, const void* xd, const float2* ab, const float2* mr,
+                  float2* P, float2* S, void* out, int B, int res, hipStream_t s) {
+    const int C = c1 + c2, hw = res * res;
+    if ((c1 % 8) || (c2 % 8) || C < 16) return (int)hipErrorInvalidValue;
+    const __bf16 *X1 = (const __bf16*)x1, *X2 = (const __bf16*)x2, *D = (const __bf16*)xd;
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<1>, dim3((C + 63) / 64, B), dim3(256), 0, s, X1, c1, X2, c2, D, C, ab, mr, P, res, 0);
+    hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(B), dim3(32), 0, s, P, (const float*)nullptr, S, C);
+    const int64_t total = (int64_t)B * hw * (C / 8);
+    if (mode == 0)
+        hipLaunchKernelGGL(gn_jvp_apply_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, C, ab, mr, S, (__bf16*)out, total, hw);
+    else
+        hipLaunchKernelGGL(gn_jvp_apply_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, C, ab, mr, S, (__bf16*)out, total, hw);
+    BWD_RET();
+}
+int launch_jvp_coef(const double* t, const double* r, const float* vt, const float* vr, double sigma_data, double sigma_shift, int drop,
+                    float* ct, int B, hipStream_t s) {
+    hipLaunchKernelGGL(jvp_coef_kernel, dim3((B + 127) / 128), dim3(128), 0, s, t, r, vt, vr, sigma_data, sigma_shift, drop, ct, B);
+    BWD_RET();
+}
+int launch_jvp_embed(const float* c_noise, const float* r_noise, const float* dc, const float* dr, const float* freqs, float* out, int B,
+                     int N, int noise_ch, hipStream_t s) {
+    hipLaunchKernelGGL(jvp_embed_kernel, dim3((B * N + 255) / 256), dim3(256), 0, s, c_noise, r_noise, dc, dr, freqs, out, B, N, noise_ch);
+    BWD_RET();
+}
+int launch_jvp_input(const float* vx, const float* x, const float* c_in, const float* dc_in, float* out, int B, int chw, hipStream_t s) {
+    const int64_t total = (int64_t)B * chw;
+    hipLaunchKernelGGL(jvp_input_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, vx, x, c_in, dc_in, out, chw, total);
+    BWD_RET();
+}
+int launch_jvp_output(const void* fd, int cf, const float* out, const float* x, const float* vx, const float* ct, float* jvp, int B, int C,
+                      int hw, hipStream_t s) {
+    const int64_t total = (int64_t)B * C * hw;
+    hipLaunchKernelGGL(jvp_output_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)fd, cf, out, x, vx, ct, jvp, B, C, hw, total);
+    BWD_RET();
+}
+int launch_fill_f32(float* p, float v, int n, hipStream_t s) {
+    hipLaunchKernelGGL(fill_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n);
+    BWD_RET();
+}
+int launch_fill_f2(float2* p, float a, float b, int n, hipStream_t s) {
+    hipLaunchKernelGGL(fill_f2_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, make_float2(a, b), n);
+    BWD_RET();
+}
+int launch_add_f32_to_bf16(const float* a, const float* b, void* out, int64_t total, hipStream_t s) {
+    hipLaunchKernelGGL(add_f32_to_bf16_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, a, b, (__bf16*)out, total);
     BWD_RET();
 }

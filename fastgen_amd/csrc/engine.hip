@@ -1360,7 +1360,7 @@ size_t plan_net_bwd(const fg_edm* h, int B, Arena& A, NetBwd& nb) {
     nb.dfp = A.take(npix * 128 * tsz);
     nb.op32 = A.take(npix * 32 * tsz);
     nb.wtmp = A.get<float>((size_t)128 * 256 * 9);
-    nb.wpad = A.get<float>((size_t)128 * 256 * 9);
+    nb.wpad = A.get<float>((size_t)256 * 256 * 9);  // head weights padded to 128 (backward) / 256 (forward-mode) output rows
     nb.vec = A.get<float>(1024);
     nb.demb = A.get<float>((size_t)B * h->emb_ch);
     nb.pre = A.get<float>((size_t)B * h->emb_ch);
@@ -1537,7 +1537,169 @@ int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, 
     }
     return FG_OK;
 }
+
+// ---- forward mode: tangents of (x_t, t, r) pushed through the network next to the kept forward -----------------
+// conv of a tangent: the forward kernel without prologue or bias on the forward's packed weights
+int tangent_conv(fg_edm* h, int ks, int res_mode, const void* src, int cin, int res_in, int res_out, const void* wpack, int cout,
+                 const float* temb, const void* resid, float scale, void* out, int B, hipStream_t s) {
+    ConvArgs a{};
+    a.src1 = src; a.C1 = cin; a.C2 = 0;
+    a.Hs = a.Ws = res_in; a.H = a.W = res_out; a.B = B;
+    a.wpack = wpack; a.bias = nullptr;
+    a.temb = temb; a.temb_stride = h->temb_total;
+    a.resid = resid; a.scale = scale; a.out = out; a.Cout = cout;
+    HIP_TRY(launch_conv_fused(1, ks, PRO_NONE, res_mode, OUT_NHWC, a, s));
+    return FG_OK;
+}
+
+// tangent of one UNetBlock: xd1 / xd2 are the tangents of its inputs, yd (bf16 [B, res_out^2, cout]) of its output
+int block_jvp(fg_edm* h, const Block& b, const Act& a1, int c1, const void* xd1, const Act& a2, int c2, const void* xd2,
+              const float* dtemb, void* yd, int B, Workspace& w, BwdScratch& q, const BlockStash& st, const float2* ident_ab,
+              hipStream_t s) {
+    const int res = b.res_out, res_in = b.res_in, hw = res * res, cin = b.cin, cout = b.cout;
+    const int rm = b.down ? 1 : (b.up ? 2 : 0);
+    const int res_mode = b.down ? RES_DOWN : (b.up ? RES_UP : RES_NONE);
+    int rc;
+    use_stash(w, st);
+    // tangent of the (virtual) concat as one dense tensor
+    const void* xd = xd1;
+    if (c2) {
+        HIP_TRY(launch_gn_act(2, xd1, c1, xd2, c2, nullptr, q.aop, B, res_in, 0, s));
+        xd = q.aop;
+    }
+    // conv0(silu(norm0(x))) + affine(emb)
+    HIP_TRY(launch_gn_jvp(0, a1.p, c1, c2 ? a2.p : nullptr, c2, xd, st.ab0, st.mr0, q.P, q.S, q.da, B, res_in, s));
+    const void* ad0 = q.da;
+    if (rm) {
+        HIP_TRY(launch_gn_act(2, q.da, cin, nullptr, 0, nullptr, q.dskip, B, res, rm, s));
+        ad0 = q.dskip;
+    }
+    if ((rc = tangent_conv(h, 3, RES_NONE, ad0, cin, res, res, b.p_conv0, cout, dtemb + b.temb_off, nullptr, 1.0f, q.dh0, B, s))) return rc;
+    // silu(norm1(h0))
+    HIP_TRY(launch_gn_jvp(0, st.h, cout, nullptr, 0, q.dh0, st.ab1, st.mr1, q.P, q.S, q.g1, B, res, s));
+    // skip path
+    const void* sd = xd;  // identity skip: same resolution and width
+    if (b.has_skip) {
+        if ((rc = tangent_conv(h, 1, res_mode, xd, cin, res_in, res, b.p_skip, cout, nullptr, nullptr, 1.0f, q.dxin, B, s))) return rc;
+        sd = q.dxin;
+    }
+    void* mid = b.attn ? q.gmid : yd;
+    if ((rc = tangent_conv(h, 3, RES_NONE, q.g1, cout, res, res, b.p_conv1, cout, nullptr, sd, kSkipScale, mid, B, s))) return rc;
+    if (b.attn) {
+        // (proj(attention(qkv(norm2(x_mid)))) + x_mid) * sigma
+        HIP_TRY(launch_gn_jvp(1, st.xattn, cout, nullptr, 0, q.gmid, st.ab2, st.mr2, q.P, q.S, q.da, B, res, s));
+        ConvArgs qa{};
+        qa.src1 = q.da; qa.C1 = cout; qa.Hs = qa.Ws = qa.H = qa.W = res; qa.B = B;
+        qa.ab = ident_ab; qa.wpack = b.p_qkv; qa.bias = nullptr; qa.scale = 1.0f; qa.Cout = 3 * cout;
+        qa.q_out = q.dq; qa.k_out = q.dk; qa.vt_out = q.dvt;
+        HIP_TRY(launch_conv_fused(1, 1, PRO_GN, RES_NONE, OUT_QKV, qa, s));
+        HIP_TRY(launch_attention_jvp(st.q, st.k, st.vt, q.dq, q.dk, q.dvt, q.da, q.att, B, hw, cout, s));
+        if ((rc = tangent_conv(h, 1, RES_NONE, q.da, cout, res, res, b.p_proj, cout, nullptr, q.gmid, kSkipScale, yd, B, s))) return rc;
+    }
+    return FG_OK;
+}
+
+int run_jvp(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* vx, const float* vt,
+            const float* vr, float* out, float* jvp, int B, Workspace& w, NetBwd& nb, hipStream_t s) {
+    const fg_edm_config& c = h->cfg;
+    const int res = c.img_resolution, hw = res * res, C = c.img_channels;
+    BwdScratch& q = nb.q;
+    int rc = run_forward(h, x_t, t, 1, r, 1, labels, out, B, w, s, nullptr, false, &nb.ts);
+    if (rc) return rc;
+    const Block *aux_norm = nullptr, *aux_conv = nullptr;
+    for (const Block& b : h->dec) {
+        if (b.kind == K_AUX_NORM) aux_norm = &b;
+        if (b.kind == K_AUX_CONV) aux_conv = &b;
+    }
+    if (!aux_norm || !aux_conv || aux_conv->cin != 256 || !h->enc[0].p_stem || !q.att)
+        return fail(FG_EINVAL, "jvp: head / stem shape not covered");
+    const int E = h->emb_ch, N = h->cond_ch, TT = h->temb_total;
+    // scratch reuse (nothing of the backward runs here): coefficient tangents, embedding tangents, identity GroupNorm coefficients
+    float* ct = nb.vec_all;                 // [8][B]  (temb_total floats >= 8 B for B <= 1056)
+    if (8 * B > TT) return fail(FG_EINVAL, "jvp: batch too large for the coefficient scratch");
+    float* e0 = nb.d0;                      // [B][N] tangent of emb0, later reused
+    float* dtemb = nb.dtemb_all;            // [B][TT] tangent of the stacked affine outputs
+    float2* ident = (float2*)nb.pre;        // [B][256] {1, 0}: `pre` has B * E floats = B * 256 float2
+    float* ones = nb.vec;                   // [<= 1024]
+    float* zeros = nb.vec + 512;
+    if (B > 512) return fail(FG_EINVAL, "jvp: batch too large for the constant scratch");
+    HIP_TRY(launch_fill_f32(ones, 1.0f, 512, s));
+    HIP_TRY(launch_fill_f32(zeros, 0.0f, 512, s));
+    HIP_TRY(launch_jvp_coef(t, c.r_timestep ? r : nullptr, vt, vr, c.sigma_data, c.sigma_shift, c.drop_precond, ct, B, s));
+    // ---- embedding: emb = silu(L1(silu(L0(emb0)))), temb = A emb + b ------------------------------------------------------------
+    {
+        const int w1 = h->find("model.map_layer1.weight"), b1 = h->find("model.map_layer1.bias");
+        const int w0 = h->find("model.map_layer0.weight"), b0 = h->find("model.map_layer0.bias");
+        HIP_TRY(launch_jvp_embed(w.coef + B, w.coef + 4 * (size_t)B, ct + 2 * (size_t)B, ct + 3 * (size_t)B, h->freqs, e0, B, N, h->noise_ch, s));
+        HIP_TRY(launch_linear(w.emb0, h->P(w0), h->P(b0), nb.d1, B, N, E, 0, s));        // pre-activation of layer 0
+        HIP_TRY(launch_linear(e0, h->P(w0), nullptr, nb.demb, B, N, E, 0, s));             // W0 emb0_dot
+        HIP_TRY(launch_silu_bwd(nb.demb, nb.d1, e0, B * E, s));                            // emb1_dot -> e0 ([B][E] fits: N <= E)
+        HIP_TRY(launch_linear(w.emb1, h->P(w1), h->P(b1), nb.d1, B, E, E, 0, s));        // pre-activation of layer 1
+        HIP_TRY(launch_linear(e0, h->P(w1), nullptr, nb.demb, B, E, E, 0, s));
+        HIP_TRY(launch_silu_bwd(nb.demb, nb.d1, e0, B * E, s));                            // emb_dot
+        HIP_TRY(launch_linear(e0, h->aff_w, nullptr, dtemb, B, E, TT, 0, s));
+    }
+    HIP_TRY(launch_fill_f2(ident, 1.0f, 0.0f, B * 256, s));
+    // ---- stem: conv(c_in x)  ->  conv(c_in vx + dc_in x) --------------------------------------------------------------------
+    float* xin = (float*)q.wg;  // fp32 [B, C, H, W]: the split-K scratch is idle here and far larger
+    HIP_TRY(launch_jvp_input(vx, x_t, ct, ct + B, xin, B, C * hw, s));
+    HIP_TRY(launch_stem(1, xin, ones, h->enc[0].p_stem, zeros, nb.genc[0], nullptr, B, res, h->enc[0].cin, s));
+    const Act none;
+    // ---- encoder -------------------------------------------------------------------------------------------------------------
+    for (size_t i = 1; i < h->enc.size(); ++i) {
+        const Block& b = h->enc[i];
+        if ((rc = block_jvp(h, b, w.skip[i - 1], b.cin, nb.genc[i - 1], none, 0, nullptr, dtemb, nb.genc[i], B, w, q,
+                            nb.ts.blocks[block_index(h, &b)], ident, s)))
+            return rc;
+    }
+    // ---- decoder -------------------------------------------------------------------------------------------------------------
+    const Act* x = &w.skip.back();
+    const void* xd = nb.genc.back();
+    void* pong[2] = {nb.ga, nb.gb};
+    int cur = 0, sp = (int)h->enc.size();
+    size_t di = 0;
+    for (const Block& b : h->dec) {
+        if (b.kind != K_BLOCK) continue;
+        const int c2 = b.skip_c, c1 = b.cin - c2;
+        const Act* x2 = &none;
+        const void* xd2 = nullptr;
+        if (c2) {
+            --sp;
+            x2 = &w.skip[sp];
+            xd2 = nb.genc[sp];
+        }
+        if ((rc = block_jvp(h, b, *x, c1, xd, *x2, c2, xd2, dtemb, pong[cur], B, w, q, nb.ts.blocks[block_index(h, &b)], ident, s)))
+            return rc;
+        x = &nb.ts.dec_store[di++];
+        xd = pong[cur];
+        cur ^= 1;
+    }
+    // ---- head: F = aux_conv(silu(aux_norm(y))), out = c_skip x + c_out F ---------------------------------------------------------
+    HIP_TRY(launch_gn_jvp(0, x->p, 256, nullptr, 0, xd, nb.ts.aux_ab, nb.ts.aux_mr, q.P, q.S, q.da, B, res, s));
+    HIP_TRY(launch_pad_rows(h->P(aux_conv->w), nb.wpad, aux_conv->cout, 256, 256 * 9, s));   // 256 output rows, C real ones
+    HIP_TRY(launch_pack_conv_weights(1, nb.wpad, q.wpk, 256, 256, 3, 0, s));
+    if ((rc = tangent_conv(h, 3, RES_NONE, q.da, 256, res, res, q.wpk, 256, nullptr, nullptr, 1.0f, q.dh0, B, s))) return rc;
+    HIP_TRY(launch_jvp_output(q.dh0, 256, out, x_t, vx, ct, jvp, B, C, hw, s));
+    return FG_OK;
+}
 }  // namespace
+
+int fg_edm_jvp(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* vx, const float* vt,
+               const float* vr, float* out, float* jvp, int batch, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !x_t || !t || !vx || !out || !jvp) return fail(FG_EINVAL, "null argument");
+    if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
+    if (!h->dtype) return fail(FG_EINVAL, "the forward-mode pass runs in the bf16 compute mode only");
+    if (h->cfg.r_timestep && !r) return fail(FG_EINVAL, "r is required by an r_timestep network");
+    if (batch <= 0 || !workspace || (((uintptr_t)workspace) & 255)) return fail(FG_EINVAL, "bad batch / workspace");
+    Arena A;
+    A.base = (char*)workspace;
+    Workspace w;
+    plan_workspace(h, batch, A, w);
+    NetBwd nb;
+    const size_t need = plan_net_bwd(h, batch, A, nb);
+    if (need > workspace_bytes) return fail(FG_ENOMEM, "workspace too small: need %zu bytes for batch %d, got %zu", need, batch, workspace_bytes);
+    return run_jvp(h, x_t, t, r, labels, vx, vt, vr, out, jvp, batch, w, nb, (hipStream_t)stream);
+}
 
 size_t fg_edm_backward_workspace_bytes(const fg_edm* h, int batch) {
     if (!h || batch <= 0) return 0;

@@ -57,6 +57,20 @@ int launch_linear_bwd(const float* dy, const float* x, const float* w, float* dw
 int launch_add_nchw_to_nhwc(const float* src, void* dst, int B, int C, int hw, hipStream_t s);
 int launch_input_grad(const void* da, int cd, const float* c_in, const float* c_skip, const float* dout, float* dx, int B, int C, int hw,
                       hipStream_t s);
+int launch_gn_jvp(int mode, const void* x1, int c1, const void* x2, int c2, const void* xd, const float2* ab, const float2* mr,
+                  float2* P, float2* S, void* out, int B, int res, hipStream_t s);
+int launch_jvp_coef(const double* t, const double* r, const float* vt, const float* vr, double sigma_data, double sigma_shift, int drop,
+                    float* ct, int B, hipStream_t s);
+int launch_jvp_embed(const float* c_noise, const float* r_noise, const float* dc, const float* dr, const float* freqs, float* out, int B,
+                     int N, int noise_ch, hipStream_t s);
+int launch_jvp_input(const float* vx, const float* x, const float* c_in, const float* dc_in, float* out, int B, int chw, hipStream_t s);
+int launch_jvp_output(const void* fd, int cf, const float* out, const float* x, const float* vx, const float* ct, float* jvp, int B, int C,
+                      int hw, hipStream_t s);
+int launch_fill_f32(float* p, float v, int n, hipStream_t s);
+int launch_fill_f2(float2* p, float a, float b, int n, hipStream_t s);
+int launch_add_f32_to_bf16(const float* a, const float* b, void* out, int64_t total, hipStream_t s);
+int launch_attention_jvp(const void* q, const void* k, const void* vt, const void* qd, const void* kd, const void* vtd, void* od,
+                         void* scratch, int B, int T, int C, hipStream_t s);
 // attn_bwd.hip
 size_t attention_backward_scratch_bytes(int B, int T, int C);
 int launch_attention_backward(const void* q, const void* k, const void* vt, const void* dO, void* dq, void* dk, void* dvt,

@@ -499,6 +499,36 @@ class EDMPrecond(FastGenNetwork):
             return out, self._logvar(t64)
         return out
 
+    @torch.no_grad()
+    def jvp(self, x_t: torch.Tensor, t: torch.Tensor, v_x: torch.Tensor, v_t: Optional[torch.Tensor] = None,
+            condition: Optional[torch.Tensor] = None, r: Optional[torch.Tensor] = None, v_r: Optional[torch.Tensor] = None,
+            fwd_pred_type: Optional[str] = None):
+        """(output, directional derivative) of `forward(x_t, t, condition=condition, r=r)` along (v_x, v_t, v_r) - what
+        `torch.func.jvp(net_wrapper, (x_t, t, r), tangents)` returns in MeanFlowModel._jvp / sCM (mean_flow.py:240-250, sCM.py:179),
+        as one library call (fg_edm_jvp, bf16 compute mode).  No graph is built (the reference detaches the result too)."""
+        if fwd_pred_type is not None and fwd_pred_type != self.net_pred_type:
+            raise NotImplementedError("jvp is provided for the network's own prediction type")
+        if r is None and self.r_timestep:
+            raise ValueError("this network was built with r_timestep=True: jvp() needs r")
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            dt, h = self._engine(x_t.device)
+        if dt != _lib.FG_DTYPE_BF16:
+            raise NotImplementedError("fastgen_amd.EDMPrecond.jvp runs in the bf16 compute mode only")
+        B, dev = x_t.shape[0], x_t.device
+        f32 = lambda a: None if a is None else torch.atleast_1d(a.detach()).to(device=dev, dtype=torch.float32).expand(B).contiguous()
+        f64 = lambda a: None if a is None else torch.atleast_1d(a.detach()).to(device=dev, dtype=torch.float64).expand(B).contiguous()
+        x32 = x_t.detach().to(torch.float32).contiguous()
+        vx = v_x.detach().to(torch.float32).contiguous()
+        t64, r64, vt, vr = f64(t), f64(r), f32(v_t), f32(v_r)
+        labels = self._labels(condition, B, dev)
+        ws = self._train_workspace(h, B, dev)
+        self._train_token = object()  # the kept state of an earlier training forward is overwritten
+        out, jv = torch.empty_like(x32), torch.empty_like(x32)
+        p = lambda a: ctypes.c_void_p(a.data_ptr() if a is not None else None)
+        _lib.check(_lib.lib().fg_edm_jvp(h, p(x32), p(t64), p(r64), p(labels), p(vx), p(vt), p(vr), p(out), p(jv), B,
+                                         ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream(dev)))
+        return out.to(x_t.dtype), jv.to(x_t.dtype)
+
     def _logvar(self, t64: torch.Tensor) -> torch.Tensor:
         """logvar_linear(PositionalEmbedding(c_noise)) — the un-flipped [cos|sin] embedding (EDM/network.py:501,571)."""
         if self.drop_precond in ("input", "both"):

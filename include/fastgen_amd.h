@@ -219,6 +219,14 @@ size_t fg_disc_edm_workspace_bytes(int res, int batch);
 int fg_disc_edm_run(const float* feat, int res, const float* const* params, float* logits, const float* dlogits, float* dfeat,
                     float* const* grads, int batch, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Forward-mode derivative (`torch.func.jvp(net, (x_t, t, r), tangents)` in MeanFlowModel._jvp / sCM,
+ * consistency_model/mean_flow.py:240-250, sCM.py:179): out = EDMPrecond.forward(x_t, t, r), jvp = its directional derivative along
+ * (vx [B,C,H,W], vt [B], vr [B]) (vt / vr nullable = 0; fp32).  bf16 compute mode; workspace sized by
+ * fg_edm_backward_workspace_bytes (the pass runs next to the kept forward and reuses its per-block stash); t > 0 for a
+ * preconditioned network (the raw output is recovered from out as (out - c_skip x) / c_out). */
+int fg_edm_jvp(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* vx, const float* vt,
+               const float* vr, float* out, float* jvp, int batch, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Samples to image bytes, the step after generator_fn in the reference's sample writer
  * (scripts/fid/compute_fid_from_ckpts.py:199): out[n,y,x,c] = uint8(clip(images[n,c,y,x] * 127.5 + 128, 0, 255)),
  * fp32 multiply then add, truncation; NaN -> 0.  images NCHW fp32, out NHWC bytes. */

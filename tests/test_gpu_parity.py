@@ -993,3 +993,26 @@ def test_backward_sees_updated_weights(sd):
         got, want = dict(net.named_parameters())[k].grad, pf[k].grad
         assert torch.equal(got, want), k                      # same kernels, same inputs: bit-identical
         assert not torch.equal(got, before[k]), k             # and the update was seen
+
+
+# ---- forward mode ---------------------------------------------------------------------------------------------
+def test_network_jvp_against_reference_func_jvp(nets, mf_nets, golden_dir):
+    """fg_edm_jvp against `torch.func.jvp` through the reference (tests/golden/jvp_b2.pt): the MeanFlow network with the tangents
+    MeanFlowModel._jvp uses, (dx/dt, 1, 0), and the preconditioned network with tangents in x_t and t.  bf16 compute:
+    relative L2 <= 3e-2 on the derivative, the forward value to the forward tolerance."""
+    fx = load(golden_dir, "jvp_b2.pt")
+    v = seeded((2, 3, 32, 32), 72).to(dev())
+    x = seeded((2, 3, 32, 32), 71).to(dev())
+    t, r = fx["mf/t"].to(dev()), fx["mf/r"].to(dev())
+    out, jv = mf_nets["bf16"].jvp(x, t, v, torch.ones_like(t), r=r, v_r=torch.zeros_like(r))
+    check(out, fx["mf/out"], "bf16", "MeanFlow jvp primal")
+    rel = float((jv.cpu() - fx["mf/jvp"]).norm() / fx["mf/jvp"].norm())
+    assert rel <= 3e-2, rel
+    t = fx["edm/t"]
+    x = (seeded((2, 3, 32, 32), 21) * t.reshape(2, 1, 1, 1)).to(dev())
+    out, jv = nets["bf16"].jvp(x, t.to(dev()), v, fx["edm/vt"].to(dev()), condition=fx["edm/cond"].to(dev()))
+    check(out, fx["edm/out"], "bf16", "EDM jvp primal")
+    rel = float((jv.cpu() - fx["edm/jvp"]).norm() / fx["edm/jvp"].norm())
+    assert rel <= 3e-2, rel
+    with pytest.raises(NotImplementedError):
+        nets["fp32"].jvp(x, t.to(dev()), v)
