@@ -37,3 +37,16 @@ class MeanFlowModel(FastGenModel):
             if jump and t_to > 0:
                 x = net.noise_scheduler.forward_process(x, torch.randn_like(x), t_to.expand(n))
         return x
+
+    @staticmethod
+    def network_jvp(net, x_t: torch.Tensor, t: torch.Tensor, r: torch.Tensor, dxt_dt: torch.Tensor,
+                    condition: Any = None) -> torch.Tensor:
+        """The tangent term of the MeanFlow objective, d/dt u(x_t + s dxt_dt, t + s, r) at s = 0 - the JVP branch of the
+        reference's `MeanFlowModel._jvp` (mean_flow.py:240-250: `torch.func.jvp(net_wrapper, (x_t, t, r), (dxt_dt, 1, 0))`), as
+        one `fg_edm_jvp` call for a `fastgen_amd` network.  Detached, like the reference's use of it."""
+        if not hasattr(net, "jvp"):
+            raise NotImplementedError("network_jvp needs a fastgen_amd network (EDMPrecond.jvp)")
+        _, u_jvp = net.jvp(x_t, t, dxt_dt, torch.ones_like(t, dtype=torch.float32), condition=condition, r=r,
+                           v_r=torch.zeros_like(r, dtype=torch.float32), fwd_pred_type="flow" if net.net_pred_type == "flow" else None)
+        return u_jvp
+
