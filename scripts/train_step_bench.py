@@ -25,7 +25,12 @@ for B in [int(a) for a in sys.argv[1:]] or [64, 128]:
         net.zero_grad(set_to_none=True)
         net(x, t, condition=cond).square().mean().backward()
 
-    for name, fn, mult in (("forward", fwd, 1.0), ("forward + backward", fwd_bwd, 3.0)):
+    vx = torch.randn_like(x)
+
+    def fwd_jvp():
+        return net.jvp(x, t, vx, torch.ones(B, device="cuda"), condition=cond)
+
+    for name, fn, mult in (("forward", fwd, 1.0), ("forward + backward", fwd_bwd, 3.0), ("forward + jvp (fg_edm_jvp)", fwd_jvp, 2.0)):
         for _ in range(2):
             fn()
         torch.cuda.synchronize()
@@ -35,4 +40,4 @@ for B in [int(a) for a in sys.argv[1:]] or [64, 128]:
             fn()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        print(f"B={B:4d} {name:20s}: {dt * 1e3:8.2f} ms  {B / dt:8.1f} img/s  {B * 42.383e9 * mult / dt / 1e12:7.1f} algorithmic TFLOP/s")
+        print(f"B={B:4d} {name:28s}: {dt * 1e3:8.2f} ms  {B / dt:8.1f} img/s  {B * 42.383e9 * mult / dt / 1e12:7.1f} algorithmic TFLOP/s")

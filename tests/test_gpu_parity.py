@@ -1008,6 +1008,8 @@ def test_network_jvp_against_reference_func_jvp(nets, mf_nets, golden_dir):
     check(out, fx["mf/out"], "bf16", "MeanFlow jvp primal")
     rel = float((jv.cpu() - fx["mf/jvp"]).norm() / fx["mf/jvp"].norm())
     assert rel <= 3e-2, rel
+    from fastgen_amd.methods.consistency_model.mean_flow import MeanFlowModel as MF
+    assert torch.equal(MF.network_jvp(mf_nets["bf16"], x, t, r, v), jv)  # the trainer-side helper: tangents (dx/dt, 1, 0)
     t = fx["edm/t"]
     x = (seeded((2, 3, 32, 32), 21) * t.reshape(2, 1, 1, 1)).to(dev())
     out, jv = nets["bf16"].jvp(x, t.to(dev()), v, fx["edm/vt"].to(dev()), condition=fx["edm/cond"].to(dev()))
