@@ -43,7 +43,9 @@ class MeanFlowModel(FastGenModel):
                     condition: Any = None) -> torch.Tensor:
         """The tangent term of the MeanFlow objective, d/dt u(x_t + s dxt_dt, t + s, r) at s = 0 - the JVP branch of the
         reference's `MeanFlowModel._jvp` (mean_flow.py:240-250: `torch.func.jvp(net_wrapper, (x_t, t, r), (dxt_dt, 1, 0))`), as
-        one `fg_edm_jvp` call for a `fastgen_amd` network.  Detached, like the reference's use of it."""
+        one `fg_edm_jvp` call for a `fastgen_amd` network.  Detached, like the reference's use of it.  It shares the module's
+        training workspace: call it BEFORE the differentiable forward of the same step (otherwise that forward's kept state is
+        overwritten and the backward recomputes it - correct, but one forward slower)."""
         if not hasattr(net, "jvp"):
             raise NotImplementedError("network_jvp needs a fastgen_amd network (EDMPrecond.jvp)")
         _, u_jvp = net.jvp(x_t, t, dxt_dt, torch.ones_like(t, dtype=torch.float32), condition=condition, r=r,
