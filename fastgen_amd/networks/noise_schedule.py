@@ -12,6 +12,7 @@ the same formulas run as HIP kernels (csrc/misc.hip) and these classes only supp
 """
 from __future__ import annotations
 
+import math
 from typing import Optional
 
 import torch
@@ -335,7 +336,82 @@ class RFNoiseSchedule(BaseNoiseSchedule):
         return self.safe_clamp(t, min_t, max_t)
 
 
-NOISE_SCHEDULES = {"edm": EDMNoiseSchedule, "rf": RFNoiseSchedule}
+class TrigNoiseSchedule(BaseNoiseSchedule):
+    """TrigFlow: x_t = cos(t) x_0 + sin(t) eps, t in [0, pi/2] (noise_schedule.py:1489-1648) - the time axis of the sCM-family
+    trainers (consistency_model/sCM.py), which wrap an EDM denoiser in `TrigFlowPrecond`.  Host-side only: nothing here runs
+    inside the fused sampler."""
+
+    schedule_id = -1  # no fused loop on this schedule
+
+    def __init__(self, min_t: float = 0.0, max_t: float = math.pi / 2, num_steps: int = 1000, **kwargs):
+        super().__init__(min_t, max_t, num_steps, **kwargs)
+        assert 0 <= min_t < max_t, "Trig min_t must be non-negative and less than max_t"
+        self._sigmas = torch.sin(torch.linspace(min_t, max_t, num_steps, dtype=self.t_precision))
+
+    @property
+    def max_sigma(self) -> float:
+        return torch.sin(torch.tensor(self.max_t)).item()
+
+    def alpha(self, t):
+        return torch.cos(t)
+
+    def sigma(self, t):
+        return torch.sin(t)
+
+    def alpha_prime(self, t):
+        return -torch.sin(t)
+
+    def sigma_prime(self, t):
+        return torch.cos(t)
+
+    def _rescale(self, t):
+        return t
+
+    def sigma_idx_to_t(self, sigma_idx: torch.Tensor) -> torch.Tensor:
+        """The table is sin of a linspace in t: index -> t linearly (noise_schedule.py:1532-1545)."""
+        assert sigma_idx.dtype == torch.long
+        return sigma_idx.to(self.t_precision) / (self.num_steps - 1) * (self.max_t - self.min_t) + self.min_t
+
+    def sqrt_snr(self, t: torch.Tensor) -> torch.Tensor:
+        """cot(t) with tan clamped away from zero, fp64 (noise_schedule.py:1547-1557)."""
+        assert self.is_t_valid(t)
+        return 1.0 / self.non_zero_clamp(torch.tan(t.to(torch.float64)))
+
+    def sqrt_snr_to_t(self, sqrt_snr_t: torch.Tensor) -> torch.Tensor:
+        """arccot as atan2(1, s), fp64 (noise_schedule.py:1559-1574)."""
+        s64 = sqrt_snr_t.to(torch.float64)
+        return torch.atan2(torch.ones_like(s64), s64).to(sqrt_snr_t.dtype)
+
+    def sample_t(self, n: int, time_dist_type: str = "uniform", train_p_mean: float = 0, train_p_std: float = 1.0,
+                 min_t: Optional[float] = 0.0, max_t: Optional[float] = math.pi / 2, device=None, **kwargs) -> torch.Tensor:
+        """Training-time timestep draws (noise_schedule.py:1576-1612)."""
+        min_t = max(min_t, self.min_t) if min_t is not None else self.min_t
+        max_t = min(max_t, self.max_t) if max_t is not None else self.max_t
+        dev = device or self._sigmas.device
+        if time_dist_type == "logitnormal":
+            t = torch.sigmoid(torch.randn(n, device=dev, dtype=self.t_precision) * train_p_std + train_p_mean) * (max_t - min_t) + min_t
+        elif time_dist_type == "uniform":
+            t = torch.rand(n, device=dev, dtype=self.t_precision) * (max_t - min_t) + min_t
+        else:
+            raise ValueError(f"Unsupported time distribution type: {time_dist_type} in TrigNoiseSchedule.")
+        return self.safe_clamp(t, min_t, max_t)
+
+    def flow_to_x0(self, xt, v, t):
+        """x_0 = cos(t) x_t - sin(t) v, fp64 (noise_schedule.py:1614-1632)."""
+        assert self.is_t_valid(t), f"t must be in [{self.min_t}, {self.max_t}], but got {t}"
+        t64 = t.to(torch.float64)
+        out = xt.to(torch.float64) * expand_like(torch.cos(t64), xt) - v.to(torch.float64) * expand_like(torch.sin(t64), xt)
+        return out.to(xt.dtype)
+
+    def x0_to_flow(self, xt, x0, t):
+        """v = (cos(t) x_t - x_0) / clamp(sin(t)), fp64 (noise_schedule.py:1634-1648)."""
+        assert self.is_t_valid(t), f"t must be in [{self.min_t}, {self.max_t}], but got {t}"
+        t64 = t.to(torch.float64)
+        num = xt.to(torch.float64) * expand_like(torch.cos(t64), xt) - x0.to(torch.float64)
+        return (num / self.non_zero_clamp(expand_like(torch.sin(t64), xt))).to(xt.dtype)
+
+
+NOISE_SCHEDULES = {"edm": EDMNoiseSchedule, "rf": RFNoiseSchedule, "rectified_flow": RFNoiseSchedule, "trig": TrigNoiseSchedule}
 
 
 def get_noise_schedule(name: str, **kwargs):

@@ -429,12 +429,53 @@ def jvp_fixture(edm_net):
     torch.save(fx, os.path.join(OUT, "jvp_b2.pt"))
 
 
+def trigflow_fixture(edm_net, ns):
+    """sCM-family network interface (consistency_model/sCM.py:21-83, 150-181): `TrigNoiseSchedule` members and `TrigFlowPrecond`
+    around the CIFAR-10 denoiser - forward and `torch.func.jvp` along seeded tangents, B = 2."""
+    import importlib
+
+    scm = importlib.import_module("fastgen.methods.consistency_model.sCM")
+    fx = {}
+    sched = ns.TrigNoiseSchedule()
+    t = torch.tensor([0.2, 0.9, 1.5], dtype=torch.float64)
+    x, e = seeded((3, 3, 4, 4), 81), seeded((3, 3, 4, 4), 82)
+    fx["sched/t"] = t
+    fx["sched/sqrt_snr"] = sched.sqrt_snr(t)
+    fx["sched/sqrt_snr_to_t"] = sched.sqrt_snr_to_t(torch.tensor([0.0, 0.4, 3.0, 1e3], dtype=torch.float32))
+    fx["sched/forward_process"] = sched.forward_process(x, e, t)
+    fx["sched/x0_to_flow"] = sched.x0_to_flow(x, e, t)
+    fx["sched/flow_to_x0"] = sched.flow_to_x0(x, e, t)
+    fx["sched/sigma_idx_to_t"] = sched.sigma_idx_to_t(torch.tensor([0, 17, 999]))
+    fx["sched/max_sigma"] = torch.tensor(sched.max_sigma, dtype=torch.float64)
+    for k in ("uniform", "logitnormal"):
+        torch.manual_seed(83)
+        fx[f"sched/sample_t_{k}"] = sched.sample_t(16, time_dist_type=k)
+    cfg = edm_ref.CIFAR10
+    sd = edm_ref.random_state_dict(cfg, seed=1234)
+    net = ref_net(edm_net, cfg, sd)
+    wrap = scm.TrigFlowPrecond(net, sigma_data=0.5)
+    t_hat = torch.tensor([0.35, 1.25])
+    xh = seeded((2, 3, 32, 32), 84) * 0.5
+    cond = torch.nn.functional.one_hot(torch.tensor([3, 7]), 10).float()
+    vx, vt = seeded((2, 3, 32, 32), 85), torch.tensor([0.16, 0.14])
+    with torch.no_grad():
+        F0 = wrap(xh, t_hat, condition=cond)
+        F1, dF = torch.func.jvp(lambda a, b: wrap(a, b.clamp(min=-torch.pi / 2 + 1e-4, max=torch.pi / 2 - 1e-4), condition=cond),
+                                (xh, t_hat), (vx, vt))
+        x_t, tt = wrap._convert_trigflow_to_net_input(xh, t_hat)
+    fx.update({"wrap/t_hat": t_hat, "wrap/vt": vt, "wrap/cond": cond, "wrap/F": F0.clone(), "wrap/dF": dF.clone(), "wrap/x_t": x_t.clone(),
+               "wrap/t": tt.clone()})
+    assert torch.allclose(F0, F1)
+    torch.save(fx, os.path.join(OUT, "trigflow_b2.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     edm_net, ns, model = _ref_import.import_reference()
     torch.manual_seed(0)
     if sys.argv[1:] == ["jvp"]:
         jvp_fixture(edm_net)
+        trigflow_fixture(edm_net, ns)
         print("jvp fixture written to", OUT)
         return
     if sys.argv[1:] == ["backward"]:
@@ -586,6 +627,7 @@ def main():
     meanflow_backward_fixture(edm_net)
     discriminator_fixture()
     jvp_fixture(edm_net)
+    trigflow_fixture(edm_net, ns)
     teacher_sample_fixture(edm_net)
 
     print("golden fixtures written to", OUT)

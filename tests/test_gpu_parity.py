@@ -1018,3 +1018,22 @@ def test_network_jvp_against_reference_func_jvp(nets, mf_nets, golden_dir):
     assert rel <= 3e-2, rel
     with pytest.raises(NotImplementedError):
         nets["fp32"].jvp(x, t.to(dev()), v)
+
+
+def test_trigflow_wrapper_jvp_on_the_hip_network(nets, golden_dir):
+    """sCM-family interface: TrigFlowPrecond around the HIP denoiser - forward and the composed forward-mode derivative against
+    `torch.func.jvp` through the reference's wrapper (tests/golden/trigflow_b2.pt); bf16 compute, relative L2 <= 3e-2."""
+    from fastgen_amd.methods.consistency_model.sCM import TrigFlowPrecond
+
+    fx = load(golden_dir, "trigflow_b2.pt")
+    w = TrigFlowPrecond(nets["bf16"], sigma_data=0.5)
+    xh = (seeded((2, 3, 32, 32), 84) * 0.5).to(dev())
+    vx = seeded((2, 3, 32, 32), 85).to(dev())
+    t_hat, vt, cond = fx["wrap/t_hat"].to(dev()), fx["wrap/vt"].to(dev()), fx["wrap/cond"].to(dev())
+    with torch.no_grad():
+        F = w(xh, t_hat, condition=cond)
+    assert float((F.cpu() - fx["wrap/F"]).norm() / fx["wrap/F"].norm()) <= 1e-2
+    F2, dF = w.jvp(xh, t_hat, vx, vt, condition=cond)
+    assert float((F2.cpu() - fx["wrap/F"]).norm() / fx["wrap/F"].norm()) <= 1e-2
+    rel = float((dF.cpu() - fx["wrap/dF"]).norm() / fx["wrap/dF"].norm())
+    assert rel <= 3e-2, rel

@@ -389,3 +389,53 @@ def test_training_abi_argument_checks_without_gpu():
             _lib.check(L.fg_op_conv_wgrad(one, one, one, 4, 32, 256, 256, 3, 0, one, 16, None))
     finally:
         L.fg_edm_destroy(h)
+
+
+def test_trig_schedule_matches_golden(golden_dir):
+    """TrigNoiseSchedule (the sCM-family time axis) against values recorded from the reference: exact."""
+    fx = torch.load(os.path.join(golden_dir, "trigflow_b2.pt"), weights_only=True)
+    s = get_noise_schedule("trig")
+    t = fx["sched/t"]
+    x = torch.randn((3, 3, 4, 4), generator=torch.Generator().manual_seed(81))
+    e = torch.randn((3, 3, 4, 4), generator=torch.Generator().manual_seed(82))
+    assert torch.equal(s.sqrt_snr(t), fx["sched/sqrt_snr"])
+    assert torch.equal(s.sqrt_snr_to_t(torch.tensor([0.0, 0.4, 3.0, 1e3], dtype=torch.float32)), fx["sched/sqrt_snr_to_t"])
+    assert torch.equal(s.forward_process(x, e, t), fx["sched/forward_process"])
+    assert torch.equal(s.x0_to_flow(x, e, t), fx["sched/x0_to_flow"])
+    assert torch.equal(s.flow_to_x0(x, e, t), fx["sched/flow_to_x0"])
+    assert torch.equal(s.sigma_idx_to_t(torch.tensor([0, 17, 999])), fx["sched/sigma_idx_to_t"])
+    assert s.max_sigma == float(fx["sched/max_sigma"])
+    for k in ("uniform", "logitnormal"):
+        torch.manual_seed(83)
+        assert torch.equal(s.sample_t(16, time_dist_type=k), fx[f"sched/sample_t_{k}"])
+
+
+def test_trigflow_wrapper_composition_with_the_oracle_as_network(golden_dir):
+    """TrigFlowPrecond's input map, forward and composed jvp (torch.func.jvp of the elementwise maps around the network's own
+    jvp) against the reference's wrapper under torch.func.jvp - with the CPU oracle standing in for the network, so the
+    composition logic is checked without a GPU."""
+    from fastgen_amd.methods.consistency_model.sCM import TrigFlowPrecond
+
+    fx = torch.load(os.path.join(golden_dir, "trigflow_b2.pt"), weights_only=True)
+    sd = R.random_state_dict(R.CIFAR10, seed=1234)
+
+    class OracleNet(torch.nn.Module):
+        noise_scheduler = get_noise_schedule("edm")
+
+        def forward(self, x, t, condition=None, return_logvar=False, fwd_pred_type="x0"):
+            return R.edm_precond_forward(sd, R.CIFAR10, x, t, condition)
+
+        def jvp(self, x, t, vx, vt, condition=None, fwd_pred_type=None):
+            return R.edm_precond_jvp(sd, R.CIFAR10, x, t, condition, vx, vt)
+
+    w = TrigFlowPrecond(OracleNet(), sigma_data=0.5)
+    xh = torch.randn((2, 3, 32, 32), generator=torch.Generator().manual_seed(84)) * 0.5
+    vx = torch.randn((2, 3, 32, 32), generator=torch.Generator().manual_seed(85))
+    x_t, t = w._convert_trigflow_to_net_input(xh, fx["wrap/t_hat"])
+    assert torch.equal(x_t, fx["wrap/x_t"]) and torch.equal(t, fx["wrap/t"])
+    with torch.no_grad():
+        F = w(xh, fx["wrap/t_hat"], condition=fx["wrap/cond"])
+    assert torch.allclose(F, fx["wrap/F"], rtol=1e-4, atol=1e-5)
+    F2, dF = w.jvp(xh, fx["wrap/t_hat"], vx, fx["wrap/vt"], condition=fx["wrap/cond"])
+    assert torch.allclose(F2, fx["wrap/F"], rtol=1e-4, atol=1e-5)
+    assert float((dF - fx["wrap/dF"]).norm() / fx["wrap/dF"].norm()) <= 1e-4
