@@ -165,7 +165,7 @@ int launch_attention_jvp(const void* q, const void* k, const void* vt, const voi
     void *t0 = take(tc), *t1 = take(tc), *t2 = take(tc), *t3 = take(tc);  // scratch sized like the backward's 4 transposes
     void *P = take(tt2), *Pd = take(tt2), *u0 = take(tt2), *u1 = take(tt2);
     float *S = (float*)take(tt4), *Sd = (float*)take(tt4);
-    (void)t2, (void)t3, (void)u0, (void)u1;
+    (void)u0, (void)u1;
     const float sc = 1.0f / sqrtf((float)C);
     nt_gemm<false>(q, k, S, B, T, T, C, 1.0f, s);
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((size_t)B * T)), dim3(T), 0, s, S, (__bf16*)P, T, sc);
@@ -192,7 +192,7 @@ int launch_attention_jvp(const void* q, const void* k, const void* vt, const voi
         const int64_t blocks = (total + 255) / 256;
         hipLaunchKernelGGL(add_to_bf16_kernel, dim3((unsigned)(blocks > 65536 ? 65536 : blocks)), dim3(256), 0, s, o0, o1, (__bf16*)od, total);
     }
-    (void)t1;
+    (void)t1, (void)t3;
     return (int)hipGetLastError();
 }
 

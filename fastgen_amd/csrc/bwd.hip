@@ -280,9 +280,6 @@ __global__ __launch_bounds__(256) void batchsum_add_kernel(const float* __restri
 __global__ void scale_to_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, float scale, int64_t total) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) out[i] = (__bf16)(in[i] * scale);
 }
-__global__ void scale_bf16_kernel(const __bf16* __restrict__ in, __bf16* __restrict__ out, float scale, int64_t total) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) out[i] = (__bf16)((float)in[i] * scale);
-}
 // bf16 [.., Cs] channels [c_off, c_off + C) -> fp32 [.., C]
 __global__ void slice_to_f32_kernel(const __bf16* __restrict__ in, int Cs, int c_off, float* __restrict__ out, int C, int64_t npix) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix * C; i += (int64_t)gridDim.x * 256) {
@@ -363,16 +360,6 @@ __global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict
 __global__ void add_bf16_kernel(__bf16* __restrict__ dst, const __bf16* __restrict__ src, int64_t total) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
         dst[i] = (__bf16)((float)dst[i] + (float)src[i]);
-}
-// dst[p][c] (=|+=) src[p][off + c]
-__global__ void slice_bf16_kernel(const __bf16* __restrict__ src, int Cs, int off, __bf16* __restrict__ dst, int C, int64_t npix,
-                                  int accumulate) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix * C; i += (int64_t)gridDim.x * 256) {
-        const int64_t p = i / C;
-        const int c = (int)(i - p * C);
-        const float v = (float)src[p * Cs + off + c];
-        dst[i] = (__bf16)(accumulate ? (float)dst[i] + v : v);
-    }
 }
 // dpre = dy * silu'(pre)   (map_layer0 / map_layer1, EDM/network.py:520-521)
 __global__ void silu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dpre, int total) {
@@ -526,10 +513,6 @@ __global__ void fill_f2_kernel(float2* __restrict__ p, float2 v, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
-// out = bf16(a + b) over fp32 operands (attention tangent: Pd V + P Vd)
-__global__ void add_f32_to_bf16_kernel(const float* __restrict__ a, const float* __restrict__ b, __bf16* __restrict__ out, int64_t total) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) out[i] = (__bf16)(a[i] + b[i]);
-}
 
 inline unsigned ew_blocks(int64_t n) {
     const int64_t b = (n + 255) / 256;
@@ -596,10 +579,6 @@ int launch_scale_to_bf16(const float* in, void* out, float scale, int64_t total,
     hipLaunchKernelGGL(scale_to_bf16_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, in, (__bf16*)out, scale, total);
     BWD_RET();
 }
-int launch_scale_bf16(const void* in, void* out, float scale, int64_t total, hipStream_t s) {
-    hipLaunchKernelGGL(scale_bf16_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)in, (__bf16*)out, scale, total);
-    BWD_RET();
-}
 int launch_slice_to_f32(const void* in, int cs, int c_off, float* out, int C, int64_t npix, hipStream_t s) {
     hipLaunchKernelGGL(slice_to_f32_kernel, dim3(ew_blocks(npix * C)), dim3(256), 0, s, (const __bf16*)in, cs, c_off, out, C, npix);
     BWD_RET();
@@ -633,10 +612,6 @@ int launch_pad_rows(const float* src, float* dst, int O, int Op, int IT, hipStre
 }
 int launch_add_bf16(void* dst, const void* src, int64_t total, hipStream_t s) {
     hipLaunchKernelGGL(add_bf16_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, (__bf16*)dst, (const __bf16*)src, total);
-    BWD_RET();
-}
-int launch_slice_bf16(const void* src, int cs, int off, void* dst, int C, int64_t npix, int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(slice_bf16_kernel, dim3(ew_blocks(npix * C)), dim3(256), 0, s, (const __bf16*)src, cs, off, (__bf16*)dst, C, npix, accumulate);
     BWD_RET();
 }
 int launch_silu_bwd(const float* dy, const float* pre, float* dpre, int total, hipStream_t s) {
@@ -709,9 +684,5 @@ int launch_fill_f32(float* p, float v, int n, hipStream_t s) {
 }
 int launch_fill_f2(float2* p, float a, float b, int n, hipStream_t s) {
     hipLaunchKernelGGL(fill_f2_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, make_float2(a, b), n);
-    BWD_RET();
-}
-int launch_add_f32_to_bf16(const float* a, const float* b, void* out, int64_t total, hipStream_t s) {
-    hipLaunchKernelGGL(add_f32_to_bf16_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, a, b, (__bf16*)out, total);
     BWD_RET();
 }

@@ -41,7 +41,6 @@ int launch_colsum(const void* t, int ct, int C, float* out, int B, int hw, float
 int launch_transpose_f32(const float* in, float* out, int R, int Cc, hipStream_t s);
 int launch_batchsum_add(const float* in, float* out, int B, int C, hipStream_t s, float* out2 = nullptr);
 int launch_scale_to_bf16(const float* in, void* out, float scale, int64_t total, hipStream_t s);
-int launch_scale_bf16(const void* in, void* out, float scale, int64_t total, hipStream_t s);
 int launch_slice_to_f32(const void* in, int cs, int c_off, float* out, int C, int64_t npix, hipStream_t s);
 int launch_affine_bwd(const float* dtemb, const float* emb, const float* w, float* dw, float* demb, int B, int C, int K, hipStream_t s);
 int launch_dgrad_weights(const float* w, float* wt, int cout, int cin, int cin_pad, int taps, hipStream_t s);
@@ -50,7 +49,6 @@ int launch_stem_operand(const float* x, const float* c_in, void* out, int B, int
 int launch_add_sub_tensor(const float* src, int Is, float* dst, int O, int I, int T, hipStream_t s);
 int launch_pad_rows(const float* src, float* dst, int O, int Op, int IT, hipStream_t s);
 int launch_add_bf16(void* dst, const void* src, int64_t total, hipStream_t s);
-int launch_slice_bf16(const void* src, int cs, int off, void* dst, int C, int64_t npix, int accumulate, hipStream_t s);
 int launch_silu_bwd(const float* dy, const float* pre, float* dpre, int total, hipStream_t s);
 int launch_linear_bwd(const float* dy, const float* x, const float* w, float* dw, float* db, float* dx, int B, int C, int K,
                       float scale, hipStream_t s, int dy_stride = 0);
@@ -68,7 +66,6 @@ int launch_jvp_output(const void* fd, int cf, const float* out, const float* x, 
                       int hw, hipStream_t s);
 int launch_fill_f32(float* p, float v, int n, hipStream_t s);
 int launch_fill_f2(float2* p, float a, float b, int n, hipStream_t s);
-int launch_add_f32_to_bf16(const float* a, const float* b, void* out, int64_t total, hipStream_t s);
 int launch_attention_jvp(const void* q, const void* k, const void* vt, const void* qd, const void* kd, const void* vtd, void* od,
                          void* scratch, int B, int T, int C, hipStream_t s);
 // attn_bwd.hip
