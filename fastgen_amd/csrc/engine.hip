@@ -1103,717 +1103,7 @@ int fg_edm_run_block(fg_edm* h, int index, const float* x1, int c1, const float*
     return FG_OK;
 }
 
-// ---- training step, block level -------------------------------------------------------------------------
-namespace {
-struct BwdScratch {
-    void *g1, *aop, *da, *dh0, *dskip, *dxin, *wpk, *wg;
-    void *gmid = nullptr, *dq = nullptr, *dk = nullptr, *dvt = nullptr, *dqkv = nullptr, *att = nullptr;  // attention blocks only
-    float2 *P, *S, *mr0, *mr1, *mr2;
-    float *dtemb, *wt;
-    size_t wg_bytes;
-};
-int pad256(int c) { return (c + 255) / 256 * 256; }
-// split-K scratch the weight-gradient kernel needs for one block's convolutions (the split count depends on every dimension)
-size_t block_wgrad_bytes(int B, int res, int cin, int cout, bool attn) {
-    size_t m = 0;
-    const int shapes[5][3] = {{cout, cout, 3}, {cin, cout, 3}, {cin, cout, 1}, {cout, 3 * cout, 1}, {cout, cout, 1}};
-    for (int i = 0; i < (attn ? 5 : 3); ++i)
-        if (conv_wgrad_supported(res, shapes[i][0], shapes[i][1], shapes[i][2]))
-            m = std::max(m, conv_wgrad_workspace_bytes(B, res, shapes[i][0], shapes[i][1], shapes[i][2]));
-    return m;
-}
-size_t plan_block_bwd(int B, int res_in, int res, int cin, int cout, Arena& A, BwdScratch& q, int attn_hw = 0, size_t wg_bytes = 0) {
-    const size_t npix = (size_t)B * res * res, npix_in = (size_t)B * res_in * res_in;
-    const int cp = pad256(cin), cm = cin > cout ? cin : cout;
-    q.g1 = A.take(npix * cout * 2);
-    q.aop = A.take(npix * cm * 2);
-    q.da = A.take(npix * (cp > cout ? cp : cout) * 2);
-    q.dh0 = A.take(npix * cout * 2);
-    q.dskip = A.take(npix * cp * 2);
-    q.dxin = A.take(npix_in * cin * 2);
-    q.P = A.get<float2>((size_t)B * cm);
-    q.S = A.get<float2>((size_t)B * 32);
-    q.mr0 = A.get<float2>((size_t)B * 32);
-    q.mr1 = A.get<float2>((size_t)B * 32);
-    q.mr2 = A.get<float2>((size_t)B * 32);
-    q.dtemb = A.get<float>((size_t)B * cout * 3);
-    if (attn_hw) {
-        q.gmid = A.take(npix * cout * 2);
-        q.dq = A.take(npix * cout * 2);
-        q.dk = A.take(npix * cout * 2);
-        q.dvt = A.take(npix * cout * 2);
-        q.dqkv = A.take(npix * cout * 3 * 2);
-        q.att = A.take(attention_backward_scratch_bytes(B, attn_hw, cout));
-    }
-    const size_t welems = (size_t)(cp > cout ? cp : cout) * (cin > cout ? cin : cout) * 9;
-    q.wt = A.get<float>(welems);
-    q.wpk = A.take(welems * 2);
-    q.wg_bytes = wg_bytes ? wg_bytes : block_wgrad_bytes(B, res, cin, cout, attn_hw != 0);
-    q.wg = A.take(q.wg_bytes);
-    return A.off;
-}
-// data gradient of a conv = the forward conv kernel on dY with transposed, flipped weights; output [npix][pad256(cin)]
-int conv_dgrad(fg_edm* h, const float* w_oihw, int cout, int cin, int ks, const void* dy, void* out, int B, int res, BwdScratch& q,
-               hipStream_t s, bool cache = true, float oscale = 1.0f) {
-    const int cp = pad256(cin);
-    void* wpk = q.wpk;
-    if (cache) {  // parameters: packed once per weight version; scratch-built weights (the padded head) are not cached
-        fg_edm::DgradW& e = h->dgrad_cache[w_oihw];
-        if (!e.packed) {
-            int rc = dev_alloc(h, &e.packed, (size_t)cp * cout * ks * ks * 2);
-            if (rc) return rc;
-        }
-        if (e.epoch != h->pack_epoch) {
-            HIP_TRY(launch_dgrad_weights(w_oihw, q.wt, cout, cin, cp, ks * ks, s));
-            HIP_TRY(launch_pack_conv_weights(1, q.wt, e.packed, cp, cout, ks, 0, s));
-            e.epoch = h->pack_epoch;
-        }
-        wpk = e.packed;
-    } else {
-        HIP_TRY(launch_dgrad_weights(w_oihw, q.wt, cout, cin, cp, ks * ks, s));
-        HIP_TRY(launch_pack_conv_weights(1, q.wt, q.wpk, cp, cout, ks, 0, s));
-    }
-    ConvArgs a{};
-    a.src1 = dy; a.C1 = cout; a.C2 = 0;
-    a.Hs = a.Ws = a.H = a.W = res; a.B = B;
-    a.wpack = wpk; a.scale = oscale; a.out = out; a.Cout = cp;
-    HIP_TRY(launch_conv_fused(1, ks, PRO_NONE, RES_NONE, OUT_NHWC, a, s));
-    return FG_OK;
-}
-
-// weight gradient with a host-side check of the split-K scratch (an undersized scratch would be an out-of-bounds write)
-int wgrad_checked(const void* act, const void* dy, float* dw, int B, int res, int cin, int cout, int ks, int accumulate, void* wg,
-                  size_t wg_bytes, hipStream_t s, float scale = 1.0f) {
-    const size_t need = conv_wgrad_workspace_bytes(B, res, cin, cout, ks);
-    if (need > wg_bytes) return fail(FG_ENOMEM, "weight-gradient scratch too small: %zu > %zu (res %d, %d -> %d, k%d)", need, wg_bytes, res, cin, cout, ks);
-    HIP_TRY(launch_conv_wgrad(act, dy, dw, B, res, cin, cout, ks, accumulate, wg, s, scale));
-    return FG_OK;
-}
-
-// Backward of one UNetBlock (bf16).  a1 / a2: the block's inputs (virtual concat) at res_in; gout: dL/d(block output), bf16
-// [B, res_out^2, cout]; dxin: bf16 [B, res_in^2, cin] (overwritten); demb [B, emb_ch] and the bound parameter gradients are
-// accumulated.  The block's forward is recomputed here (activation checkpointing at block granularity).
-int block_backward(fg_edm* h, const Block& b, const Act& a1, int c1, const Act& a2, int c2, const float* emb, const float* temb,
-                   const void* gout, void* dxin, float* demb, int B, Workspace& w, BwdScratch& q, hipStream_t s,
-                   float* dtemb_all = nullptr, const BlockStash* stash = nullptr, void* dxin2 = nullptr, int dx_accumulate = 0) {
-    // dxin2 != nullptr: the gradients of the two concat sources go to their own dense tensors (dxin: [.., c1], dxin2: [.., c2]);
-    // dx_accumulate: added to what dxin (/ dxin2) hold
-    const int res = b.res_out, res_in = b.res_in, hw = res * res, cin = b.cin, cout = b.cout, cp = pad256(cin);
-    const int rm = b.down ? 1 : (b.up ? 2 : 0);
-    if (!conv_wgrad_supported(res, cout, cout, 3) || !conv_wgrad_supported(res, cin, cout, 3))
-        return fail(FG_EINVAL, "%s: shape not covered by the weight-gradient kernel", b.key.c_str());
-    const size_t npix = (size_t)B * hw;
-    int rc = FG_OK;
-    if (stash) {
-        // the forward that preceded this call left the block's intermediates in its stash: nothing to recompute
-        use_stash(w, *stash);
-        q.mr0 = stash->mr0, q.mr1 = stash->mr1, q.mr2 = stash->mr2;
-    } else {
-        w.mr0 = q.mr0;
-        w.mr1 = q.mr1;
-        w.mr2 = q.mr2;
-        rc = run_block(h, b, a1, c1, a2, c2, temb, w.xa, B, w, s);
-        w.mr0 = w.mr1 = w.mr2 = nullptr;
-        if (rc) return rc;
-    }
-    // The gradient reaching a block's output is used as is; the residual scale sigma = sqrt(1/2) of
-    // out = (branch + skip) * sigma travels as a factor into every consumer (no scaled copy, one bf16 rounding less).
-    const float sg = kSkipScale;
-    if (b.attn) {
-        // out = (proj(attention(qkv(norm2(x_mid)))) + x_mid) * sigma, EDM/network.py:290-298
-        if (!q.att) return fail(FG_EINVAL, "%s: scratch was planned without the attention part", b.key.c_str());
-        const int C3 = 3 * cout;
-        HIP_TRY(launch_colsum(gout, cout, cout, q.dtemb, B, hw, sg, s));
-        if (h->G(b.proj_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.proj_b), B, cout, s));
-        if (h->G(b.proj_w) && (rc = wgrad_checked(w.aout, gout, h->G(b.proj_w), B, res, cout, cout, 1, 1, q.wg, q.wg_bytes, s, sg))) return rc;
-        if ((rc = conv_dgrad(h, h->P(b.proj_w), cout, cout, 1, gout, q.da, B, res, q, s, true, sg))) return rc;
-        HIP_TRY(launch_attention_backward(w.q, w.k, w.vt, q.da, q.dq, q.dk, q.dvt, q.att, B, hw, cout, s));
-        HIP_TRY(launch_qkv_interleave(q.dq, q.dk, q.dvt, q.dqkv, B, hw, cout, s));
-        HIP_TRY(launch_colsum(q.dqkv, C3, C3, q.dtemb, B, hw, 1.0f, s));
-        if (h->G(b.qkv_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.qkv_b), B, C3, s));
-        if (h->G(b.qkv_w)) {
-            HIP_TRY(launch_gn_act(1, w.xattn.p, cout, nullptr, 0, w.ab2, q.aop, B, res, 0, s));
-            if ((rc = wgrad_checked(q.aop, q.dqkv, h->G(b.qkv_w), B, res, cout, C3, 1, 1, q.wg, q.wg_bytes, s))) return rc;
-        }
-        if ((rc = conv_dgrad(h, h->P(b.qkv_w), C3, cout, 1, q.dqkv, q.da, B, res, q, s))) return rc;
-        // norm2 (no activation); the residual x_mid -> out contributes sigma * gout directly
-        HIP_TRY(launch_gn_bwd(1, w.xattn.p, cout, nullptr, 0, q.da, pad256(cout), w.ab2, q.mr2, h->P(b.norm2_w), q.P, q.S,
-                              h->G(b.norm2_w), h->G(b.norm2_b), gout, cout, sg, q.gmid, B, res, 0, s));
-        gout = q.gmid;
-    }
-    // x_mid = (conv1(act1) + skip) * sigma: sigma * gout reaches conv1's output and the skip path alike
-    HIP_TRY(launch_colsum(gout, cout, cout, q.dtemb, B, hw, sg, s));
-    {
-        float* d1 = h->G(b.conv1_b);
-        float* d2 = b.has_skip ? h->G(b.skip_b) : nullptr;
-        if (d1 || d2) HIP_TRY(launch_batchsum_add(q.dtemb, d1 ? d1 : d2, B, cout, s, d1 ? d2 : nullptr));
-    }
-    // conv1
-    if (h->G(b.conv1_w)) {
-        HIP_TRY(launch_gn_act(0, w.h.p, cout, nullptr, 0, w.ab1, q.aop, B, res, 0, s));
-        if ((rc = wgrad_checked(q.aop, gout, h->G(b.conv1_w), B, res, cout, cout, 3, 1, q.wg, q.wg_bytes, s, sg))) return rc;
-    }
-    if ((rc = conv_dgrad(h, h->P(b.conv1_w), cout, cout, 3, gout, q.da, B, res, q, s, true, sg))) return rc;
-    // norm1 + silu
-    HIP_TRY(launch_gn_bwd(0, w.h.p, cout, nullptr, 0, q.da, pad256(cout), w.ab1, q.mr1, h->P(b.norm1_w), q.P, q.S, h->G(b.norm1_w),
-                          h->G(b.norm1_b), nullptr, 0, 0.f, q.dh0, B, res, 0, s));
-    // bias of conv0 and the embedding affine see the pixel sum of dh0
-    if (dtemb_all) {
-        // whole-network pass: parked in the stacked [B][temb_total] matrix; biases, affine weights and demb follow in one go
-        HIP_TRY(launch_colsum(q.dh0, cout, cout, dtemb_all + b.temb_off, B, hw, 1.0f, s, h->temb_total));
-    } else {
-        HIP_TRY(launch_colsum(q.dh0, cout, cout, q.dtemb, B, hw, 1.0f, s));
-        if (h->G(b.conv0_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.conv0_b), B, cout, s));
-        if (h->G(b.aff_b)) HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.aff_b), B, cout, s));
-        HIP_TRY(launch_affine_bwd(q.dtemb, emb, h->P(b.aff_w), h->G(b.aff_w), demb, B, cout, h->emb_ch, s));
-    }
-    // conv0: its operand is silu(norm0(x)), resampled to the output resolution
-    if (h->G(b.conv0_w)) {
-        HIP_TRY(launch_gn_act(0, a1.p, c1, a2.p, c2, w.ab0, q.aop, B, res, rm, s));
-        if ((rc = wgrad_checked(q.aop, q.dh0, h->G(b.conv0_w), B, res, cin, cout, 3, 1, q.wg, q.wg_bytes, s))) return rc;
-    }
-    if ((rc = conv_dgrad(h, h->P(b.conv0_w), cout, cin, 3, q.dh0, q.da, B, res, q, s))) return rc;
-    // skip path: its gradient joins dx_in inside the norm0 backward pass (both live at the output resolution)
-    const void* add = gout;
-    int ca = cout;
-    float add_scale = sg;
-    if (b.has_skip) {
-        if (h->G(b.skip_w)) {
-            HIP_TRY(launch_gn_act(2, a1.p, c1, a2.p, c2, nullptr, q.aop, B, res, rm, s));
-            if ((rc = wgrad_checked(q.aop, gout, h->G(b.skip_w), B, res, cin, cout, 1, 1, q.wg, q.wg_bytes, s, sg))) return rc;
-        }
-        if ((rc = conv_dgrad(h, h->P(b.skip_w), cout, cin, 1, gout, q.dskip, B, res, q, s, true, sg))) return rc;
-        add = q.dskip;
-        ca = cp;
-        add_scale = 1.0f;
-    }
-    HIP_TRY(launch_gn_bwd(0, a1.p, c1, a2.p, c2, q.da, cp, w.ab0, q.mr0, h->P(b.norm0_w), q.P, q.S, h->G(b.norm0_w), h->G(b.norm0_b),
-                          add, ca, add_scale, dxin, B, res_in, rm, s, dxin2, dx_accumulate));
-    return FG_OK;
-}
-
-// ---- whole network: forward keeping every block input, then the blocks in reverse ----------------------------------------------
-struct NetBwd {
-    TrainStash ts;
-    std::vector<void*> genc;      // gradient w.r.t. each encoder output (bf16)
-    void *ga, *gb;                // running gradient, ping-pong
-    void *dfp, *op32;             // padded head gradient [npix][128], padded stem operand [npix][32]
-    float *wtmp, *wpad, *vec;     // padded weight-gradient / weight scratch, small vector scratch
-    float *demb, *pre, *d1, *d0;  // embedding MLP
-    float *dtemb_all, *vec_all;   // [B][temb_total] pixel sums of every block's dh0, and their batch sum
-    void* wgx;                    // split-K scratch of the head / stem weight gradients
-    size_t wgx_bytes;
-    BwdScratch q;
-};
-size_t plan_net_bwd(const fg_edm* h, int B, Arena& A, NetBwd& nb) {
-    const size_t tsz = 2;
-    size_t max_act = 0, max_in = 0;
-    int max_res = 0, max_cin = 0, attn_hw = 0;
-    size_t wg_max = 0;
-    const size_t st_elems = (size_t)B * 8 * 64;
-    nb.ts.dec_store.clear();
-    nb.ts.blocks.clear();
-    nb.genc.clear();
-    nb.ts.aux_ab = A.get<float2>((size_t)B * 256);
-    nb.ts.aux_mr = A.get<float2>((size_t)B * 32);
-    for (const Block* b : h->blocks) {
-        const size_t np = (size_t)B * b->res_out * b->res_out;
-        BlockStash st;
-        st.h = A.take(np * b->cout * tsz);
-        st.ab0 = A.get<float2>((size_t)B * b->cin);
-        st.ab1 = A.get<float2>((size_t)B * b->cout);
-        st.mr0 = A.get<float2>((size_t)B * 32);
-        st.mr1 = A.get<float2>((size_t)B * 32);
-        if (b->attn) {
-            st.ab2 = A.get<float2>((size_t)B * b->cout);
-            st.mr2 = A.get<float2>((size_t)B * 32);
-            st.xattn = A.take(np * b->cout * tsz);
-            st.q = A.take(np * b->cout * tsz);
-            st.k = A.take(np * b->cout * tsz);
-            st.vt = A.take(np * b->cout * tsz);
-            st.aout = A.take(np * b->cout * tsz);
-        }
-        nb.ts.blocks.push_back(st);
-    }
-    for (const Block& b : h->enc) {
-        nb.genc.push_back(A.take((size_t)B * b.res_out * b.res_out * b.cout * tsz));
-        max_act = std::max(max_act, (size_t)b.res_out * b.res_out * b.cout);
-    }
-    for (const Block& b : h->dec) {
-        if (b.kind != K_BLOCK) continue;
-        Act a;
-        a.p = A.take((size_t)B * b.res_out * b.res_out * b.cout * tsz);
-        a.st = A.get<float2>(st_elems);
-        nb.ts.dec_store.push_back(a);
-    }
-    for (const Block* b : h->blocks) {
-        max_act = std::max(max_act, (size_t)b->res_out * b->res_out * b->cout);
-        max_in = std::max(max_in, (size_t)b->res_in * b->res_in * b->cin);
-        max_res = std::max(max_res, std::max(b->res_in, b->res_out));
-        max_cin = std::max(max_cin, b->cin);
-        if (b->attn) attn_hw = std::max(attn_hw, b->res_out * b->res_out);
-        wg_max = std::max(wg_max, block_wgrad_bytes(B, b->res_out, b->cin, b->cout, b->attn));
-    }
-    nb.ga = A.take((size_t)B * std::max(max_act, max_in) * tsz);
-    nb.gb = A.take((size_t)B * std::max(max_act, max_in) * tsz);
-    const size_t npix = (size_t)B * h->cfg.img_resolution * h->cfg.img_resolution;
-    nb.dfp = A.take(npix * 128 * tsz);
-    nb.op32 = A.take(npix * 32 * tsz);
-    nb.wtmp = A.get<float>((size_t)128 * 256 * 9);
-    nb.wpad = A.get<float>((size_t)256 * 256 * 9);  // head weights padded to 128 (backward) / 256 (forward-mode) output rows
-    nb.vec = A.get<float>(1024);
-    nb.demb = A.get<float>((size_t)B * h->emb_ch);
-    nb.pre = A.get<float>((size_t)B * h->emb_ch);
-    nb.d1 = A.get<float>((size_t)B * h->emb_ch);
-    nb.d0 = A.get<float>((size_t)B * std::max(h->cond_ch, h->emb_ch));
-    nb.dtemb_all = A.get<float>((size_t)B * h->temb_total);
-    nb.vec_all = A.get<float>((size_t)h->temb_total);
-    nb.wgx_bytes = std::max(conv_wgrad_workspace_bytes(B, h->cfg.img_resolution, 256, 128, 3),
-                            conv_wgrad_workspace_bytes(B, h->cfg.img_resolution, 32, 128, 3));
-    nb.wgx = A.take(nb.wgx_bytes);
-    plan_block_bwd(B, max_res, max_res, max_cin, 256, A, nb.q, attn_hw, wg_max);
-    return A.off;
-}
-
-// dout == nullptr: only the encoder is differentiated (the forward returned the feature taps early); dfeats[tap] (nullable, NCHW
-// fp32) joins the gradient of that tap's encoder output; dx_t (nullable) receives the gradient of the network input.
-int run_backward(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* dout, float* out,
-                 int B, Workspace& w, NetBwd& nb, hipStream_t s, bool have_forward, const float* const* dfeats = nullptr,
-                 float* dx_t = nullptr) {
-    const fg_edm_config& c = h->cfg;
-    const int res = c.img_resolution, hw = res * res;
-    const size_t npix = (size_t)B * hw;
-    BwdScratch& q = nb.q;
-    int rc = FG_OK;
-    const bool early = dout == nullptr;
-    if (!have_forward && (rc = run_forward(h, x_t, t, 1, r, 1, labels, out, B, w, s, nullptr, early, &nb.ts))) return rc;
-    const Block *aux_norm = nullptr, *aux_conv = nullptr;
-    for (const Block& b : h->dec) {
-        if (b.kind == K_AUX_NORM) aux_norm = &b;
-        if (b.kind == K_AUX_CONV) aux_conv = &b;
-    }
-    if (!aux_norm || !aux_conv || aux_conv->cin != 256 || aux_conv->cout > 8 || h->enc[0].cout != 128 || h->enc[0].cin > 8)
-        return fail(FG_EINVAL, "backward: head / stem shape not covered (needs model_channels 128, 256-channel head)");
-    const Act none;
-    if (early) {
-        // nothing downstream of the encoder: the gradients start at the feature taps
-        for (size_t i = 0; i < h->enc.size(); ++i)
-            HIP_TRY(hipMemsetAsync(nb.genc[i], 0, (size_t)B * h->enc[i].res_out * h->enc[i].res_out * h->enc[i].cout * 2, s));
-        HIP_TRY(hipMemsetAsync(nb.dtemb_all, 0, sizeof(float) * (size_t)B * h->temb_total, s));  // decoder blocks contribute nothing
-    } else {
-    // ---- output head: F = aux_conv(silu(aux_norm(y))), out = c_skip x + c_out F ------------------------------------------------
-    const Act& y = nb.ts.dec_store.back();
-    w.ab0 = nb.ts.aux_ab;  // aux_norm's coefficients and {mean, rstd} were left there by the kept forward
-    q.mr0 = nb.ts.aux_mr;
-    HIP_TRY(launch_head_grad(dout, w.coef + 3 * (size_t)B, nb.dfp, B, aux_conv->cout, 128, hw, s));
-    if (h->G(aux_conv->b)) {
-        HIP_TRY(launch_colsum(nb.dfp, 128, 8, q.dtemb, B, hw, 1.0f, s));
-        HIP_TRY(hipMemsetAsync(nb.vec, 0, sizeof(float) * 8, s));
-        HIP_TRY(launch_batchsum_add(q.dtemb, nb.vec, B, 8, s));
-        HIP_TRY(launch_add_sub_tensor(nb.vec, 8, h->G(aux_conv->b), 1, aux_conv->cout, 1, s));
-    }
-    if (h->G(aux_conv->w)) {
-        HIP_TRY(launch_gn_act(0, y.p, 256, nullptr, 0, w.ab0, q.aop, B, res, 0, s));
-        if ((rc = wgrad_checked(q.aop, nb.dfp, nb.wtmp, B, res, 256, 128, 3, 0, nb.wgx, nb.wgx_bytes, s))) return rc;
-        HIP_TRY(launch_add_sub_tensor(nb.wtmp, 256, h->G(aux_conv->w), aux_conv->cout, 256, 9, s));
-    }
-    HIP_TRY(launch_pad_rows(h->P(aux_conv->w), nb.wpad, aux_conv->cout, 128, 256 * 9, s));
-    if ((rc = conv_dgrad(h, nb.wpad, 128, 256, 3, nb.dfp, q.da, B, res, q, s, false))) return rc;
-    void* g_cur = nb.ga;
-    void* g_alt = nb.gb;
-    HIP_TRY(launch_gn_bwd(0, y.p, 256, nullptr, 0, q.da, 256, w.ab0, q.mr0, h->P(aux_norm->w), q.P, q.S, h->G(aux_norm->w),
-                          h->G(aux_norm->b), nullptr, 0, 0.f, g_cur, B, res, 0, s));
-    // ---- decoder blocks in reverse ---------------------------------------------------------------------------------------
-    struct Rec {
-        const Block* b;
-        const Act* x;
-        const Act* x2;
-        int sk;
-    };
-    std::vector<Rec> recs;
-    {
-        int sp = (int)h->enc.size();
-        const Act* x = &w.skip.back();
-        size_t di = 0;
-        for (const Block& b : h->dec) {
-            if (b.kind != K_BLOCK) continue;
-            Rec rcd{&b, x, nullptr, -1};
-            if (b.skip_c) {
-                rcd.sk = --sp;
-                rcd.x2 = &w.skip[rcd.sk];
-            }
-            recs.push_back(rcd);
-            x = &nb.ts.dec_store[di++];
-        }
-    }
-    for (int i = (int)recs.size() - 1; i >= 0; --i) {
-        const Block& b = *recs[i].b;
-        const int c2 = b.skip_c, c1 = b.cin - c2;
-        const size_t npin = (size_t)B * b.res_in * b.res_in;
-        // the x part of the input gradient becomes the next (earlier) block's incoming gradient, the skip part that encoder output's
-        if ((rc = block_backward(h, b, *recs[i].x, c1, c2 ? *recs[i].x2 : none, c2, w.emb, w.temb, g_cur, g_alt, nb.demb, B, w, q, s, nb.dtemb_all,
-                                 &nb.ts.blocks[block_index(h, &b)], c2 ? nb.genc[recs[i].sk] : nullptr, 0)))
-            return rc;
-        (void)npin;
-        std::swap(g_cur, g_alt);
-    }
-    // the decoder's first block read the last encoder output directly
-    {
-        const Block& last = h->enc.back();
-        HIP_TRY(launch_add_bf16(nb.genc.back(), g_cur, (int64_t)B * last.res_out * last.res_out * last.cout, s));
-    }
-    }  // !early
-    // gradients arriving at the feature taps (the encoder's `block3` outputs, EDM/network.py:535-539)
-    if (dfeats)
-        for (size_t i = 0; i < h->enc.size(); ++i) {
-            const Block& b = h->enc[i];
-            if (b.tap >= 0 && dfeats[b.tap]) HIP_TRY(launch_add_nchw_to_nhwc(dfeats[b.tap], nb.genc[i], B, b.cout, b.res_out * b.res_out, s));
-        }
-    // ---- encoder blocks in reverse -------------------------------------------------------------------------------------------
-    for (int i = (int)h->enc.size() - 1; i >= 1; --i) {
-        const Block& b = h->enc[i];
-        // accumulated straight into the previous encoder output's gradient (which already holds the decoder's share)
-        if ((rc = block_backward(h, b, w.skip[i - 1], b.cin, none, 0, w.emb, w.temb, nb.genc[i], nb.genc[i - 1], nb.demb, B, w, q, s, nb.dtemb_all,
-                                 &nb.ts.blocks[block_index(h, &b)], nullptr, 1)))
-            return rc;
-    }
-    // ---- stem: conv(c_in * x_t) ---------------------------------------------------------------------------------------------------
-    {
-        const Block& b = h->enc[0];
-        if (h->G(b.b)) {
-            HIP_TRY(launch_colsum(nb.genc[0], b.cout, b.cout, q.dtemb, B, hw, 1.0f, s));
-            HIP_TRY(launch_batchsum_add(q.dtemb, h->G(b.b), B, b.cout, s));
-        }
-        if (h->G(b.w)) {
-            HIP_TRY(launch_stem_operand(x_t, w.coef, nb.op32, B, b.cin, 32, hw, s));
-            if ((rc = wgrad_checked(nb.op32, nb.genc[0], nb.wtmp, B, res, 32, b.cout, 3, 0, nb.wgx, nb.wgx_bytes, s))) return rc;
-            HIP_TRY(launch_add_sub_tensor(nb.wtmp, 32, h->G(b.w), b.cout, b.cin, 9, s));
-        }
-        if (dx_t) {
-            // d x_t = c_in * conv^T(g, W_stem)  (+ c_skip * dout through precond_output); drop_precond 'input' has c_in = 1
-            if ((rc = conv_dgrad(h, h->P(b.w), b.cout, b.cin, 3, nb.genc[0], q.da, B, res, q, s))) return rc;
-            HIP_TRY(launch_input_grad(q.da, 256, w.coef, w.coef + 2 * (size_t)B, dout, dx_t, B, b.cin, hw, s));
-        }
-    }
-    // ---- all 33 embedding affines at once (stacked as in the forward): biases, weights, and demb = dtemb_all @ aff_w ---------------
-    {
-        const int E = h->emb_ch, TT = h->temb_total;
-        HIP_TRY(hipMemsetAsync(nb.vec_all, 0, sizeof(float) * TT, s));
-        HIP_TRY(launch_batchsum_add(nb.dtemb_all, nb.vec_all, B, TT, s));
-        for (const Block* b : h->blocks) {
-            if (h->G(b->conv0_b)) HIP_TRY(launch_add_sub_tensor(nb.vec_all + b->temb_off, b->cout, h->G(b->conv0_b), 1, b->cout, 1, s));
-            if (h->G(b->aff_b)) HIP_TRY(launch_add_sub_tensor(nb.vec_all + b->temb_off, b->cout, h->G(b->aff_b), 1, b->cout, 1, s));
-            if (h->G(b->aff_w))
-                HIP_TRY(launch_linear_bwd(nb.dtemb_all + b->temb_off, w.emb, nullptr, h->G(b->aff_w), nullptr, nullptr, B, b->cout, E, 1.0f, s, TT));
-        }
-        if (!h->aff_wT) {
-            int rc2 = dev_alloc(h, (void**)&h->aff_wT, sizeof(float) * (size_t)E * TT);
-            if (rc2) return rc2;
-        }
-        if (h->aff_wT_epoch != h->pack_epoch) {
-            HIP_TRY(launch_transpose_f32(h->aff_w, h->aff_wT, TT, E, s));
-            h->aff_wT_epoch = h->pack_epoch;
-        }
-        HIP_TRY(launch_linear(nb.dtemb_all, h->aff_wT, nullptr, nb.demb, B, TT, E, 0, s));
-    }
-    // ---- embedding MLP: emb = silu(L1(silu(L0(emb0)))), emb0 = posemb + map_label(labels sqrt(L))  (:501-521) ------------------
-    {
-        const int E = h->emb_ch, N = h->cond_ch;
-        const int w1 = h->find("model.map_layer1.weight"), b1 = h->find("model.map_layer1.bias");
-        const int w0 = h->find("model.map_layer0.weight"), b0 = h->find("model.map_layer0.bias");
-        HIP_TRY(launch_linear(w.emb1, h->P(w1), h->P(b1), nb.pre, B, E, E, 0, s));
-        HIP_TRY(launch_silu_bwd(nb.demb, nb.pre, nb.d1, B * E, s));
-        HIP_TRY(hipMemsetAsync(nb.d0, 0, sizeof(float) * (size_t)B * E, s));
-        HIP_TRY(launch_linear_bwd(nb.d1, w.emb1, h->P(w1), h->G(w1), h->G(b1), nb.d0, B, E, E, 1.0f, s));
-        HIP_TRY(launch_linear(w.emb0, h->P(w0), h->P(b0), nb.pre, B, N, E, 0, s));
-        HIP_TRY(launch_silu_bwd(nb.d0, nb.pre, nb.d1, B * E, s));
-        HIP_TRY(hipMemsetAsync(nb.d0, 0, sizeof(float) * (size_t)B * N, s));
-        HIP_TRY(launch_linear_bwd(nb.d1, w.emb0, h->P(w0), h->G(w0), h->G(b0), nb.d0, B, E, N, 1.0f, s));
-        if (c.label_dim > 0) {
-            const int wl = h->find("model.map_label.weight"), bl = h->find("model.map_label.bias");
-            HIP_TRY(launch_linear_bwd(nb.d0, labels, nullptr, labels ? h->G(wl) : nullptr, h->G(bl), nullptr, B, N, c.label_dim,
-                                      std::sqrt((float)c.label_dim), s));
-        }
-    }
-    return FG_OK;
-}
-
-// ---- forward mode: tangents of (x_t, t, r) pushed through the network next to the kept forward -----------------
-// conv of a tangent: the forward kernel without prologue or bias on the forward's packed weights
-int tangent_conv(fg_edm* h, int ks, int res_mode, const void* src, int cin, int res_in, int res_out, const void* wpack, int cout,
-                 const float* temb, const void* resid, float scale, void* out, int B, hipStream_t s) {
-    ConvArgs a{};
-    a.src1 = src; a.C1 = cin; a.C2 = 0;
-    a.Hs = a.Ws = res_in; a.H = a.W = res_out; a.B = B;
-    a.wpack = wpack; a.bias = nullptr;
-    a.temb = temb; a.temb_stride = h->temb_total;
-    a.resid = resid; a.scale = scale; a.out = out; a.Cout = cout;
-    HIP_TRY(launch_conv_fused(1, ks, PRO_NONE, res_mode, OUT_NHWC, a, s));
-    return FG_OK;
-}
-
-// tangent of one UNetBlock: xd1 / xd2 are the tangents of its inputs, yd (bf16 [B, res_out^2, cout]) of its output
-int block_jvp(fg_edm* h, const Block& b, const Act& a1, int c1, const void* xd1, const Act& a2, int c2, const void* xd2,
-              const float* dtemb, void* yd, int B, Workspace& w, BwdScratch& q, const BlockStash& st, const float2* ident_ab,
-              hipStream_t s) {
-    const int res = b.res_out, res_in = b.res_in, hw = res * res, cin = b.cin, cout = b.cout;
-    const int rm = b.down ? 1 : (b.up ? 2 : 0);
-    const int res_mode = b.down ? RES_DOWN : (b.up ? RES_UP : RES_NONE);
-    int rc;
-    use_stash(w, st);
-    // tangent of the (virtual) concat as one dense tensor
-    const void* xd = xd1;
-    if (c2) {
-        HIP_TRY(launch_gn_act(2, xd1, c1, xd2, c2, nullptr, q.aop, B, res_in, 0, s));
-        xd = q.aop;
-    }
-    // conv0(silu(norm0(x))) + affine(emb)
-    HIP_TRY(launch_gn_jvp(0, a1.p, c1, c2 ? a2.p : nullptr, c2, xd, st.ab0, st.mr0, q.P, q.S, q.da, B, res_in, s));
-    const void* ad0 = q.da;
-    if (rm) {
-        HIP_TRY(launch_gn_act(2, q.da, cin, nullptr, 0, nullptr, q.dskip, B, res, rm, s));
-        ad0 = q.dskip;
-    }
-    if ((rc = tangent_conv(h, 3, RES_NONE, ad0, cin, res, res, b.p_conv0, cout, dtemb + b.temb_off, nullptr, 1.0f, q.dh0, B, s))) return rc;
-    // silu(norm1(h0))
-    HIP_TRY(launch_gn_jvp(0, st.h, cout, nullptr, 0, q.dh0, st.ab1, st.mr1, q.P, q.S, q.g1, B, res, s));
-    // skip path
-    const void* sd = xd;  // identity skip: same resolution and width
-    if (b.has_skip) {
-        if ((rc = tangent_conv(h, 1, res_mode, xd, cin, res_in, res, b.p_skip, cout, nullptr, nullptr, 1.0f, q.dxin, B, s))) return rc;
-        sd = q.dxin;
-    }
-    void* mid = b.attn ? q.gmid : yd;
-    if ((rc = tangent_conv(h, 3, RES_NONE, q.g1, cout, res, res, b.p_conv1, cout, nullptr, sd, kSkipScale, mid, B, s))) return rc;
-    if (b.attn) {
-        // (proj(attention(qkv(norm2(x_mid)))) + x_mid) * sigma
-        HIP_TRY(launch_gn_jvp(1, st.xattn, cout, nullptr, 0, q.gmid, st.ab2, st.mr2, q.P, q.S, q.da, B, res, s));
-        ConvArgs qa{};
-        qa.src1 = q.da; qa.C1 = cout; qa.Hs = qa.Ws = qa.H = qa.W = res; qa.B = B;
-        qa.ab = ident_ab; qa.wpack = b.p_qkv; qa.bias = nullptr; qa.scale = 1.0f; qa.Cout = 3 * cout;
-        qa.q_out = q.dq; qa.k_out = q.dk; qa.vt_out = q.dvt;
-        HIP_TRY(launch_conv_fused(1, 1, PRO_GN, RES_NONE, OUT_QKV, qa, s));
-        HIP_TRY(launch_attention_jvp(st.q, st.k, st.vt, q.dq, q.dk, q.dvt, q.da, q.att, B, hw, cout, s));
-        if ((rc = tangent_conv(h, 1, RES_NONE, q.da, cout, res, res, b.p_proj, cout, nullptr, q.gmid, kSkipScale, yd, B, s))) return rc;
-    }
-    return FG_OK;
-}
-
-int run_jvp(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* vx, const float* vt,
-            const float* vr, float* out, float* jvp, int B, Workspace& w, NetBwd& nb, hipStream_t s) {
-    const fg_edm_config& c = h->cfg;
-    const int res = c.img_resolution, hw = res * res, C = c.img_channels;
-    BwdScratch& q = nb.q;
-    int rc = run_forward(h, x_t, t, 1, r, 1, labels, out, B, w, s, nullptr, false, &nb.ts);
-    if (rc) return rc;
-    const Block *aux_norm = nullptr, *aux_conv = nullptr;
-    for (const Block& b : h->dec) {
-        if (b.kind == K_AUX_NORM) aux_norm = &b;
-        if (b.kind == K_AUX_CONV) aux_conv = &b;
-    }
-    if (!aux_norm || !aux_conv || aux_conv->cin != 256 || !h->enc[0].p_stem || !q.att)
-        return fail(FG_EINVAL, "jvp: head / stem shape not covered");
-    const int E = h->emb_ch, N = h->cond_ch, TT = h->temb_total;
-    // scratch reuse (nothing of the backward runs here): coefficient tangents, embedding tangents, identity GroupNorm coefficients
-    float* ct = nb.vec_all;                 // [8][B]  (temb_total floats >= 8 B for B <= 1056)
-    if (8 * B > TT) return fail(FG_EINVAL, "jvp: batch too large for the coefficient scratch");
-    float* e0 = nb.d0;                      // [B][N] tangent of emb0, later reused
-    float* dtemb = nb.dtemb_all;            // [B][TT] tangent of the stacked affine outputs
-    float2* ident = (float2*)nb.pre;        // [B][256] {1, 0}: `pre` has B * E floats = B * 256 float2
-    float* ones = nb.vec;                   // [<= 1024]
-    float* zeros = nb.vec + 512;
-    if (B > 512) return fail(FG_EINVAL, "jvp: batch too large for the constant scratch");
-    HIP_TRY(launch_fill_f32(ones, 1.0f, 512, s));
-    HIP_TRY(launch_fill_f32(zeros, 0.0f, 512, s));
-    HIP_TRY(launch_jvp_coef(t, c.r_timestep ? r : nullptr, vt, vr, c.sigma_data, c.sigma_shift, c.drop_precond, ct, B, s));
-    // ---- embedding: emb = silu(L1(silu(L0(emb0)))), temb = A emb + b ------------------------------------------------------------
-    {
-        const int w1 = h->find("model.map_layer1.weight"), b1 = h->find("model.map_layer1.bias");
-        const int w0 = h->find("model.map_layer0.weight"), b0 = h->find("model.map_layer0.bias");
-        HIP_TRY(launch_jvp_embed(w.coef + B, w.coef + 4 * (size_t)B, ct + 2 * (size_t)B, ct + 3 * (size_t)B, h->freqs, e0, B, N, h->noise_ch, s));
-        HIP_TRY(launch_linear(w.emb0, h->P(w0), h->P(b0), nb.d1, B, N, E, 0, s));        // pre-activation of layer 0
-        HIP_TRY(launch_linear(e0, h->P(w0), nullptr, nb.demb, B, N, E, 0, s));             // W0 emb0_dot
-        HIP_TRY(launch_silu_bwd(nb.demb, nb.d1, e0, B * E, s));                            // emb1_dot -> e0 ([B][E] fits: N <= E)
-        HIP_TRY(launch_linear(w.emb1, h->P(w1), h->P(b1), nb.d1, B, E, E, 0, s));        // pre-activation of layer 1
-        HIP_TRY(launch_linear(e0, h->P(w1), nullptr, nb.demb, B, E, E, 0, s));
-        HIP_TRY(launch_silu_bwd(nb.demb, nb.d1, e0, B * E, s));                            // emb_dot
-        HIP_TRY(launch_linear(e0, h->aff_w, nullptr, dtemb, B, E, TT, 0, s));
-    }
-    HIP_TRY(launch_fill_f2(ident, 1.0f, 0.0f, B * 256, s));
-    // ---- stem: conv(c_in x)  ->  conv(c_in vx + dc_in x) --------------------------------------------------------------------
-    float* xin = (float*)q.wg;  // fp32 [B, C, H, W]: the split-K scratch is idle here and far larger
-    HIP_TRY(launch_jvp_input(vx, x_t, ct, ct + B, xin, B, C * hw, s));
-    HIP_TRY(launch_stem(1, xin, ones, h->enc[0].p_stem, zeros, nb.genc[0], nullptr, B, res, h->enc[0].cin, s));
-    const Act none;
-    // ---- encoder -------------------------------------------------------------------------------------------------------------
-    for (size_t i = 1; i < h->enc.size(); ++i) {
-        const Block& b = h->enc[i];
-        if ((rc = block_jvp(h, b, w.skip[i - 1], b.cin, nb.genc[i - 1], none, 0, nullptr, dtemb, nb.genc[i], B, w, q,
-                            nb.ts.blocks[block_index(h, &b)], ident, s)))
-            return rc;
-    }
-    // ---- decoder -------------------------------------------------------------------------------------------------------------
-    const Act* x = &w.skip.back();
-    const void* xd = nb.genc.back();
-    void* pong[2] = {nb.ga, nb.gb};
-    int cur = 0, sp = (int)h->enc.size();
-    size_t di = 0;
-    for (const Block& b : h->dec) {
-        if (b.kind != K_BLOCK) continue;
-        const int c2 = b.skip_c, c1 = b.cin - c2;
-        const Act* x2 = &none;
-        const void* xd2 = nullptr;
-        if (c2) {
-            --sp;
-            x2 = &w.skip[sp];
-            xd2 = nb.genc[sp];
-        }
-        if ((rc = block_jvp(h, b, *x, c1, xd, *x2, c2, xd2, dtemb, pong[cur], B, w, q, nb.ts.blocks[block_index(h, &b)], ident, s)))
-            return rc;
-        x = &nb.ts.dec_store[di++];
-        xd = pong[cur];
-        cur ^= 1;
-    }
-    // ---- head: F = aux_conv(silu(aux_norm(y))), out = c_skip x + c_out F ---------------------------------------------------------
-    HIP_TRY(launch_gn_jvp(0, x->p, 256, nullptr, 0, xd, nb.ts.aux_ab, nb.ts.aux_mr, q.P, q.S, q.da, B, res, s));
-    HIP_TRY(launch_pad_rows(h->P(aux_conv->w), nb.wpad, aux_conv->cout, 256, 256 * 9, s));   // 256 output rows, C real ones
-    HIP_TRY(launch_pack_conv_weights(1, nb.wpad, q.wpk, 256, 256, 3, 0, s));
-    if ((rc = tangent_conv(h, 3, RES_NONE, q.da, 256, res, res, q.wpk, 256, nullptr, nullptr, 1.0f, q.dh0, B, s))) return rc;
-    HIP_TRY(launch_jvp_output(q.dh0, 256, out, x_t, vx, ct, jvp, B, C, hw, s));
-    return FG_OK;
-}
-}  // namespace
-
-int fg_edm_jvp(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* vx, const float* vt,
-               const float* vr, float* out, float* jvp, int batch, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!h || !x_t || !t || !vx || !out || !jvp) return fail(FG_EINVAL, "null argument");
-    if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
-    if (!h->dtype) return fail(FG_EINVAL, "the forward-mode pass runs in the bf16 compute mode only");
-    if (h->cfg.r_timestep && !r) return fail(FG_EINVAL, "r is required by an r_timestep network");
-    if (batch <= 0 || !workspace || (((uintptr_t)workspace) & 255)) return fail(FG_EINVAL, "bad batch / workspace");
-    Arena A;
-    A.base = (char*)workspace;
-    Workspace w;
-    plan_workspace(h, batch, A, w);
-    NetBwd nb;
-    const size_t need = plan_net_bwd(h, batch, A, nb);
-    if (need > workspace_bytes) return fail(FG_ENOMEM, "workspace too small: need %zu bytes for batch %d, got %zu", need, batch, workspace_bytes);
-    return run_jvp(h, x_t, t, r, labels, vx, vt, vr, out, jvp, batch, w, nb, (hipStream_t)stream);
-}
-
-size_t fg_edm_backward_workspace_bytes(const fg_edm* h, int batch) {
-    if (!h || batch <= 0) return 0;
-    Arena A;
-    A.dry = true;
-    Workspace w;
-    plan_workspace(h, batch, A, w);
-    NetBwd nb;
-    return plan_net_bwd(h, batch, A, nb);
-}
-
-int fg_edm_forward_train(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, float* out,
-                         float* const* features, int batch, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!h || !x_t || !t || (!out && !features)) return fail(FG_EINVAL, "null argument");
-    if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
-    if (!h->dtype) return fail(FG_EINVAL, "the backward pass runs in the bf16 compute mode only");
-    if (features)
-        for (const Block& b : h->enc)
-            if (b.tap >= 0 && features[b.tap] && ((b.cout % 32) || ((b.res_out * b.res_out) % 32)))
-                return fail(FG_EINVAL, "feature tap %d: channels and pixels must be multiples of 32", b.tap);
-    if (h->cfg.r_timestep && !r) return fail(FG_EINVAL, "r is required by an r_timestep network");
-    if (batch <= 0 || !workspace || (((uintptr_t)workspace) & 255)) return fail(FG_EINVAL, "bad batch / workspace");
-    Arena A;
-    A.base = (char*)workspace;
-    Workspace w;
-    plan_workspace(h, batch, A, w);
-    NetBwd nb;
-    const size_t need = plan_net_bwd(h, batch, A, nb);
-    if (need > workspace_bytes) return fail(FG_ENOMEM, "workspace too small: need %zu bytes for batch %d, got %zu", need, batch, workspace_bytes);
-    return run_forward(h, x_t, t, 1, r, 1, labels, out, batch, w, (hipStream_t)stream, features, out == nullptr, &nb.ts);
-}
-
-int fg_edm_backward(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* dout,
-                    float* out, int have_forward, int batch, void* workspace, size_t workspace_bytes, void* stream) {
-    return fg_edm_backward_ex(h, x_t, t, r, labels, dout, nullptr, out, nullptr, have_forward, batch, workspace, workspace_bytes, stream);
-}
-
-int fg_edm_backward_ex(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* dout,
-                       const float* const* dfeatures, float* out, float* dx_t, int have_forward, int batch, void* workspace,
-                       size_t workspace_bytes, void* stream) {
-    if (!h || !x_t || !t || (!dout && !dfeatures)) return fail(FG_EINVAL, "null argument");
-    if (dout && !out && !have_forward) return fail(FG_EINVAL, "out is required when the forward runs here");
-    if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
-    if (!h->dtype) return fail(FG_EINVAL, "the backward pass runs in the bf16 compute mode only");
-    if (h->cfg.r_timestep && !r) return fail(FG_EINVAL, "r is required by an r_timestep network");
-    if (batch <= 0 || !workspace || (((uintptr_t)workspace) & 255)) return fail(FG_EINVAL, "bad batch / workspace");
-    Arena A;
-    A.base = (char*)workspace;
-    Workspace w;
-    plan_workspace(h, batch, A, w);
-    NetBwd nb;
-    const size_t need = plan_net_bwd(h, batch, A, nb);
-    if (need > workspace_bytes) return fail(FG_ENOMEM, "workspace too small: need %zu bytes for batch %d, got %zu", need, batch, workspace_bytes);
-    return run_backward(h, x_t, t, r, labels, dout, out, batch, w, nb, (hipStream_t)stream, have_forward != 0, dfeatures, dx_t);
-}
-
-int fg_edm_bind_grad(fg_edm* h, const char* name, float* grad, int64_t numel) {
-    if (!h || !name) return fail(FG_EINVAL, "null argument");
-    const int i = h->find(name);
-    if (i < 0) return fail(FG_EINVAL, "unknown parameter '%s'", name);
-    if (grad && numel != h->params[i].numel) return fail(FG_EINVAL, "%s: expected %lld gradient elements, got %lld", name, (long long)h->params[i].numel, (long long)numel);
-    h->params[i].grad = grad;
-    return FG_OK;
-}
-
-size_t fg_edm_block_backward_workspace_bytes(const fg_edm* h, int index, int batch) {
-    if (!h || batch <= 0 || index < 0 || index >= (int)h->blocks.size()) return 0;
-    const Block& b = *h->blocks[index];
-    Arena A;
-    A.dry = true;
-    Workspace w;
-    plan_workspace(h, batch, A, w);
-    BwdScratch q;
-    plan_block_bwd(batch, b.res_in, b.res_out, b.cin, b.cout, A, q, b.attn ? b.res_out * b.res_out : 0);
-    A.take((size_t)batch * b.res_out * b.res_out * b.cout * 2);  // gout in bf16
-    return A.off;
-}
-
-int fg_edm_run_block_backward(fg_edm* h, int index, const float* x1, int c1, const float* x2, int c2, const float* emb,
-                              const float* dout, float* dx1, float* dx2, float* demb, int batch, void* workspace,
-                              size_t workspace_bytes, void* stream) {
-    if (!h || !x1 || !emb || !dout) return fail(FG_EINVAL, "null argument");
-    if (!h->packed) return fail(FG_ENOTREADY, "weights are not packed (call fg_edm_pack_weights)");
-    if (!h->dtype) return fail(FG_EINVAL, "the backward pass runs in the bf16 compute mode only");
-    if (index < 0 || index >= (int)h->blocks.size()) return fail(FG_EINVAL, "block index out of range");
-    const Block& b = *h->blocks[index];
-    if (c1 + c2 != b.cin || (c1 % 8) || (c2 % 8)) return fail(FG_EINVAL, "%s: bad input channel split %d+%d", b.key.c_str(), c1, c2);
-    if (batch <= 0 || !workspace || (((uintptr_t)workspace) & 255)) return fail(FG_EINVAL, "bad batch / workspace");
-    const int B = batch;
-    Arena A;
-    A.base = (char*)workspace;
-    Workspace w;
-    plan_workspace(h, B, A, w);
-    BwdScratch q;
-    plan_block_bwd(B, b.res_in, b.res_out, b.cin, b.cout, A, q, b.attn ? b.res_out * b.res_out : 0);
-    const size_t npix = (size_t)B * b.res_out * b.res_out, npix_in = (size_t)B * b.res_in * b.res_in;
-    void* gout = A.take(npix * b.cout * 2);
-    if (A.off > workspace_bytes) return fail(FG_ENOMEM, "workspace too small: need %zu bytes, got %zu", A.off, workspace_bytes);
-    hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(launch_linear(emb, h->aff_w, h->aff_b, w.temb, B, h->emb_ch, h->temb_total, 0, s));
-    Act a1, a2;
-    HIP_TRY(launch_to_act(1, x1, w.cvt1, (int64_t)npix_in * c1, s));
-    a1.p = w.cvt1;
-    if (c2) {
-        HIP_TRY(launch_to_act(1, x2, w.cvt2, (int64_t)npix_in * c2, s));
-        a2.p = w.cvt2;
-    }
-    HIP_TRY(launch_scale_to_bf16(dout, gout, 1.0f, (int64_t)npix * b.cout, s));
-    int rc = block_backward(h, b, a1, c1, a2, c2, emb, w.temb, gout, q.dxin, demb, B, w, q, s);
-    if (rc) return rc;
-    if (dx1) HIP_TRY(launch_slice_to_f32(q.dxin, b.cin, 0, dx1, c1, (int64_t)npix_in, s));
-    if (dx2 && c2) HIP_TRY(launch_slice_to_f32(q.dxin, b.cin, c1, dx2, c2, (int64_t)npix_in, s));
-    return FG_OK;
-}
+#include "engine_train.inc"  // block / network backward, forward-mode pass and their entry points
 
 int fg_op_gn_coeffs(const float* x1, int c1, const float* x2, int c2, const float* gamma, const float* beta, float eps,
                     float* ab_out, int batch, int hw, void* stream) {
