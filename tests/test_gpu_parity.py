@@ -1037,3 +1037,34 @@ def test_trigflow_wrapper_jvp_on_the_hip_network(nets, golden_dir):
     assert float((F2.cpu() - fx["wrap/F"]).norm() / fx["wrap/F"].norm()) <= 1e-2
     rel = float((dF.cpu() - fx["wrap/dF"]).norm() / fx["wrap/dF"].norm())
     assert rel <= 3e-2, rel
+
+
+def test_network_jvp_properties_at_training_batch(nets):
+    """Size-independent properties of the forward-mode pass at a training batch (B = 64): zero tangents give exactly zero (no
+    stray additive term: biases and the label embedding carry no tangent), the derivative is linear in the tangents, the primal
+    it returns is the ordinary forward, and a finite difference of the forward agrees with it in direction."""
+    net = nets["bf16"]
+    B = 64
+    g = torch.Generator().manual_seed(3)
+    t = (torch.rand(B, generator=g, dtype=torch.float64) * 20 + 0.5).to(dev())
+    x = (torch.randn((B, 3, 32, 32), generator=g)).to(dev()) * t.reshape(B, 1, 1, 1).float()
+    cond = torch.nn.functional.one_hot(torch.arange(B) % 10, 10).float().to(dev())
+    vx = torch.randn((B, 3, 32, 32), generator=g).to(dev())
+    vt = torch.randn(B, generator=g).to(dev()) * 0.1
+    out0, z = net.jvp(x, t, torch.zeros_like(vx), torch.zeros_like(vt), condition=cond)
+    assert float(z.abs().max()) == 0.0
+    with torch.no_grad():
+        assert torch.equal(out0, net(x, t, condition=cond))
+    _, j1 = net.jvp(x, t, vx, vt, condition=cond)
+    _, j2 = net.jvp(x, t, 2 * vx, 2 * vt, condition=cond)
+    assert float((j2 - 2 * j1).norm() / (2 * j1).norm()) <= 1e-2   # exact up to bf16 rounding of the scaled tangents
+    _, jx = net.jvp(x, t, vx, torch.zeros_like(vt), condition=cond)
+    _, jt = net.jvp(x, t, torch.zeros_like(vx), vt, condition=cond)
+    assert float((jx + jt - j1).norm() / j1.norm()) <= 2e-2
+    # central finite difference of the fp32-mode forward (coarse: checks direction and scale, not digits)
+    e = 1e-2
+    with torch.no_grad():
+        f = nets["fp32"]
+        fd = (f(x + e * vx, t + e * vt.double(), condition=cond) - f(x - e * vx, t - e * vt.double(), condition=cond)) / (2 * e)
+    cos = float((fd * j1).sum() / (fd.norm() * j1.norm()))
+    assert cos >= 0.99 and abs(float(fd.norm() / j1.norm()) - 1) <= 5e-2, (cos, float(fd.norm() / j1.norm()))
