@@ -17,7 +17,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void aux_head_kernel(const T* __restrict__ x, const float2* __restrict__ ab,
                                                        const T* __restrict__ wpack, const float* __restrict__ bias,
                                                        const float* __restrict__ x_t, const float* __restrict__ coef,
-                                                       float* __restrict__ out, int B, int C, int cout) {
+                                                       float* __restrict__ out, float* __restrict__ raw, int B, int C, int cout) {
     constexpr int KC = DT<T>::KC, KK = KC / 16, OPP = KC / 8;
     constexpr bool FAST = DT<T>::FAST;
     constexpr int LOG_OPP = (OPP == 8) ? 3 : 2;
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void aux_head_kernel(const T* __restrict__ x, 
         for (int i = 0; i < 16; ++i) {
             const size_t o = (((size_t)n * cout + r) * 32 + y) * 32 + acc_row(i, h);
             out[o] = c_skip * x_t[o] + c_out * (acc[i] + bv);
+            if (raw) raw[o] = acc[i] + bv;  // the network's own output F, kept for the forward-mode pass
         }
     }
 }
@@ -209,11 +210,11 @@ int launch_pack_aux_weights(int dtype, const float* w, void* out, int C, int cou
 int aux_head_supported(int dtype, int res, int C, int cout) { return res == 32 && C % (dtype ? 64 : 32) == 0 && cout <= 32; }
 
 int launch_aux_head(int dtype, const void* x, const float2* ab, const void* wpack, const float* bias, const float* x_t,
-                    const float* coef, float* out, int B, int C, int cout, hipStream_t s) {
+                    const float* coef, float* out, int B, int C, int cout, hipStream_t s, float* raw) {
     if (dtype)
-        hipLaunchKernelGGL(aux_head_kernel<__bf16>, dim3(B * 8), dim3(256), 0, s, (const __bf16*)x, ab, (const __bf16*)wpack, bias, x_t, coef, out, B, C, cout);
+        hipLaunchKernelGGL(aux_head_kernel<__bf16>, dim3(B * 8), dim3(256), 0, s, (const __bf16*)x, ab, (const __bf16*)wpack, bias, x_t, coef, out, raw, B, C, cout);
     else
-        hipLaunchKernelGGL(aux_head_kernel<float>, dim3(B * 8), dim3(256), 0, s, (const float*)x, ab, (const float*)wpack, bias, x_t, coef, out, B, C, cout);
+        hipLaunchKernelGGL(aux_head_kernel<float>, dim3(B * 8), dim3(256), 0, s, (const float*)x, ab, (const float*)wpack, bias, x_t, coef, out, raw, B, C, cout);
     return (int)hipGetLastError();
 }
 

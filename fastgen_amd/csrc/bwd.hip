@@ -491,9 +491,9 @@ __global__ void jvp_input_kernel(const float* __restrict__ vx, const float* __re
         out[i] = fmaf(c_in[n], vx[i], dc_in[n] * x[i]);
     }
 }
-// jvp[n][c][p] = c_out Fd + dc_out F + c_skip vx + dc_skip x,  F = (out - c_skip x) / c_out (the network's raw output);
+// jvp[n][c][p] = c_out Fd + dc_out F + c_skip vx + dc_skip x,  F = the network's raw output (kept by the forward that precedes);
 // Fd is NHWC bf16 with channel stride Cf
-__global__ void jvp_output_kernel(const __bf16* __restrict__ fd, int Cf, const float* __restrict__ out, const float* __restrict__ x,
+__global__ void jvp_output_kernel(const __bf16* __restrict__ fd, int Cf, const float* __restrict__ F_raw, const float* __restrict__ x,
                                   const float* __restrict__ vx, const float* __restrict__ ct, float* __restrict__ jvp, int B, int C, int HW,
                                   int64_t total) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -501,8 +501,7 @@ __global__ void jvp_output_kernel(const __bf16* __restrict__ fd, int Cf, const f
         const int c = (int)((i / HW) % C);
         const int64_t n = i / ((int64_t)HW * C);
         const float cs = ct[4 * B + n], dcs = ct[5 * B + n], co = ct[6 * B + n], dco = ct[7 * B + n];
-        const float F = co != 0.f ? (out[i] - cs * x[i]) / co : 0.f;
-        jvp[i] = fmaf(co, (float)fd[(n * HW + p) * Cf + c], dco * F) + fmaf(cs, vx[i], dcs * x[i]);
+        jvp[i] = fmaf(co, (float)fd[(n * HW + p) * Cf + c], dco * F_raw[i]) + fmaf(cs, vx[i], dcs * x[i]);
     }
 }
 __global__ void fill_f32_kernel(float* __restrict__ p, float v, int n) {

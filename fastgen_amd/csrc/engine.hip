@@ -115,6 +115,7 @@ struct TrainStash {
     std::vector<BlockStash> blocks;  // indexed like fg_edm::blocks
     float2* aux_ab = nullptr;        // coefficients of aux_norm
     float2* aux_mr = nullptr;        // its {mean, rstd}
+    float* raw_out = nullptr;        // the network's own output F (before precond_output), [B, C, H, W] fp32
 };
 
 struct GraphKey {
@@ -592,9 +593,9 @@ int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, cons
             aux_ab = w.ab0;
         } else if (b.kind == K_AUX_CONV) {
             if (b.p_aux)
-                HIP_TRY(launch_aux_head(h->dtype, x->p, aux_ab, b.p_aux, h->P(b.b), x_t, w.coef, out, B, b.cin, b.cout, s));
+                HIP_TRY(launch_aux_head(h->dtype, x->p, aux_ab, b.p_aux, h->P(b.b), x_t, w.coef, out, B, b.cin, b.cout, s, ts ? ts->raw_out : nullptr));
             else
-                HIP_TRY(launch_aux_out(h->dtype, x->p, aux_ab, h->P(b.w), h->P(b.b), x_t, w.coef, out, B, b.res_out, b.cin, b.cout, s));
+                HIP_TRY(launch_aux_out(h->dtype, x->p, aux_ab, h->P(b.w), h->P(b.b), x_t, w.coef, out, B, b.res_out, b.cin, b.cout, s, ts ? ts->raw_out : nullptr));
         }
     }
     return FG_OK;

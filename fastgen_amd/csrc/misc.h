@@ -17,7 +17,7 @@ int launch_linear(const float* x, const float* w, const float* bias, float* y, i
 int launch_conv_in(int dtype, const float* x, const float* c_in, const float* w, const float* bias, void* out, int B,
                    int res, int cin, int cout, hipStream_t s);
 int launch_aux_out(int dtype, const void* x, const float2* ab, const float* w, const float* bias, const float* x_t,
-                   const float* coef, float* out, int B, int res, int C, int cout, hipStream_t s);
+                   const float* coef, float* out, int B, int res, int C, int cout, hipStream_t s, float* raw = nullptr);
 int launch_latents(const float* noise, double tv, const double* tp, int ti, float* out, int64_t total, hipStream_t s);
 int launch_forward_process(const float* x0, const float* eps, double tv, const double* tp, int ti, int sched, float* out,
                            int64_t total, hipStream_t s);
@@ -98,7 +98,7 @@ size_t aux_pack_elems(int C);
 int launch_pack_aux_weights(int dtype, const float* w, void* out, int C, int cout, hipStream_t s);
 int aux_head_supported(int dtype, int res, int C, int cout);
 int launch_aux_head(int dtype, const void* x, const float2* ab, const void* wpack, const float* bias, const float* x_t,
-                    const float* coef, float* out, int B, int C, int cout, hipStream_t s);
+                    const float* coef, float* out, int B, int C, int cout, hipStream_t s, float* raw = nullptr);
 
 // MFMA stem conv (aux.hip): conv3x3(c_in * x_t) + bias, img_channels -> 128, NCHW fp32 in, NHWC activations out.
 int stem_supported(int res, int cin, int cout);

@@ -314,7 +314,7 @@ template <bool FAST, typename AT>
 __global__ __launch_bounds__(256) void aux_out_kernel(const AT* __restrict__ x, const float2* __restrict__ ab,
                                                       const float* __restrict__ w, const float* __restrict__ bias,
                                                       const float* __restrict__ x_t, const float* __restrict__ coef,
-                                                      float* __restrict__ out, int B, int res, int C, int cout) {
+                                                      float* __restrict__ out, float* __restrict__ raw, int B, int res, int C, int cout) {
     extern __shared__ float smem_f[];
     float* sw = smem_f;                                               // [9][cout][C]
     float2* sab = reinterpret_cast<float2*>(smem_f + 9 * cout * C);   // [C]
@@ -357,6 +357,7 @@ __global__ __launch_bounds__(256) void aux_out_kernel(const AT* __restrict__ x, 
             for (int co = 0; co < cout; ++co) {
                 const size_t o = (((size_t)n * cout + co) * res + y) * res + px;
                 out[o] = c_skip * x_t[o] + c_out * (acc[co] + bias[co]);
+                if (raw) raw[o] = acc[co] + bias[co];
             }
         }
     }
@@ -596,14 +597,14 @@ int launch_conv_in(int dtype, const float* x, const float* c_in, const float* w,
 }
 
 int launch_aux_out(int dtype, const void* x, const float2* ab, const float* w, const float* bias, const float* x_t,
-                   const float* coef, float* out, int B, int res, int C, int cout, hipStream_t s) {
+                   const float* coef, float* out, int B, int res, int C, int cout, hipStream_t s, float* raw) {
     if (cout > 4 || C % 32) return (int)hipErrorInvalidValue;
     const size_t lds = (size_t)9 * cout * C * sizeof(float) + (size_t)C * sizeof(float2);
     if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
     if (dtype)
-        hipLaunchKernelGGL((aux_out_kernel<true, __bf16>), dim3(B * res), dim3(256), lds, s, (const __bf16*)x, ab, w, bias, x_t, coef, out, B, res, C, cout);
+        hipLaunchKernelGGL((aux_out_kernel<true, __bf16>), dim3(B * res), dim3(256), lds, s, (const __bf16*)x, ab, w, bias, x_t, coef, out, raw, B, res, C, cout);
     else
-        hipLaunchKernelGGL((aux_out_kernel<false, float>), dim3(B * res), dim3(256), lds, s, (const float*)x, ab, w, bias, x_t, coef, out, B, res, C, cout);
+        hipLaunchKernelGGL((aux_out_kernel<false, float>), dim3(B * res), dim3(256), lds, s, (const float*)x, ab, w, bias, x_t, coef, out, raw, B, res, C, cout);
     RET_LAST();
 }
 

@@ -222,8 +222,7 @@ int fg_disc_edm_run(const float* feat, int res, const float* const* params, floa
 /* Forward-mode derivative (`torch.func.jvp(net, (x_t, t, r), tangents)` in MeanFlowModel._jvp / sCM,
  * consistency_model/mean_flow.py:240-250, sCM.py:179): out = EDMPrecond.forward(x_t, t, r), jvp = its directional derivative along
  * (vx [B,C,H,W], vt [B], vr [B]) (vt / vr nullable = 0; fp32).  bf16 compute mode; workspace sized by
- * fg_edm_backward_workspace_bytes (the pass runs next to the kept forward and reuses its per-block stash); t > 0 for a
- * preconditioned network (the raw output is recovered from out as (out - c_skip x) / c_out). */
+ * fg_edm_backward_workspace_bytes (the pass runs next to the kept forward and reuses its per-block stash). */
 int fg_edm_jvp(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* vx, const float* vt,
                const float* vr, float* out, float* jvp, int batch, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -426,6 +426,13 @@ def jvp_fixture(edm_net):
     oo, oj = edm_ref.edm_precond_jvp(sd, cfg, x, t, cond, v, vt)
     assert torch.allclose(oo, out, rtol=1e-4, atol=1e-5) and torch.allclose(oj, jv, rtol=1e-3, atol=1e-4 * float(jv.abs().max()))
     fx.update({"edm/out": out.clone(), "edm/jvp": jv.clone(), "edm/t": t, "edm/vt": vt, "edm/cond": cond})
+    # near the data end, where c_out -> 0 (the raw network output must not be recovered by dividing by it)
+    t = torch.tensor([0.004, 0.05])
+    vt = torch.tensor([0.001, -0.01])
+    x = seeded((2, 3, 32, 32), 73) * 0.5
+    with torch.no_grad():
+        out, jv = torch.func.jvp(lambda a, b: net(a, b, condition=cond, fwd_pred_type="x0"), (x, t), (v, vt))
+    fx.update({"edm_small/out": out.clone(), "edm_small/jvp": jv.clone(), "edm_small/t": t, "edm_small/vt": vt})
     torch.save(fx, os.path.join(OUT, "jvp_b2.pt"))
 
 

@@ -1016,6 +1016,13 @@ def test_network_jvp_against_reference_func_jvp(nets, mf_nets, golden_dir):
     check(out, fx["edm/out"], "bf16", "EDM jvp primal")
     rel = float((jv.cpu() - fx["edm/jvp"]).norm() / fx["edm/jvp"].norm())
     assert rel <= 3e-2, rel
+    # near the data end (c_out -> 0)
+    t = fx["edm_small/t"]
+    xs = (seeded((2, 3, 32, 32), 73) * 0.5).to(dev())
+    out, jv = nets["bf16"].jvp(xs, t.to(dev()), v, fx["edm_small/vt"].to(dev()), condition=fx["edm/cond"].to(dev()))
+    check(out, fx["edm_small/out"], "bf16", "EDM jvp primal, small t")
+    rel = float((jv.cpu() - fx["edm_small/jvp"]).norm() / fx["edm_small/jvp"].norm())
+    assert rel <= 3e-2, rel
     with pytest.raises(NotImplementedError):
         nets["fp32"].jvp(x, t.to(dev()), v)
 
