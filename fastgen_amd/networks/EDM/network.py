@@ -334,7 +334,7 @@ class EDMPrecond(FastGenNetwork):
         return torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
                                             or (x_t is not None and x_t.requires_grad))
 
-    def _check_trainable_call(self, return_logvar):
+    def _check_trainable_call(self, return_logvar=False):
         """Autograd through the module (fg_edm_backward_ex): gradients of the prediction and of the feature taps with respect to
         the parameters and to x_t, in the bf16 compute mode - what the DMD2 student / fake-score updates and its GAN branch need
         (dmd2.py).  Everything else raises."""
@@ -342,8 +342,8 @@ class EDMPrecond(FastGenNetwork):
             raise NotImplementedError(
                 "fastgen_amd.EDMPrecond: the backward pass runs in the bf16 compute mode only - call under "
                 "torch.autocast('cuda', dtype=torch.bfloat16) (or compute_dtype='bf16'), or under torch.no_grad() for inference")
-        if return_logvar:
-            raise NotImplementedError("fastgen_amd.EDMPrecond: logvar is forward-only (call under torch.no_grad())")
+        # return_logvar needs no special handling: logvar_linear(posemb(c_noise)) is a [B, 128] x [128, 1] product evaluated with
+        # torch on the module's own parameters (host-side plumbing) and differentiates through ordinary autograd
 
     def _labels(self, condition, batch: int, device) -> Optional[torch.Tensor]:
         if isinstance(condition, dict) and "aug_condition" in condition:

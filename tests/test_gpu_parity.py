@@ -768,6 +768,12 @@ def test_module_autograd_through_the_hip_backward(nets, golden_dir):
         assert torch.isfinite(params["model.enc.16x16_block1.conv1.weight"].grad).all()
         with pytest.raises(NotImplementedError):
             nets["fp32"](x, t, condition=cond)  # the backward pass exists in the bf16 mode only
+        # the uncertainty head used by the sCM-family losses trains alongside (return_logvar under autograd)
+        net.zero_grad(set_to_none=True)
+        o, lv = net(x, t, condition=cond, fwd_pred_type="x0", return_logvar=True)
+        assert lv.shape == (2, 1) and lv.requires_grad
+        ((o * dout).sum() + lv.sum()).backward()
+        assert float(params["model.logvar_linear.weight"].grad.abs().max()) > 0
         # a conversion after the network stays differentiable (eps prediction from the x0 network)
         net.zero_grad(set_to_none=True)
         net(x, t, condition=cond, fwd_pred_type="eps").square().mean().backward()
