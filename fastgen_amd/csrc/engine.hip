@@ -149,6 +149,7 @@ struct fg_edm {
     };
     std::map<const float*, DgradW> dgrad_cache;
     uint64_t pack_epoch = 0;
+    const float* augment = nullptr;  // [B][augment_dim] augmentation labels of the next calls (fg_edm_set_augment), or none
     float* aff_wT = nullptr;  // [emb_ch][temb_total]: the stacked affine matrix transposed, for the batched embedding gradient
     uint64_t aff_wT_epoch = 0;
     // owned device memory
@@ -526,7 +527,7 @@ int run_mapping(fg_edm* h, const float* labels, int B, Workspace& w, hipStream_t
     const fg_edm_config& c = h->cfg;
     HIP_TRY(launch_mapping_in(w.coef + B, w.coef + 4 * (size_t)B, h->freqs, labels, c.label_dim,
                               h->P(h->find("model.map_label.weight")), h->P(h->find("model.map_label.bias")), w.emb0, B,
-                              h->cond_ch, h->noise_ch, s));
+                              h->cond_ch, h->noise_ch, s, h->augment, h->augment ? h->P(h->find("model.map_augment.weight")) : nullptr, c.augment_dim));
     HIP_TRY(launch_linear(w.emb0, h->P(h->find("model.map_layer0.weight")), h->P(h->find("model.map_layer0.bias")), w.emb1,
                           B, h->cond_ch, h->emb_ch, 1, s));
     HIP_TRY(launch_linear(w.emb1, h->P(h->find("model.map_layer1.weight")), h->P(h->find("model.map_layer1.bias")), w.emb, B,
@@ -792,7 +793,7 @@ int fg_edm_pack_weights(fg_edm* h, void* stream) {
     int rc0 = ensure_device_state(h);
     if (rc0) return rc0;
     for (const Param& p : h->params) {
-        const bool unused = p.name == "model.map_augment.weight" || p.name.rfind("model.logvar_linear", 0) == 0;
+        const bool unused = (p.name == "model.map_augment.weight" && !h->augment) || p.name.rfind("model.logvar_linear", 0) == 0;
         if (!p.ptr && !unused) return fail(FG_ENOTREADY, "parameter '%s' is not bound", p.name.c_str());
     }
     ++h->pack_epoch;
@@ -1123,6 +1124,12 @@ int fg_op_forward_process(const float* x0, const float* eps, double t, int sched
 }
 int fg_op_x0_to_eps(const float* xt, const float* x0, double t, int schedule, float* out, int64_t total, void* stream) {
     HIP_TRY(launch_x0_to_eps(xt, x0, t, nullptr, 0, schedule, 1e-6, out, total, (hipStream_t)stream));
+    return FG_OK;
+}
+int fg_edm_set_augment(fg_edm* h, const float* augment_labels) {
+    if (!h) return fail(FG_EINVAL, "null handle");
+    if (augment_labels && h->cfg.augment_dim <= 0) return fail(FG_EINVAL, "this network was built without augment_dim");
+    h->augment = augment_labels;
     return FG_OK;
 }
 int fg_disc_edm_num_params(int res) { return disc_num_params(res); }

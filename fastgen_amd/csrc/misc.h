@@ -11,7 +11,7 @@ int launch_gn_finalize(const float2* st1, int c1, int s1, const float2* st2, int
 int launch_precond_coef(const double* t, int t_stride, const double* r, int r_stride, double sigma_data,
                         double sigma_shift, double clamp_min, int drop, float* coef, int B, hipStream_t s);
 int launch_mapping_in(const float* c_noise, const float* r_noise, const float* freqs, const float* labels, int label_dim,
-                      const float* wl, const float* bl, float* out, int B, int N, int noise_ch, hipStream_t s);
+                      const float* wl, const float* bl, float* out, int B, int N, int noise_ch, hipStream_t s, const float* aug = nullptr, const float* wa = nullptr, int aug_dim = 0);
 int launch_linear(const float* x, const float* w, const float* bias, float* y, int B, int I, int O, int act_silu,
                   hipStream_t s);
 int launch_conv_in(int dtype, const float* x, const float* c_in, const float* w, const float* bias, void* out, int B,

@@ -142,7 +142,7 @@ __global__ void precond_coef_kernel(const double* __restrict__ t, int t_stride, 
 __global__ void mapping_in_kernel(const float* __restrict__ c_noise, const float* __restrict__ r_noise,
                                   const float* __restrict__ freqs, const float* __restrict__ labels, int label_dim,
                                   const float* __restrict__ wl, const float* __restrict__ bl, float* __restrict__ out, int B,
-                                  int N, int noise_ch) {
+                                  int N, int noise_ch, const float* __restrict__ aug, const float* __restrict__ wa, int aug_dim) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * N) return;
     const int b = idx / N, j = idx % N;
@@ -157,6 +157,11 @@ __global__ void mapping_in_kernel(const float* __restrict__ c_noise, const float
         if (labels)
             for (int i = 0; i < label_dim; ++i) acc = fmaf(labels[(size_t)b * label_dim + i] * sc, wl[(size_t)j * label_dim + i], acc);
         v += acc + bl[j];
+    }
+    if (aug) {  // + map_augment(augment_labels), no bias (EDM/network.py:518-519): training-time augmentation pipeline
+        float acc = 0.f;
+        for (int i = 0; i < aug_dim; ++i) acc = fmaf(aug[(size_t)b * aug_dim + i], wa[(size_t)j * aug_dim + i], acc);
+        v += acc;
     }
     out[idx] = v;
 }
@@ -547,9 +552,9 @@ int launch_precond_coef(const double* t, int t_stride, const double* r, int r_st
 }
 
 int launch_mapping_in(const float* c_noise, const float* r_noise, const float* freqs, const float* labels, int label_dim,
-                      const float* wl, const float* bl, float* out, int B, int N, int noise_ch, hipStream_t s) {
+                      const float* wl, const float* bl, float* out, int B, int N, int noise_ch, hipStream_t s, const float* aug, const float* wa, int aug_dim) {
     hipLaunchKernelGGL(mapping_in_kernel, dim3((B * N + 255) / 256), dim3(256), 0, s, c_noise, r_noise, freqs, labels,
-                       label_dim, wl, bl, out, B, N, noise_ch);
+                       label_dim, wl, bl, out, B, N, noise_ch, aug, wa, aug_dim);
     RET_LAST();
 }
 

@@ -73,7 +73,9 @@ class _EDMForwardFn(torch.autograd.Function):
     that autograd accumulates into their .grad and DDP hooks fire, as for the reference module) and x_t."""
 
     @staticmethod
-    def forward(ctx, net, x32, t64, r64, labels, taps, early, *weights):
+    def forward(ctx, net, x32, t64, r64, labels, taps_aug, early, *weights):
+        taps, aug = taps_aug
+        ctx.aug = aug
         dev, B = x32.device, x32.shape[0]
         L = _lib.lib()
         dt, h = net._engine(dev)
@@ -88,12 +90,13 @@ class _EDMForwardFn(torch.autograd.Function):
             f = torch.empty(B, ch.value, res.value, res.value, dtype=torch.float32, device=dev)
             ptrs[i] = f.data_ptr()
             feats.append(f)
-        _lib.check(L.fg_edm_forward_train(
-            h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
-            ctypes.c_void_p(r64.data_ptr() if r64 is not None else None),
-            ctypes.c_void_p(labels.data_ptr() if labels is not None else None),
-            ctypes.c_void_p(out.data_ptr() if out is not None else None), ptrs if taps else None,
-            B, ctypes.c_void_p(ws.data_ptr()), ws.numel(), net._stream(dev)))
+        with net._AugmentScope(h, aug):
+            _lib.check(L.fg_edm_forward_train(
+                h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
+                ctypes.c_void_p(r64.data_ptr() if r64 is not None else None),
+                ctypes.c_void_p(labels.data_ptr() if labels is not None else None),
+                ctypes.c_void_p(out.data_ptr() if out is not None else None), ptrs if taps else None,
+                B, ctypes.c_void_p(ws.data_ptr()), ws.numel(), net._stream(dev)))
         # the training workspace now holds this call's state; any later training forward of the module replaces the token, and
         # the backward of this call then recomputes its forward
         ctx.token = net._train_token = object()
@@ -147,6 +150,8 @@ class _EDMForwardFn(torch.autograd.Function):
             for (n, _), g in zip(named, grads):
                 if g is not None:
                     _lib.check(L.fg_edm_bind_grad(h, n.encode(), ctypes.c_void_p(g.data_ptr()), g.numel()))
+            if ctx.aug is not None:
+                _lib.check(L.fg_edm_set_augment(h, ctypes.c_void_p(ctx.aug.data_ptr())))
             _lib.check(L.fg_edm_backward_ex(
                 h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
                 ctypes.c_void_p(r64.data_ptr() if ctx.has_r else None), ctypes.c_void_p(labels.data_ptr() if ctx.has_labels else None),
@@ -155,6 +160,8 @@ class _EDMForwardFn(torch.autograd.Function):
                 ctypes.c_void_p(dx.data_ptr() if dx is not None else None), have_forward, B,
                 ctypes.c_void_p(ws.data_ptr()), ws.numel(), net._stream(dev)))
         finally:
+            if ctx.aug is not None:
+                _lib.check(L.fg_edm_set_augment(h, None))
             for (n, _), g in zip(named, grads):
                 if g is not None:
                     _lib.check(L.fg_edm_bind_grad(h, n.encode(), None, 0))
@@ -208,6 +215,7 @@ class EDMPrecond(FastGenNetwork):
         cfg = _lib.fg_edm_config()
         cfg.img_resolution, cfg.img_channels, cfg.label_dim = img_resolution, img_channels, label_dim
         cfg.augment_dim = mk.get("augment_dim", 0)
+        self.augment_dim = int(cfg.augment_dim)
         cfg.model_channels = mk.get("model_channels", 128)
         mult = list(mk.get("channel_mult", [1, 2, 2, 2]))
         attn = list(mk.get("attn_resolutions", [16]))
@@ -347,7 +355,7 @@ class EDMPrecond(FastGenNetwork):
 
     def _labels(self, condition, batch: int, device) -> Optional[torch.Tensor]:
         if isinstance(condition, dict) and "aug_condition" in condition:
-            raise NotImplementedError("augmentation labels are a training-time input and are not implemented here")
+            condition = condition.get("orig_condition")  # the augmentation part is taken by _augment()
         if self.label_dim == 0 or condition is None:
             return None  # the library broadcasts map_label(zeros) as the reference does (EDM/network.py:919-925)
         c = condition.reshape(-1, self.label_dim).to(device=device, dtype=torch.float32)
@@ -356,6 +364,34 @@ class EDMPrecond(FastGenNetwork):
         if c.shape[0] != batch:
             raise ValueError(f"condition has {c.shape[0]} rows, expected {batch}")
         return c.contiguous()
+
+    def _augment(self, condition, batch: int, device) -> Optional[torch.Tensor]:
+        """Augmentation labels of a {"aug_condition", "orig_condition"} condition (EDM/network.py:903-915): [B, augment_dim] fp32,
+        or None; a width that does not match map_augment is ignored, as the reference does (with a warning there)."""
+        if not (isinstance(condition, dict) and "aug_condition" in condition):
+            return None
+        aug = condition["aug_condition"]
+        if aug is None or self.augment_dim == 0 or aug.shape[-1] != self.augment_dim:
+            return None
+        a = aug.detach().reshape(-1, self.augment_dim).to(device=device, dtype=torch.float32)
+        if a.shape[0] != batch:
+            raise ValueError(f"aug_condition has {a.shape[0]} rows, expected {batch}")
+        return a.contiguous()
+
+    class _AugmentScope:
+        """fg_edm_set_augment(h, aug) for the duration of one library call."""
+
+        def __init__(self, h, aug):
+            self.h, self.aug = h, aug
+
+        def __enter__(self):
+            if self.aug is not None:
+                _lib.check(_lib.lib().fg_edm_set_augment(self.h, ctypes.c_void_p(self.aug.data_ptr())))
+
+        def __exit__(self, *exc):
+            if self.aug is not None:
+                _lib.check(_lib.lib().fg_edm_set_augment(self.h, None))
+            return False
 
     # ------------------------------------------------------------------------------------------------
     def reset_parameters(self):
@@ -443,6 +479,7 @@ class EDMPrecond(FastGenNetwork):
             if r64.numel() != B:
                 raise ValueError(f"r has {r64.numel()} entries, expected {B}")
         labels = self._labels(condition, B, dev)
+        aug = self._augment(condition, B, dev)
         dt, h = self._engine(dev)
         ws = self._workspace(dt, h, B, dev)
         L = _lib.lib()
@@ -452,7 +489,7 @@ class EDMPrecond(FastGenNetwork):
             taps = tuple(i for i in range(ntap) if i in feature_indices)
             if return_features_early:
                 assert len(taps) == len(feature_indices), f"{len(taps)} != {len(feature_indices)}"
-            res = _EDMForwardFn.apply(self, x32, t64, r64, labels, taps, bool(return_features_early),
+            res = _EDMForwardFn.apply(self, x32, t64, r64, labels, (taps, aug), bool(return_features_early),
                                       *[p_ for _, p_ in self._named_weights()])
             res = list(res)
             out = None if return_features_early else res.pop(0)
@@ -474,7 +511,8 @@ class EDMPrecond(FastGenNetwork):
             if return_features_early:
                 assert len(features) == len(feature_indices), f"{len(features)} != {len(feature_indices)}"
             out = None if return_features_early else torch.empty_like(x32)
-            _lib.check(L.fg_edm_forward_features(
+            with self._AugmentScope(h, aug):
+                _lib.check(L.fg_edm_forward_features(
                 h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
                 ctypes.c_void_p(r64.data_ptr() if r64 is not None else None),
                 ctypes.c_void_p(labels.data_ptr() if labels is not None else None),
@@ -485,11 +523,12 @@ class EDMPrecond(FastGenNetwork):
                 return features
         else:
             out = torch.empty_like(x32)
-            _lib.check(L.fg_edm_forward(
-                h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
-                ctypes.c_void_p(r64.data_ptr() if r64 is not None else None),
-                ctypes.c_void_p(labels.data_ptr() if labels is not None else None), ctypes.c_void_p(out.data_ptr()), None,
-                B, ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream(dev)))
+            with self._AugmentScope(h, aug):
+                _lib.check(L.fg_edm_forward(
+                    h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
+                    ctypes.c_void_p(r64.data_ptr() if r64 is not None else None),
+                    ctypes.c_void_p(labels.data_ptr() if labels is not None else None), ctypes.c_void_p(out.data_ptr()), None,
+                    B, ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream(dev)))
         out = out.to(x_t.dtype)
         out = self.noise_scheduler.convert_model_output(x_t, out, t64, src_pred_type=self.net_pred_type,
                                                         target_pred_type=fwd_pred_type)

@@ -226,6 +226,11 @@ int fg_disc_edm_run(const float* feat, int res, const float* const* params, floa
 int fg_edm_jvp(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* vx, const float* vt,
                const float* vr, float* out, float* jvp, int batch, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Augmentation labels of the training-time augmentation pipeline (EDM/network.py:495, 518-519, 903-915: condition =
+ * {"aug_condition", "orig_condition"}): [B, augment_dim] fp32, added to the mapping network's input through map_augment by every
+ * following forward / backward / jvp call of this handle until reset with NULL (borrowed pointer; must cover the call's batch). */
+int fg_edm_set_augment(fg_edm* h, const float* augment_labels);
+
 /* Samples to image bytes, the step after generator_fn in the reference's sample writer
  * (scripts/fid/compute_fid_from_ckpts.py:199): out[n,y,x,c] = uint8(clip(images[n,c,y,x] * 127.5 + 128, 0, 255)),
  * fp32 multiply then add, truncation; NaN -> 0.  images NCHW fp32, out NHWC bytes. */

@@ -277,9 +277,10 @@ def positional_embedding(t: Tensor, num_channels: int, max_positions: int = 1000
     return torch.cat([ang.cos(), ang.sin()], dim=1)
 
 
-def mapping(sd, cfg: SongUNetConfig, noise_labels: Tensor, class_labels: Optional[Tensor], r_noise_labels=None):
-    """Embedding MLP, SongUNet.forward EDM/network.py:500-521 (augment branch skipped: labels are None
-    on the sampling path, :916-917)."""
+def mapping(sd, cfg: SongUNetConfig, noise_labels: Tensor, class_labels: Optional[Tensor], r_noise_labels=None,
+            augment_labels: Optional[Tensor] = None):
+    """Embedding MLP, SongUNet.forward EDM/network.py:500-521; the augment branch (:518-519) only when the training-time
+    augmentation pipeline supplies labels (None on the sampling path, :916-917)."""
     emb = positional_embedding(noise_labels, cfg.noise_channels)
     emb = emb.reshape(emb.shape[0], 2, -1).flip(1).reshape(*emb.shape)  # -> [sin | cos]
     if r_noise_labels is not None:
@@ -288,17 +289,19 @@ def mapping(sd, cfg: SongUNetConfig, noise_labels: Tensor, class_labels: Optiona
         emb = torch.cat([emb, er], dim=-1)
     if cfg.label_dim:
         emb = emb + linear(class_labels * math.sqrt(cfg.label_dim), sd["model.map_label.weight"], sd["model.map_label.bias"])
+    if augment_labels is not None and "model.map_augment.weight" in sd:
+        emb = emb + linear(augment_labels, sd["model.map_augment.weight"], None)
     emb = F.silu(linear(emb, sd["model.map_layer0.weight"], sd["model.map_layer0.bias"]))
     emb = F.silu(linear(emb, sd["model.map_layer1.weight"], sd["model.map_layer1.bias"]))
     return emb
 
 
 def song_unet(sd, cfg: SongUNetConfig, x: Tensor, noise_labels: Tensor, class_labels, trace: Optional[dict] = None,
-              r_noise_labels: Optional[Tensor] = None):
+              r_noise_labels: Optional[Tensor] = None, augment_labels: Optional[Tensor] = None):
     """SongUNet.forward (standard encoder/decoder), EDM/network.py:489-574."""
     if r_noise_labels is not None and not cfg.r_timestep:
         raise ValueError("r_noise_labels provided, but r_timestep is not set")  # :510
-    emb = mapping(sd, cfg, noise_labels, class_labels, r_noise_labels)
+    emb = mapping(sd, cfg, noise_labels, class_labels, r_noise_labels, augment_labels)
     if trace is not None:
         trace["emb"] = emb
     enc, dec = layout(cfg)
@@ -328,7 +331,7 @@ def song_unet(sd, cfg: SongUNetConfig, x: Tensor, noise_labels: Tensor, class_la
 
 
 def edm_precond_forward(sd, cfg: SongUNetConfig, x_t: Tensor, t: Tensor, condition: Optional[Tensor], trace=None,
-                        r: Optional[Tensor] = None) -> Tensor:
+                        r: Optional[Tensor] = None, augment_labels: Optional[Tensor] = None) -> Tensor:
     """EDMPrecond.forward with fwd_pred_type = net_pred_type (identity conversion), eval mode, EDM/network.py:881-974;
     precond_input :755-778 (clamp_min 1e-6 from the scheduler, :930), precond_output :781-805; drop_precond :929-934,
     :959-960.  t (and r) are float64 on entry; coefficients are computed in float64 and cast to x_t.dtype before use."""
@@ -352,7 +355,7 @@ def edm_precond_forward(sd, cfg: SongUNetConfig, x_t: Tensor, t: Tensor, conditi
     t_in = t_in.to(x_t.dtype)
     if r_in is not None:
         r_in = r_in.to(x_t.dtype)
-    F_x = song_unet(sd, cfg, x_in, t_in, class_labels, trace=trace, r_noise_labels=r_in)
+    F_x = song_unet(sd, cfg, x_in, t_in, class_labels, trace=trace, r_noise_labels=r_in, augment_labels=augment_labels)
     if cfg.drop_precond in ("output", "both"):
         return F_x
     ts = t - cfg.sigma_shift  # eval mode

@@ -476,10 +476,43 @@ def trigflow_fixture(edm_net, ns):
     torch.save(fx, os.path.join(OUT, "trigflow_b2.pt"))
 
 
+def augment_fixture(edm_net):
+    """Training-time augmentation labels (EDM/network.py:495, 518-519, 903-915): forward and autograd of the reference with
+    condition = {"aug_condition", "orig_condition"}; output, map_augment's gradient and two other parameter gradients, B = 2."""
+    cfg = edm_ref.CIFAR10
+    sd = edm_ref.random_state_dict(cfg, seed=1234)
+    net = ref_net(edm_net, cfg, sd)
+    for p in net.parameters():
+        p.requires_grad_(True)
+        p.grad = None
+    tt = torch.tensor([3.3, 0.45], dtype=torch.float64)
+    x = seeded((2, 3, 32, 32), 91) * tt.reshape(2, 1, 1, 1).float()
+    cond = torch.nn.functional.one_hot(torch.tensor([1, 8]), 10).float()
+    aug = seeded((2, cfg.augment_dim), 92)
+    dout = seeded((2, 3, 32, 32), 93)
+    out = net(x, tt, condition={"aug_condition": aug, "orig_condition": cond}, fwd_pred_type="x0")
+    out.backward(dout)
+    oo = edm_ref.edm_precond_forward(sd, cfg, x, tt, cond, augment_labels=aug)
+    assert torch.allclose(oo, out, rtol=1e-4, atol=1e-5)
+    with torch.no_grad():
+        plain = net(x, tt, condition=cond, fwd_pred_type="x0")
+    assert not torch.allclose(plain, out)  # the labels do change the result
+    ps = dict(net.named_parameters())
+    fx = {"t": tt, "cond": cond, "out": out.detach().clone(), "map_augment_grad": ps["model.map_augment.weight"].grad.clone()}
+    for n in ("model.map_layer0.weight", "model.dec.32x32_block2.conv1.weight"):
+        g = ps[n].grad.reshape(-1)
+        fx[f"{n}/sample"] = g[:: max(1, g.numel() // 512)][:512].clone()
+    torch.save(fx, os.path.join(OUT, "augment_b2.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     edm_net, ns, model = _ref_import.import_reference()
     torch.manual_seed(0)
+    if sys.argv[1:] == ["augment"]:
+        augment_fixture(edm_net)
+        print("augment fixture written to", OUT)
+        return
     if sys.argv[1:] == ["jvp"]:
         jvp_fixture(edm_net)
         trigflow_fixture(edm_net, ns)
@@ -635,6 +668,7 @@ def main():
     discriminator_fixture()
     jvp_fixture(edm_net)
     trigflow_fixture(edm_net, ns)
+    augment_fixture(edm_net)
     teacher_sample_fixture(edm_net)
 
     print("golden fixtures written to", OUT)

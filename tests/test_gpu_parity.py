@@ -1081,3 +1081,34 @@ def test_network_jvp_properties_at_training_batch(nets):
         fd = (f(x + e * vx, t + e * vt.double(), condition=cond) - f(x - e * vx, t - e * vt.double(), condition=cond)) / (2 * e)
     cos = float((fd * j1).sum() / (fd.norm() * j1.norm()))
     assert cos >= 0.99 and abs(float(fd.norm() / j1.norm()) - 1) <= 5e-2, (cos, float(fd.norm() / j1.norm()))
+
+
+def test_augmentation_labels(nets, golden_dir):
+    """condition = {"aug_condition", "orig_condition"} (the training-time augmentation pipeline, EDM/network.py:903-915): forward in
+    both compute modes and autograd (map_augment's gradient) against the reference (tests/golden/augment_b2.pt); a width that
+    does not match map_augment is ignored like the reference does."""
+    fx = load(golden_dir, "augment_b2.pt")
+    t, cond = fx["t"].to(dev()), fx["cond"].to(dev())
+    x = (seeded((2, 3, 32, 32), 91) * fx["t"].reshape(2, 1, 1, 1).float()).to(dev())
+    aug = seeded((2, 9), 92).to(dev())
+    dout = seeded((2, 3, 32, 32), 93).to(dev())
+    c = {"aug_condition": aug, "orig_condition": cond}
+    with torch.no_grad():
+        for mode in ("fp32", "bf16"):
+            check(nets[mode](x, t, condition=c, fwd_pred_type="x0"), fx["out"], mode, f"augment forward {mode}")
+        plain = nets["fp32"](x, t, condition=cond, fwd_pred_type="x0")
+        assert torch.equal(nets["fp32"](x, t, condition={"aug_condition": aug[:, :5], "orig_condition": cond}, fwd_pred_type="x0"), plain)
+        assert torch.equal(nets["fp32"](x, t, condition=cond, fwd_pred_type="x0"), plain)  # the labels do not stick to the handle
+    net = nets["bf16"]
+    params = dict(net.named_parameters())
+    try:
+        net.zero_grad(set_to_none=True)
+        (net(x, t, condition=c, fwd_pred_type="x0") * dout).sum().backward()
+        g = params["model.map_augment.weight"].grad.cpu()
+        assert float((g - fx["map_augment_grad"]).norm() / fx["map_augment_grad"].norm()) <= 5e-2
+        for n in ("model.map_layer0.weight", "model.dec.32x32_block2.conv1.weight"):
+            gg = params[n].grad.detach().cpu().reshape(-1)
+            smp = gg[:: max(1, gg.numel() // 512)][:512]
+            assert float((smp - fx[f"{n}/sample"]).norm() / fx[f"{n}/sample"].norm()) <= 8e-2, n
+    finally:
+        net.zero_grad(set_to_none=True)

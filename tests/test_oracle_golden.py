@@ -295,3 +295,11 @@ def test_oracle_jvp_matches_reference_func_jvp(golden_dir, full_sd, mf_sd):
     out, jv = R.edm_precond_jvp(full_sd, R.CIFAR10, x, t, fx["edm/cond"], v, fx["edm/vt"])
     assert torch.allclose(out, fx["edm/out"], rtol=1e-4, atol=1e-5)
     assert float((jv - fx["edm/jvp"]).norm() / fx["edm/jvp"].norm()) <= 1e-4
+
+
+def test_oracle_augmentation_labels(golden_dir, full_sd):
+    fx = torch.load(os.path.join(golden_dir, "augment_b2.pt"), weights_only=True)
+    x = torch.randn((2, 3, 32, 32), generator=torch.Generator().manual_seed(91)) * fx["t"].reshape(2, 1, 1, 1).float()
+    aug = torch.randn((2, 9), generator=torch.Generator().manual_seed(92))
+    out = R.edm_precond_forward(full_sd, R.CIFAR10, x, fx["t"], fx["cond"], augment_labels=aug)
+    assert torch.allclose(out, fx["out"], rtol=1e-4, atol=1e-5)
