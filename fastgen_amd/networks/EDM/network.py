@@ -193,8 +193,9 @@ class EDMPrecond(FastGenNetwork):
             raise NotImplementedError(f"schedule_type={schedule_type!r} is not implemented by the fused MI355X path")
         mk = dict(model_kwargs)
         unsupported = {
-            "embedding_type": "positional", "encoder_type": "standard", "decoder_type": "standard", "label_dropout": 0,
+            "embedding_type": "positional", "encoder_type": "standard", "decoder_type": "standard",
         }
+        self.label_dropout = float(mk.get("label_dropout", 0) or 0)  # class-label dropout in training mode (EDM/network.py:515-516)
         for k, want in unsupported.items():
             if mk.get(k, want) != want:
                 raise NotImplementedError(f"{k}={mk[k]!r} is not implemented by the fused MI355X path (only {want!r})")
@@ -363,6 +364,10 @@ class EDMPrecond(FastGenNetwork):
             c = c.expand(batch, -1)
         if c.shape[0] != batch:
             raise ValueError(f"condition has {c.shape[0]} rows, expected {batch}")
+        if self.training and self.label_dropout:
+            # whole label rows are zeroed with probability label_dropout (classifier-free-guidance training), same draw as the
+            # reference: torch.rand([B, 1]) on the input's device (EDM/network.py:515-516)
+            c = c * (torch.rand([batch, 1], device=device) >= self.label_dropout).to(c.dtype)
         return c.contiguous()
 
     def _augment(self, condition, batch: int, device) -> Optional[torch.Tensor]:

@@ -439,3 +439,18 @@ def test_trigflow_wrapper_composition_with_the_oracle_as_network(golden_dir):
     F2, dF = w.jvp(xh, fx["wrap/t_hat"], vx, fx["wrap/vt"], condition=fx["wrap/cond"])
     assert torch.allclose(F2, fx["wrap/F"], rtol=1e-4, atol=1e-5)
     assert float((dF - fx["wrap/dF"]).norm() / fx["wrap/dF"].norm()) <= 1e-4
+
+
+def test_label_dropout_follows_reference_semantics():
+    """label_dropout zeroes whole class-label rows in training mode only, with the reference's draw (torch.rand([B, 1]) on the
+    input's device, EDM/network.py:515-516); eval mode leaves the labels alone."""
+    n = EDMPrecond(**{**KW, "label_dropout": 0.5})
+    c = torch.eye(10)[:8]
+    n.train()
+    torch.manual_seed(3)
+    got = n._labels(c, 8, torch.device("cpu"))
+    torch.manual_seed(3)
+    want = c * (torch.rand([8, 1]) >= 0.5).to(c.dtype)
+    assert torch.equal(got, want) and 0 < int(got.sum()) < 8
+    n.eval()
+    assert torch.equal(n._labels(c, 8, torch.device("cpu")), c)
