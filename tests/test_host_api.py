@@ -371,6 +371,7 @@ def test_training_abi_argument_checks_without_gpu():
         with pytest.raises(_lib.FastGenAMDError, match="gradient elements"):
             _lib.check(L.fg_edm_bind_grad(h, b"model.enc.32x32_conv.bias", ctypes.cast(buf, ctypes.c_void_p), 4))
         _lib.check(L.fg_edm_bind_grad(h, b"model.enc.32x32_conv.bias", None, 0))  # unbinding is always accepted
+        _lib.check(L.fg_edm_set_augment(h, None))  # resetting is always accepted
         assert L.fg_edm_backward_workspace_bytes(h, 0) == 0
         assert L.fg_edm_backward_workspace_bytes(h, 4) > L.fg_edm_workspace_bytes(h, 4)
         assert L.fg_edm_block_backward_workspace_bytes(h, 999, 2) == 0
