@@ -38,6 +38,37 @@ __device__ __forceinline__ const __bf16* cat_ptr(const __bf16* x1, int C1, const
     return (c0 < C1) ? x1 + pix * C1 + c0 : x2 + pix * C2 + (c0 - C1);
 }
 
+// Dropout of conv1's operand in training mode (UNetBlock.forward, EDM/network.py:283-284: F.dropout(silu(norm1(x)), p)): the keep
+// factors (0 or 1 / (1 - p)) of the 8 consecutive elements starting at flat index e0 (a multiple of 8) of block `blk`'s operand
+// come from Philox4x32-10 keyed by the call's seed with counter (e0 / 4 + {0, 1}, blk), so the backward and the forward-mode pass
+// regenerate exactly the mask the forward used.  p == 0: all ones.
+__device__ __forceinline__ void philox4(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[1] = (uint32_t)p1, c[3] = (uint32_t)p0, c[0] = n0, c[2] = n2;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ void dropout_keep8(const DropArgs& d, uint64_t e0, float (&k)[8]) {
+    if (d.p <= 0.f) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) k[j] = 1.f;
+        return;
+    }
+    const uint32_t thr = (uint32_t)fminf(d.p * 4294967296.0f, 4294967295.0f);
+    const float inv = 1.0f / (1.0f - d.p);
+#pragma unroll
+    for (int hq = 0; hq < 2; ++hq) {
+        const uint64_t q = e0 / 4 + hq;
+        uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), d.block, 0x5eedu};
+        philox4(c, (uint32_t)d.seed, (uint32_t)(d.seed >> 32));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k[4 * hq + j] = c[j] >= thr ? inv : 0.f;
+    }
+}
+
 // Gradient tensor t lives at the conv's OUTPUT resolution; fetch what reaches input pixel p (row-major, width `res`) of image n.
 // rm 0: same resolution.  rm 1: the forward averaged 2x2 input pixels (down-sampling) -> a quarter of the coarse value.
 // rm 2: the forward repeated each input pixel 2x2 (nearest up-sampling) -> the sum of the four fine values.
@@ -70,7 +101,7 @@ __device__ __forceinline__ void fetch_res(const __bf16* t, int Ct, int n, int p,
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_act_kernel(const __bf16* __restrict__ x1, int C1, const __bf16* __restrict__ x2, int C2,
                                                      const float2* __restrict__ ab, __bf16* __restrict__ out, int64_t total_oct,
-                                                     int res, int rm) {
+                                                     int res, int rm, DropArgs drop) {
     const int C = C1 + C2, OC = C >> 3, HW = res * res;
     const int ri = rm == 1 ? res * 2 : (rm == 2 ? res / 2 : res);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_oct; i += (int64_t)gridDim.x * 256) {
@@ -102,6 +133,12 @@ __global__ __launch_bounds__(256) void gn_act_kernel(const __bf16* __restrict__ 
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] *= 0.25f;
         }
+        if (drop.p > 0.f) {
+            float keep[8];
+            dropout_keep8(drop, (uint64_t)pix * C + c0, keep);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] *= keep[j];
+        }
         store8bf(out + pix * C + c0, o);
     }
 }
@@ -112,7 +149,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const __bf16* __restrict__ x1, int C1, const __bf16* __restrict__ x2,
                                                             int C2, const __bf16* __restrict__ dact, int Cd,
                                                             const float2* __restrict__ ab, const float2* __restrict__ mr,
-                                                            float2* __restrict__ P, int res, int rm) {
+                                                            float2* __restrict__ P, int res, int rm, DropArgs drop) {
     const int C = C1 + C2, HW = res * res;
     const int groups = min(32, C / 4), cpg = C / groups;
     const int n = blockIdx.y, oct = threadIdx.x & 7, pl = threadIdx.x >> 3;
@@ -134,6 +171,12 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const __bf16* __rest
             float xv[8], dv[8];
             load8bf(cat_ptr(x1, C1, x2, C2, pix, c0), xv);
             fetch_res(dact, Cd, n, p, c0, res, rm, dv);
+            if (drop.p > 0.f) {  // the operand was silu(y) * keep: its gradient passes through the same factors
+                float keep[8];
+                dropout_keep8(drop, (uint64_t)pix * C + c0, keep);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dv[j] *= keep[j];
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float dy = MODE == 0 ? dv[j] * silu_grad(fmaf(xv[j], a[j], b[j])) : dv[j];
@@ -195,7 +238,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const __bf16* __restr
                                                            const float2* __restrict__ ab, const float2* __restrict__ mr,
                                                            const float2* __restrict__ S, const __bf16* __restrict__ add, int Ca,
                                                            float add_scale, __bf16* __restrict__ dx, int dxs, __bf16* __restrict__ dx2,
-                                                           int dxs2, int accumulate, int64_t total_oct, int res, int rm) {
+                                                           int dxs2, int accumulate, int64_t total_oct, int res, int rm, DropArgs drop) {
     // destination: channels [0, C1) -> dx (pixel stride dxs), channels [C1, C) -> dx2 (pixel stride dxs2); accumulate: +=
     const int C = C1 + C2, OC = C >> 3, HW = res * res;
     const int groups = min(32, C / 4), cpg = C / groups;
@@ -207,6 +250,12 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const __bf16* __restr
         float xv[8], dv[8], av[8];
         load8bf(cat_ptr(x1, C1, x2, C2, pix, c0), xv);
         fetch_res(dact, Cd, n, p, c0, res, rm, dv);
+        if (drop.p > 0.f) {
+            float keep[8];
+            dropout_keep8(drop, (uint64_t)pix * C + c0, keep);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dv[j] *= keep[j];
+        }
         if (add) fetch_res(add, Ca, n, p, c0, res, rm, av);
         float o[8];
 #pragma unroll
@@ -418,7 +467,7 @@ __global__ __launch_bounds__(256) void gn_jvp_apply_kernel(const __bf16* __restr
                                                            int C2, const __bf16* __restrict__ xd, int Cd,
                                                            const float2* __restrict__ ab, const float2* __restrict__ mr,
                                                            const float2* __restrict__ S, __bf16* __restrict__ out, int64_t total_oct,
-                                                           int HW) {
+                                                           int HW, DropArgs drop) {
     const int C = C1 + C2, OC = C >> 3;
     const int groups = min(32, C / 4), cpg = C / groups;
     const float inv_m = 1.0f / ((float)cpg * (float)HW);
@@ -439,6 +488,12 @@ __global__ __launch_bounds__(256) void gn_jvp_apply_kernel(const __bf16* __restr
             float r = t.x * (dv[j] - fmaf(xhat, s.y, s.x) * inv_m);
             if (MODE == 0) r *= silu_grad(fmaf(xv[j], t.x, t.y));
             o[j] = r;
+        }
+        if (drop.p > 0.f) {
+            float keep[8];
+            dropout_keep8(drop, (uint64_t)pix * C + c0, keep);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] *= keep[j];
         }
         store8bf(out + pix * C + c0, o);
     }
@@ -513,6 +568,16 @@ __global__ void fill_f2_kernel(float2* __restrict__ p, float2 v, int n) {
     if (i < n) p[i] = v;
 }
 
+// the keep factors themselves (parity tests feed them to the oracle): out[e] for e < total, total % 8 == 0
+__global__ void dropout_mask_kernel(float* __restrict__ out, int64_t total, DropArgs drop) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total / 8; i += (int64_t)gridDim.x * 256) {
+        float keep[8];
+        dropout_keep8(drop, (uint64_t)i * 8, keep);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[i * 8 + j] = keep[j];
+    }
+}
+
 inline unsigned ew_blocks(int64_t n) {
     const int64_t b = (n + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
@@ -523,23 +588,23 @@ inline unsigned ew_blocks(int64_t n) {
 #define BWD_RET() return (int)hipGetLastError()
 
 int launch_gn_act(int mode, const void* x1, int c1, const void* x2, int c2, const float2* ab, void* out, int B, int res, int rm,
-                  hipStream_t s) {
+                  hipStream_t s, DropArgs drop) {
     if ((c1 % 8) || (c2 % 8)) return (int)hipErrorInvalidValue;
     const int hw = res * res;
     const int64_t total = (int64_t)B * hw * ((c1 + c2) / 8);
     if (mode == 0)
-        hipLaunchKernelGGL(gn_act_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, ab, (__bf16*)out, total, res, rm);
+        hipLaunchKernelGGL(gn_act_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, ab, (__bf16*)out, total, res, rm, drop);
     else if (mode == 2)
-        hipLaunchKernelGGL(gn_act_kernel<2>, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, ab, (__bf16*)out, total, res, rm);
+        hipLaunchKernelGGL(gn_act_kernel<2>, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, ab, (__bf16*)out, total, res, rm, drop);
     else
-        hipLaunchKernelGGL(gn_act_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, ab, (__bf16*)out, total, res, rm);
+        hipLaunchKernelGGL(gn_act_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, ab, (__bf16*)out, total, res, rm, drop);
     BWD_RET();
 }
 
 // GroupNorm(+SiLU) backward.  P: [B][C] float2 scratch, S: [B][groups] float2 scratch.  dgamma / dbeta are accumulated.
 int launch_gn_bwd(int mode, const void* x1, int c1, const void* x2, int c2, const void* dact, int cd, const float2* ab,
                   const float2* mr, const float* gamma, float2* P, float2* S, float* dgamma, float* dbeta, const void* add, int ca,
-                  float add_scale, void* dx, int B, int res, int rm, hipStream_t s, void* dx2, int accumulate) {
+                  float add_scale, void* dx, int B, int res, int rm, hipStream_t s, void* dx2, int accumulate, DropArgs drop) {
     const int C = c1 + c2, hw = res * res;
     // default destination: one [B, hw, C] tensor; with dx2 the two halves of the concat go to their own (dense) tensors
     __bf16* d1 = (__bf16*)dx;
@@ -550,16 +615,16 @@ int launch_gn_bwd(int mode, const void* x1, int c1, const void* x2, int c2, cons
     dim3 rg((C + 63) / 64, B);
     const __bf16 *X1 = (const __bf16*)x1, *X2 = (const __bf16*)x2, *D = (const __bf16*)dact, *A = (const __bf16*)add;
     if (mode == 0)
-        hipLaunchKernelGGL(gn_bwd_reduce_kernel<0>, rg, dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, P, res, rm);
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<0>, rg, dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, P, res, rm, drop);
     else
-        hipLaunchKernelGGL(gn_bwd_reduce_kernel<1>, rg, dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, P, res, rm);
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<1>, rg, dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, P, res, rm, drop);
     hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(B), dim3(32), 0, s, P, gamma, S, C);
     if (dgamma || dbeta) hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 63) / 64), dim3(256), 0, s, P, dgamma, dbeta, B, C);
     const int64_t total = (int64_t)B * hw * (C / 8);
     if (mode == 0)
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, S, A, ca, add_scale, d1, s1, d2, s2, accumulate, total, res, rm);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, S, A, ca, add_scale, d1, s1, d2, s2, accumulate, total, res, rm, drop);
     else
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, S, A, ca, add_scale, d1, s1, d2, s2, accumulate, total, res, rm);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, S, A, ca, add_scale, d1, s1, d2, s2, accumulate, total, res, rm, drop);
     (void)groups;
     BWD_RET();
 }
@@ -643,17 +708,17 @@ int launch_input_grad(const void* da, int cd, const float* c_in, const float* c_
 }
 // GroupNorm(+SiLU) tangent of xd (dense [B, hw, C] over the concat) -> out [B, hw, C]; P / S scratch as in launch_gn_bwd
 int launch_gn_jvp(int mode, const void* x1, int c1, const void* x2, int c2, const void* xd, const float2* ab, const float2* mr,
-                  float2* P, float2* S, void* out, int B, int res, hipStream_t s) {
+                  float2* P, float2* S, void* out, int B, int res, hipStream_t s, DropArgs drop) {
     const int C = c1 + c2, hw = res * res;
     if ((c1 % 8) || (c2 % 8) || C < 16) return (int)hipErrorInvalidValue;
     const __bf16 *X1 = (const __bf16*)x1, *X2 = (const __bf16*)x2, *D = (const __bf16*)xd;
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel<1>, dim3((C + 63) / 64, B), dim3(256), 0, s, X1, c1, X2, c2, D, C, ab, mr, P, res, 0);
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<1>, dim3((C + 63) / 64, B), dim3(256), 0, s, X1, c1, X2, c2, D, C, ab, mr, P, res, 0, DropArgs{});
     hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(B), dim3(32), 0, s, P, (const float*)nullptr, S, C);
     const int64_t total = (int64_t)B * hw * (C / 8);
     if (mode == 0)
-        hipLaunchKernelGGL(gn_jvp_apply_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, C, ab, mr, S, (__bf16*)out, total, hw);
+        hipLaunchKernelGGL(gn_jvp_apply_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, C, ab, mr, S, (__bf16*)out, total, hw, drop);
     else
-        hipLaunchKernelGGL(gn_jvp_apply_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, C, ab, mr, S, (__bf16*)out, total, hw);
+        hipLaunchKernelGGL(gn_jvp_apply_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, C, ab, mr, S, (__bf16*)out, total, hw, drop);
     BWD_RET();
 }
 int launch_jvp_coef(const double* t, const double* r, const float* vt, const float* vr, double sigma_data, double sigma_shift, int drop,
@@ -683,5 +748,10 @@ int launch_fill_f32(float* p, float v, int n, hipStream_t s) {
 }
 int launch_fill_f2(float2* p, float a, float b, int n, hipStream_t s) {
     hipLaunchKernelGGL(fill_f2_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, make_float2(a, b), n);
+    BWD_RET();
+}
+int launch_dropout_mask(float* out, int64_t total, DropArgs drop, hipStream_t s) {
+    if (total % 8) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(total / 8)), dim3(256), 0, s, out, total, drop);
     BWD_RET();
 }

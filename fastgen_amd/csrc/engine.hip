@@ -93,6 +93,8 @@ struct Workspace {
     float *coef, *emb0, *emb1, *emb, *temb;
     float2 *ab0, *ab1, *ab2;
     float2 *mr0 = nullptr, *mr1 = nullptr, *mr2 = nullptr;  // {mean, rstd} of norm0 / norm1 / norm2, kept when a backward pass follows
+    void* a1d = nullptr;   // training forward with dropout: where the block's dropped conv1 operand goes
+    DropArgs drop;         // ... and its dropout parameters (p == 0: off)
     std::vector<Act> skip;  // encoder outputs
     Act xa, xb, h, xattn;
     void *sbuf, *aout, *pool;
@@ -109,6 +111,8 @@ struct BlockStash {
     void* h = nullptr;                      // conv0 output
     float2 *ab0 = nullptr, *ab1 = nullptr, *ab2 = nullptr, *mr0 = nullptr, *mr1 = nullptr, *mr2 = nullptr;
     void *xattn = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *aout = nullptr;  // attention blocks
+    void* a1d = nullptr;   // conv1's operand silu(norm1(h)) * keep, materialised when dropout is on
+    uint32_t index = 0;    // position in fg_edm::blocks: the block's Philox stream
 };
 struct TrainStash {
     std::vector<Act> dec_store;      // decoder block outputs (the encoder's live on the skip stack anyway)
@@ -150,6 +154,8 @@ struct fg_edm {
     std::map<const float*, DgradW> dgrad_cache;
     uint64_t pack_epoch = 0;
     const float* augment = nullptr;  // [B][augment_dim] augmentation labels of the next calls (fg_edm_set_augment), or none
+    float dropout_p = 0.f;           // training-mode dropout of conv1's operand (fg_edm_set_dropout); 0 = off
+    uint64_t dropout_seed = 0;
     float* aff_wT = nullptr;  // [emb_ch][temb_total]: the stacked affine matrix transposed, for the batched embedding gradient
     uint64_t aff_wT_epoch = 0;
     // owned device memory
@@ -449,6 +455,8 @@ int norm_coeffs(int dtype, const Act& x1, int c1, const Act& x2, int c2, const f
 void use_stash(Workspace& w, const BlockStash& st) {
     w.h.p = st.h;
     w.ab0 = st.ab0, w.ab1 = st.ab1, w.mr0 = st.mr0, w.mr1 = st.mr1;
+    w.a1d = st.a1d;
+    w.drop.block = st.index;
     if (st.xattn) {
         w.xattn.p = st.xattn;
         w.ab2 = st.ab2, w.mr2 = st.mr2;
@@ -503,7 +511,15 @@ int run_block(fg_edm* h, const Block& b, const Act& x1, int c1, const Act& x2, i
     d.src1 = w.h.p; d.C1 = b.cout; d.Hs = d.Ws = d.H = d.W = b.res_out; d.B = B;
     d.ab = w.ab1; d.wpack = b.p_conv1; d.wpack_ws = b.p_conv1_ws; d.bias = h->P(b.conv1_b);
     d.resid = resid; d.scale = kSkipScale; d.out = x_mid.p; d.Cout = b.cout; d.stats = x_mid.st;
-    HIP_TRY(conv_launch(h, 3, PRO_GN_SILU, RES_NONE, OUT_NHWC, d, s));
+    if (w.drop.p > 0.f && w.a1d) {
+        // training mode with dropout (EDM/network.py:283-284): the operand silu(norm1(h)) * keep is materialised once (the
+        // backward's weight gradient contracts with the same tensor) and the conv runs without a prologue
+        HIP_TRY(launch_gn_act(0, w.h.p, b.cout, nullptr, 0, w.ab1, w.a1d, B, b.res_out, 0, s, w.drop));
+        d.src1 = w.a1d; d.ab = nullptr; d.wpack_ws = nullptr;
+        HIP_TRY(conv_launch(h, 3, PRO_NONE, RES_NONE, OUT_NHWC, d, s));
+    } else {
+        HIP_TRY(conv_launch(h, 3, PRO_GN_SILU, RES_NONE, OUT_NHWC, d, s));
+    }
     x_mid.slots = slots;
     if (b.attn) {
         HIP_TRY(launch_gn_finalize(x_mid.st, b.cout, slots, nullptr, 0, 0, h->P(b.norm2_w), h->P(b.norm2_b), kBlockEps, w.ab2, B, hw, s, w.mr2));
@@ -548,6 +564,8 @@ int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, cons
                                 c.drop_precond, w.coef, B, s));
     int rc = run_mapping(h, labels, B, w, s);
     if (rc) return rc;
+    w.drop = DropArgs{};
+    if (ts && h->dropout_p > 0.f) w.drop.p = h->dropout_p, w.drop.seed = h->dropout_seed;  // training forwards only
     // encoder
     const Act none;
     const Act* x = nullptr;
@@ -1124,6 +1142,20 @@ int fg_op_forward_process(const float* x0, const float* eps, double t, int sched
 }
 int fg_op_x0_to_eps(const float* xt, const float* x0, double t, int schedule, float* out, int64_t total, void* stream) {
     HIP_TRY(launch_x0_to_eps(xt, x0, t, nullptr, 0, schedule, 1e-6, out, total, (hipStream_t)stream));
+    return FG_OK;
+}
+int fg_edm_set_dropout(fg_edm* h, float p, uint64_t seed) {
+    if (!h) return fail(FG_EINVAL, "null handle");
+    if (!(p >= 0.f && p < 1.f)) return fail(FG_EINVAL, "dropout probability must be in [0, 1), got %g", (double)p);
+    h->dropout_p = p;
+    h->dropout_seed = seed;
+    return FG_OK;
+}
+int fg_op_dropout_mask(float* out, int64_t total, float p, uint32_t block_index, uint64_t seed, void* stream) {
+    if (!out || total <= 0 || (total % 8)) return fail(FG_EINVAL, "fg_op_dropout_mask: bad argument");
+    DropArgs d;
+    d.p = p, d.block = block_index, d.seed = seed;
+    HIP_TRY(launch_dropout_mask(out, total, d, (hipStream_t)stream));
     return FG_OK;
 }
 int fg_edm_set_augment(fg_edm* h, const float* augment_labels) {

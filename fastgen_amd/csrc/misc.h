@@ -30,12 +30,20 @@ int launch_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, cons
 int launch_gn_silu_pool(int dtype, const void* x, const float2* ab, void* out, int B, int H, int W, int C, hipStream_t s);
 int launch_to_act(int dtype, const float* in, void* out, int64_t total, hipStream_t s);
 int launch_from_act(int dtype, const void* in, float* out, int64_t total, hipStream_t s);
+// dropout of conv1's operand in training mode: probability, block index (its own Philox stream), seed of the call; p == 0: off
+struct DropArgs {
+    float p = 0.f;
+    uint32_t block = 0;
+    uint64_t seed = 0;
+};
+int launch_dropout_mask(float* out, int64_t total, DropArgs drop, hipStream_t s);
 // bwd.hip: elementwise / reduction pieces of the block backward pass (bf16 activations)
 int launch_gn_act(int mode, const void* x1, int c1, const void* x2, int c2, const float2* ab, void* out, int B, int res, int rm,
-                  hipStream_t s);  // res = output resolution; rm 0 none, 1 down (avg 2x2), 2 up (nearest)
+                  hipStream_t s, DropArgs drop = DropArgs{});  // res = output resolution; rm 0 none, 1 down (avg 2x2), 2 up (nearest)
 int launch_gn_bwd(int mode, const void* x1, int c1, const void* x2, int c2, const void* dact, int cd, const float2* ab,
                   const float2* mr, const float* gamma, float2* P, float2* S, float* dgamma, float* dbeta, const void* add, int ca,
-                  float add_scale, void* dx, int B, int res, int rm, hipStream_t s, void* dx2 = nullptr, int accumulate = 0);
+                  float add_scale, void* dx, int B, int res, int rm, hipStream_t s, void* dx2 = nullptr, int accumulate = 0,
+                  DropArgs drop = DropArgs{});
                   // res = the norm's (input) resolution; dx2: separate dense tensor for the second concat source; accumulate: +=
 int launch_colsum(const void* t, int ct, int C, float* out, int B, int hw, float scale, hipStream_t s, int out_stride = 0);
 int launch_transpose_f32(const float* in, float* out, int R, int Cc, hipStream_t s);
@@ -56,7 +64,7 @@ int launch_add_nchw_to_nhwc(const float* src, void* dst, int B, int C, int hw, h
 int launch_input_grad(const void* da, int cd, const float* c_in, const float* c_skip, const float* dout, float* dx, int B, int C, int hw,
                       hipStream_t s);
 int launch_gn_jvp(int mode, const void* x1, int c1, const void* x2, int c2, const void* xd, const float2* ab, const float2* mr,
-                  float2* P, float2* S, void* out, int B, int res, hipStream_t s);
+                  float2* P, float2* S, void* out, int B, int res, hipStream_t s, DropArgs drop = DropArgs{});
 int launch_jvp_coef(const double* t, const double* r, const float* vt, const float* vr, double sigma_data, double sigma_shift, int drop,
                     float* ct, int B, hipStream_t s);
 int launch_jvp_embed(const float* c_noise, const float* r_noise, const float* dc, const float* dr, const float* freqs, float* out, int B,

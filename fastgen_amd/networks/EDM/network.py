@@ -74,11 +74,13 @@ class _EDMForwardFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, x32, t64, r64, labels, taps_aug, early, *weights):
-        taps, aug = taps_aug
-        ctx.aug = aug
+        taps, aug, drop = taps_aug
+        ctx.aug, ctx.drop = aug, drop
         dev, B = x32.device, x32.shape[0]
         L = _lib.lib()
         dt, h = net._engine(dev)
+        if drop is not None:  # before the workspace is sized: one more tensor per block
+            _lib.check(L.fg_edm_set_dropout(h, drop[0], drop[1]))
         ws = net._train_workspace(h, B, dev)
         out = None if early else torch.empty_like(x32)
         ntap = L.fg_edm_num_feature_taps(h)
@@ -97,6 +99,8 @@ class _EDMForwardFn(torch.autograd.Function):
                 ctypes.c_void_p(labels.data_ptr() if labels is not None else None),
                 ctypes.c_void_p(out.data_ptr() if out is not None else None), ptrs if taps else None,
                 B, ctypes.c_void_p(ws.data_ptr()), ws.numel(), net._stream(dev)))
+        if drop is not None:
+            _lib.check(L.fg_edm_set_dropout(h, 0.0, 0))
         # the training workspace now holds this call's state; any later training forward of the module replaces the token, and
         # the backward of this call then recomputes its forward
         ctx.token = net._train_token = object()
@@ -126,6 +130,8 @@ class _EDMForwardFn(torch.autograd.Function):
                 off += p.numel()
             else:
                 grads.append(None)
+        if ctx.drop is not None:
+            _lib.check(L.fg_edm_set_dropout(h, ctx.drop[0], ctx.drop[1]))
         ws = net._train_workspace(h, B, dev)
         have_forward = int(getattr(net, "_train_token", None) is ctx.token and ws.data_ptr() == ctx.ws_ptr)
         douts = list(douts)
@@ -160,6 +166,8 @@ class _EDMForwardFn(torch.autograd.Function):
                 ctypes.c_void_p(dx.data_ptr() if dx is not None else None), have_forward, B,
                 ctypes.c_void_p(ws.data_ptr()), ws.numel(), net._stream(dev)))
         finally:
+            if ctx.drop is not None:
+                _lib.check(L.fg_edm_set_dropout(h, 0.0, 0))
             if ctx.aug is not None:
                 _lib.check(L.fg_edm_set_augment(h, None))
             for (n, _), g in zip(named, grads):
@@ -458,10 +466,12 @@ class EDMPrecond(FastGenNetwork):
             raise ValueError("this network was built with r_timestep=True: forward() needs r")
         if fwd_kwargs:
             raise TypeError(f"unexpected forward kwargs: {sorted(fwd_kwargs)}")
+        # training mode with dropout (EDM/network.py:283-284): a fresh mask per call, regenerated by the backward from the seed
+        drop = None
         if self.training and self.dropout:
-            raise NotImplementedError("dropout in training mode is not implemented (call .eval())")
+            drop = (float(self.dropout), int(torch.randint(0, 2**62, (1,)).item()))
         needs_grad = self._needs_grad(x_t)
-        if needs_grad:
+        if needs_grad or (self.training and self.dropout):
             self._check_trainable_call(return_logvar)
         if x_t.device.type != "cuda":
             raise RuntimeError("fastgen_amd runs on a HIP GPU only (no CPU path); got a tensor on " + str(x_t.device))
@@ -489,12 +499,12 @@ class EDMPrecond(FastGenNetwork):
         ws = self._workspace(dt, h, B, dev)
         L = _lib.lib()
         features: List[torch.Tensor] = []
-        if needs_grad:
+        if needs_grad or drop is not None:  # the training entry points (under no_grad the Function simply records nothing)
             ntap = L.fg_edm_num_feature_taps(h)
             taps = tuple(i for i in range(ntap) if i in feature_indices)
             if return_features_early:
                 assert len(taps) == len(feature_indices), f"{len(taps)} != {len(feature_indices)}"
-            res = _EDMForwardFn.apply(self, x32, t64, r64, labels, (taps, aug), bool(return_features_early),
+            res = _EDMForwardFn.apply(self, x32, t64, r64, labels, (taps, aug, drop), bool(return_features_early),
                                       *[p_ for _, p_ in self._named_weights()])
             res = list(res)
             out = None if return_features_early else res.pop(0)
@@ -565,12 +575,22 @@ class EDMPrecond(FastGenNetwork):
         vx = v_x.detach().to(torch.float32).contiguous()
         t64, r64, vt, vr = f64(t), f64(r), f32(v_t), f32(v_r)
         labels = self._labels(condition, B, dev)
-        ws = self._train_workspace(h, B, dev)
-        self._train_token = object()  # the kept state of an earlier training forward is overwritten
-        out, jv = torch.empty_like(x32), torch.empty_like(x32)
-        p = lambda a: ctypes.c_void_p(a.data_ptr() if a is not None else None)
-        _lib.check(_lib.lib().fg_edm_jvp(h, p(x32), p(t64), p(r64), p(labels), p(vx), p(vt), p(vr), p(out), p(jv), B,
-                                         ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream(dev)))
+        aug = self._augment(condition, B, dev)
+        L = _lib.lib()
+        drop = self.training and bool(self.dropout)
+        if drop:  # train() mode: a fresh mask, as a training forward would draw (before the workspace is sized)
+            _lib.check(L.fg_edm_set_dropout(h, float(self.dropout), int(torch.randint(0, 2**62, (1,)).item())))
+        try:
+            ws = self._train_workspace(h, B, dev)
+            self._train_token = object()  # the kept state of an earlier training forward is overwritten
+            out, jv = torch.empty_like(x32), torch.empty_like(x32)
+            p = lambda a: ctypes.c_void_p(a.data_ptr() if a is not None else None)
+            with self._AugmentScope(h, aug):
+                _lib.check(L.fg_edm_jvp(h, p(x32), p(t64), p(r64), p(labels), p(vx), p(vt), p(vr), p(out), p(jv), B,
+                                        ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream(dev)))
+        finally:
+            if drop:
+                _lib.check(L.fg_edm_set_dropout(h, 0.0, 0))
         return out.to(x_t.dtype), jv.to(x_t.dtype)
 
     def _logvar(self, t64: torch.Tensor) -> torch.Tensor:

@@ -231,6 +231,14 @@ int fg_edm_jvp(fg_edm* h, const float* x_t, const double* t, const double* r, co
  * following forward / backward / jvp call of this handle until reset with NULL (borrowed pointer; must cover the call's batch). */
 int fg_edm_set_augment(fg_edm* h, const float* augment_labels);
 
+/* Training-mode dropout of conv1's operand in every UNetBlock (EDM/network.py:283-284; the SFT config trains with p = 0.13):
+ * honoured by fg_edm_forward_train / fg_edm_backward(_ex) / fg_edm_jvp (never by the inference entry points), p = 0 turns it off.
+ * The mask is Philox4x32-10(seed; element, block) - the backward regenerates it - so a forward and its backward must see the same
+ * (p, seed); set p before sizing the workspace (one more tensor per block).  fg_op_dropout_mask writes the keep factors
+ * (0 or 1/(1-p)) of one block's operand, flattened [B, H*W, C] (parity tests). */
+int fg_edm_set_dropout(fg_edm* h, float p, uint64_t seed);
+int fg_op_dropout_mask(float* out, int64_t total, float p, uint32_t block_index, uint64_t seed, void* stream);
+
 /* Samples to image bytes, the step after generator_fn in the reference's sample writer
  * (scripts/fid/compute_fid_from_ckpts.py:199): out[n,y,x,c] = uint8(clip(images[n,c,y,x] * 127.5 + 128, 0, 255)),
  * fp32 multiply then add, truncation; NaN -> 0.  images NCHW fp32, out NHWC bytes. */

@@ -245,14 +245,17 @@ SKIP_SCALE = math.sqrt(0.5)  # block_kwargs.skip_scale, EDM/network.py:385
 BLOCK_EPS = 1e-6  # block_kwargs.eps, EDM/network.py:386 (also aux_norm :483)
 
 
-def unet_block(sd: Dict[str, Tensor], b: BlockSpec, x: Tensor, emb: Tensor) -> Tensor:
-    """UNetBlock.forward with adaptive_scale=False, dropout=0, EDM/network.py:274-299."""
+def unet_block(sd: Dict[str, Tensor], b: BlockSpec, x: Tensor, emb: Tensor, drop_keep: Optional[Tensor] = None) -> Tensor:
+    """UNetBlock.forward with adaptive_scale=False, EDM/network.py:274-299.  drop_keep: the training-mode dropout of conv1's
+    operand (:283-284, F.dropout(silu(norm1(x)), p)) as explicit keep factors (0 or 1/(1-p), same shape as the operand)."""
     k = b.key
     orig = x
     h = F.silu(group_norm(x, sd[f"{k}.norm0.weight"], sd[f"{k}.norm0.bias"], BLOCK_EPS))
     h = conv2d(h, sd[f"{k}.conv0.weight"], sd[f"{k}.conv0.bias"], up=b.up, down=b.down)
     h = h + linear(emb, sd[f"{k}.affine.weight"], sd[f"{k}.affine.bias"])[:, :, None, None]
     h = F.silu(group_norm(h, sd[f"{k}.norm1.weight"], sd[f"{k}.norm1.bias"], BLOCK_EPS))
+    if drop_keep is not None:
+        h = h * drop_keep
     h = conv2d(h, sd[f"{k}.conv1.weight"], sd[f"{k}.conv1.bias"])
     if f"{k}.skip.weight" in sd:
         orig = conv2d(orig, sd[f"{k}.skip.weight"], sd[f"{k}.skip.bias"], up=b.up, down=b.down)
@@ -297,7 +300,7 @@ def mapping(sd, cfg: SongUNetConfig, noise_labels: Tensor, class_labels: Optiona
 
 
 def song_unet(sd, cfg: SongUNetConfig, x: Tensor, noise_labels: Tensor, class_labels, trace: Optional[dict] = None,
-              r_noise_labels: Optional[Tensor] = None, augment_labels: Optional[Tensor] = None):
+              r_noise_labels: Optional[Tensor] = None, augment_labels: Optional[Tensor] = None, drop_keeps=None):
     """SongUNet.forward (standard encoder/decoder), EDM/network.py:489-574."""
     if r_noise_labels is not None and not cfg.r_timestep:
         raise ValueError("r_noise_labels provided, but r_timestep is not set")  # :510
@@ -310,7 +313,7 @@ def song_unet(sd, cfg: SongUNetConfig, x: Tensor, noise_labels: Tensor, class_la
         if b.kind == "conv":
             x = conv2d(x, sd[f"{b.key}.weight"], sd[f"{b.key}.bias"])
         else:
-            x = unet_block(sd, b, x, emb)
+            x = unet_block(sd, b, x, emb, None if drop_keeps is None else drop_keeps[b.key])
         skips.append(x)
         if trace is not None:
             trace[b.key] = x
@@ -324,14 +327,14 @@ def song_unet(sd, cfg: SongUNetConfig, x: Tensor, noise_labels: Tensor, class_la
         else:
             if x.shape[1] != b.cin:
                 x = torch.cat([x, skips.pop()], dim=1)
-            x = unet_block(sd, b, x, emb)
+            x = unet_block(sd, b, x, emb, None if drop_keeps is None else drop_keeps[b.key])
             if trace is not None:
                 trace[b.key] = x
     return out
 
 
 def edm_precond_forward(sd, cfg: SongUNetConfig, x_t: Tensor, t: Tensor, condition: Optional[Tensor], trace=None,
-                        r: Optional[Tensor] = None, augment_labels: Optional[Tensor] = None) -> Tensor:
+                        r: Optional[Tensor] = None, augment_labels: Optional[Tensor] = None, drop_keeps=None) -> Tensor:
     """EDMPrecond.forward with fwd_pred_type = net_pred_type (identity conversion), eval mode, EDM/network.py:881-974;
     precond_input :755-778 (clamp_min 1e-6 from the scheduler, :930), precond_output :781-805; drop_precond :929-934,
     :959-960.  t (and r) are float64 on entry; coefficients are computed in float64 and cast to x_t.dtype before use."""
@@ -355,7 +358,8 @@ def edm_precond_forward(sd, cfg: SongUNetConfig, x_t: Tensor, t: Tensor, conditi
     t_in = t_in.to(x_t.dtype)
     if r_in is not None:
         r_in = r_in.to(x_t.dtype)
-    F_x = song_unet(sd, cfg, x_in, t_in, class_labels, trace=trace, r_noise_labels=r_in, augment_labels=augment_labels)
+    F_x = song_unet(sd, cfg, x_in, t_in, class_labels, trace=trace, r_noise_labels=r_in, augment_labels=augment_labels,
+                    drop_keeps=drop_keeps)  # drop_keeps: {block key: keep factors} of a training-mode call, or None
     if cfg.drop_precond in ("output", "both"):
         return F_x
     ts = t - cfg.sigma_shift  # eval mode

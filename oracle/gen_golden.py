@@ -505,12 +505,71 @@ def augment_fixture(edm_net):
     torch.save(fx, os.path.join(OUT, "augment_b2.pt"))
 
 
+def dropout_fixture(edm_net):
+    """Training-mode dropout (EDM/network.py:283-284; the SFT config trains with p = 0.13): the reference in train() mode with
+    `torch.nn.functional.dropout` replaced by a deterministic stand-in that multiplies by explicit keep factors drawn from seeded
+    generators (call i uses seed 600 + i), so that WHERE the dropout sits and how it scales are pinned; the oracle given the same
+    factors must reproduce output and gradients."""
+    import torch.nn.functional as TF
+
+    p_drop = 0.13
+    cfg = edm_ref.CIFAR10
+    sd = edm_ref.random_state_dict(cfg, seed=1234)
+    net = edm_net.EDMPrecond(
+        img_resolution=32, img_channels=3, label_dim=10, sigma_shift=0.0, sigma_data=0.5, model_type="SongUNet", augment_dim=9,
+        model_channels=128, channel_mult=[2, 2, 2], channel_mult_noise=1, num_blocks=4, attn_resolutions=[16],
+        embedding_type="positional", encoder_type="standard", decoder_type="standard", resample_filter=[1, 1], dropout=p_drop,
+        label_dropout=0, r_timestep=False, drop_precond=None)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    calls = []
+    orig = TF.dropout
+
+    def fake_dropout(x, p=0.5, training=True, inplace=False):
+        assert training and abs(p - p_drop) < 1e-12
+        i = len(calls)
+        keep = (torch.rand(x.shape, generator=torch.Generator().manual_seed(600 + i)) >= p).to(x.dtype) / (1 - p)
+        calls.append(tuple(x.shape))
+        return x * keep
+
+    tt = torch.tensor([2.2, 0.31], dtype=torch.float64)
+    x = seeded((2, 3, 32, 32), 95) * tt.reshape(2, 1, 1, 1).float()
+    cond = torch.nn.functional.one_hot(torch.tensor([0, 5]), 10).float()
+    dout = seeded((2, 3, 32, 32), 96)
+    for p in net.parameters():
+        p.requires_grad_(True)
+    TF.dropout = fake_dropout
+    torch.nn.functional.dropout = fake_dropout
+    try:
+        out = net(x, tt, condition=cond, fwd_pred_type="x0")
+        out.backward(dout)
+    finally:
+        TF.dropout = orig
+        torch.nn.functional.dropout = orig
+    enc, dec = edm_ref.layout(cfg)
+    blocks = [b for b in enc + dec if b.kind == "block"]
+    assert len(calls) == len(blocks) == 33, len(calls)   # one call per UNetBlock, in execution order
+    keeps = {}
+    for i, b in enumerate(blocks):
+        assert calls[i] == (2, b.cout, b.res, b.res)
+        keeps[b.key] = (torch.rand(calls[i], generator=torch.Generator().manual_seed(600 + i)) >= p_drop).float() / (1 - p_drop)
+    oo = edm_ref.edm_precond_forward(sd, cfg, x, tt, cond, drop_keeps=keeps)
+    assert torch.allclose(oo, out, rtol=1e-4, atol=1e-5), float((oo - out).abs().max())
+    ps = dict(net.named_parameters())
+    fx = {"p": torch.tensor(p_drop), "t": tt, "cond": cond, "out": out.detach().clone()}
+    for n in ("model.enc.32x32_block1.conv1.weight", "model.enc.16x16_block2.norm1.weight", "model.dec.8x8_block1.conv0.weight"):
+        g = ps[n].grad.reshape(-1)
+        fx[f"{n}/sample"] = g[:: max(1, g.numel() // 512)][:512].clone()
+    torch.save(fx, os.path.join(OUT, "dropout_b2.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     edm_net, ns, model = _ref_import.import_reference()
     torch.manual_seed(0)
     if sys.argv[1:] == ["augment"]:
         augment_fixture(edm_net)
+        dropout_fixture(edm_net)
         print("augment fixture written to", OUT)
         return
     if sys.argv[1:] == ["jvp"]:
@@ -669,6 +728,7 @@ def main():
     jvp_fixture(edm_net)
     trigflow_fixture(edm_net, ns)
     augment_fixture(edm_net)
+    dropout_fixture(edm_net)
     teacher_sample_fixture(edm_net)
 
     print("golden fixtures written to", OUT)

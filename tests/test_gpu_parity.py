@@ -1112,3 +1112,60 @@ def test_augmentation_labels(nets, golden_dir):
             assert float((smp - fx[f"{n}/sample"]).norm() / fx[f"{n}/sample"].norm()) <= 8e-2, n
     finally:
         net.zero_grad(set_to_none=True)
+
+
+def test_training_mode_dropout(sd, golden_dir):
+    """dropout > 0 in train() mode (the SFT config's 0.13): the module draws a seed, the engine derives every block's mask from it
+    (Philox) in the forward, the backward and the forward-mode pass.  The masks are read back with fg_op_dropout_mask and handed
+    to the oracle, whose forward / autograd the HIP results must match (bf16 tolerances); eval mode and p = 0 are untouched."""
+    L = _lib.lib()
+    p = 0.13
+    net = EDMPrecond(compute_dtype="bf16", **{**KW, "dropout": p})
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev())
+    g = torch.Generator().manual_seed(11)
+    t = torch.tensor([2.2, 0.31], dtype=torch.float64)
+    x = torch.randn((2, 3, 32, 32), generator=g) * t.reshape(2, 1, 1, 1).float()
+    cond = torch.nn.functional.one_hot(torch.tensor([0, 5]), 10).float()
+    dout = torch.randn((2, 3, 32, 32), generator=g)
+    net.eval()
+    with torch.no_grad():
+        ev = net(x.to(dev()), t.to(dev()), condition=cond.to(dev()))
+    net.train()
+    torch.manual_seed(77)
+    seed = int(torch.randint(0, 2**62, (1,)).item())   # what the module will draw
+    torch.manual_seed(77)
+    out = net(x.to(dev()), t.to(dev()), condition=cond.to(dev()), fwd_pred_type="x0")
+    (out * dout.to(dev())).sum().backward()
+    assert not torch.allclose(out.detach(), ev, atol=1e-3)  # the dropout was applied
+    # the masks the engine used, block by block (NHWC flat -> NCHW)
+    enc, dec = R.layout(R.CIFAR10)
+    blocks = [b for b in enc + dec if b.kind == "block"]
+    keeps = {}
+    for i, b in enumerate(blocks):
+        m = torch.empty(2 * b.res * b.res * b.cout, device=dev())
+        _lib.check(L.fg_op_dropout_mask(m.data_ptr(), m.numel(), p, i, seed, None))
+        keeps[b.key] = m.reshape(2, b.res, b.res, b.cout).permute(0, 3, 1, 2).contiguous().cpu()
+    frac = float(torch.cat([k.reshape(-1) for k in keeps.values()]).eq(0).float().mean())
+    assert abs(frac - p) < 2e-3, frac                          # drop rate, and the survivors are scaled by 1 / (1 - p)
+    assert float(keeps[blocks[0].key].max()) == pytest.approx(1 / (1 - p), rel=1e-6)
+    names = ["model.enc.32x32_block1.conv1.weight", "model.enc.16x16_block2.norm1.weight", "model.dec.8x8_block1.conv0.weight"]
+    sdg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    with torch.enable_grad():
+        want = R.edm_precond_forward(sdg, R.CIFAR10, x, t, cond, drop_keeps=keeps)
+        want.backward(dout)
+    check(out, want, "bf16", "training-mode forward with dropout")
+    params = dict(net.named_parameters())
+    for n in names:
+        rel = float((params[n].grad.cpu() - sdg[n].grad).norm() / sdg[n].grad.norm())
+        assert rel <= 8e-2, (n, rel)
+    # the forward-mode pass sees the same masks: directional derivative along x against a finite difference of the oracle
+    torch.manual_seed(77)
+    v = torch.randn((2, 3, 32, 32), generator=g)
+    _, jv = net.jvp(x.to(dev()), t.to(dev()), v.to(dev()), torch.zeros(2, device=dev()), condition=cond.to(dev()))
+    e = 1e-2
+    with torch.no_grad():
+        fd = (R.edm_precond_forward(sd, R.CIFAR10, x + e * v, t, cond, drop_keeps=keeps)
+              - R.edm_precond_forward(sd, R.CIFAR10, x - e * v, t, cond, drop_keeps=keeps)) / (2 * e)
+    cos = float((fd * jv.cpu()).sum() / (fd.norm() * jv.cpu().norm()))
+    assert cos >= 0.99, cos

@@ -303,3 +303,18 @@ def test_oracle_augmentation_labels(golden_dir, full_sd):
     aug = torch.randn((2, 9), generator=torch.Generator().manual_seed(92))
     out = R.edm_precond_forward(full_sd, R.CIFAR10, x, fx["t"], fx["cond"], augment_labels=aug)
     assert torch.allclose(out, fx["out"], rtol=1e-4, atol=1e-5)
+
+
+def test_oracle_training_mode_dropout(golden_dir, full_sd):
+    """Where the training-mode dropout sits and how it scales (EDM/network.py:283-284): the oracle with explicit keep factors
+    against the reference in train() mode whose F.dropout was replaced by the same seeded factors (tests/golden/dropout_b2.pt)."""
+    fx = torch.load(os.path.join(golden_dir, "dropout_b2.pt"), weights_only=True)
+    p = float(fx["p"])
+    enc, dec = R.layout(R.CIFAR10)
+    blocks = [b for b in enc + dec if b.kind == "block"]
+    keeps = {b.key: (torch.rand((2, b.cout, b.res, b.res), generator=torch.Generator().manual_seed(600 + i)) >= p).float() / (1 - p)
+             for i, b in enumerate(blocks)}
+    x = torch.randn((2, 3, 32, 32), generator=torch.Generator().manual_seed(95)) * fx["t"].reshape(2, 1, 1, 1).float()
+    out = R.edm_precond_forward(full_sd, R.CIFAR10, x, fx["t"], fx["cond"], drop_keeps=keeps)
+    assert torch.allclose(out, fx["out"], rtol=1e-4, atol=1e-5)
+    assert not torch.allclose(R.edm_precond_forward(full_sd, R.CIFAR10, x, fx["t"], fx["cond"]), fx["out"], atol=1e-3)
