@@ -886,9 +886,12 @@ def test_module_under_distributed_data_parallel(nets, golden_dir):
     dout = seeded((2, 3, 32, 32), 401).to(dev())
     created = False
     if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("gloo", rank=0, world_size=1)
+        import socket
+
+        with socket.socket() as sk:  # a free port: nothing else on the box may hold a fixed one
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
         created = True
     try:
         net.zero_grad(set_to_none=True)
