@@ -179,7 +179,7 @@ int tiles_per_image(int res, int ks) { return res >= 16 ? (res / (ks == 3 ? 8 : 
 int conv_wgrad_splits(int B, int res, int cin, int cout, int ks) {
     const int blocks = (cin / WG_CI) * (cout / WG_CO);
     const int ntiles = B * tiles_per_image(res, ks);
-    int splits = (512 + blocks - 1) / blocks;  // about two workgroups per CU ...
+    int splits = 512 / blocks;  // at most two workgroups per CU in ONE round (528 workgroups would run a second, almost empty round) ...
     if (splits > ntiles / 8) splits = ntiles / 8;  // ... but at least 8 tiles per split: the partials cost HBM traffic
     if (splits < 1) splits = 1;
     return splits;
