@@ -1185,7 +1185,7 @@ size_t fg_op_conv_wgrad_workspace_bytes(int batch, int res, int cin, int cout, i
 int fg_op_conv_wgrad(const void* act, const void* dy, float* dw, int batch, int res, int cin, int cout, int ks,
                      int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     if (!conv_wgrad_supported(res, cin, cout, ks))
-        return fail(FG_EINVAL, "fg_op_conv_wgrad: unsupported shape res=%d cin=%d cout=%d ks=%d (res 8/16/32, cin %% 32, cout %% 128, ks 1/3)",
+        return fail(FG_EINVAL, "fg_op_conv_wgrad: unsupported shape res=%d cin=%d cout=%d ks=%d (res 8/16/32, cin %% 32 [k3] / 128 [k1], cout %% 128, ks 1/3)",
                     res, cin, cout, ks);
     if (batch <= 0 || !act || !dy || !dw || !workspace) return fail(FG_EINVAL, "fg_op_conv_wgrad: bad argument");
     if (workspace_bytes < conv_wgrad_workspace_bytes(batch, res, cin, cout, ks))

@@ -25,10 +25,11 @@ namespace {
 
 constexpr int WG_THREADS = 256;
 constexpr int WG_CO = 128;       // output channels per workgroup (4 waves x 32)
-constexpr int WG_CI = 32;        // input channels per workgroup
+constexpr int WG_CI = 32;        // input channels per workgroup, 3x3 kernel (nine 32x32 accumulators per wave)
+constexpr int WG_CI1 = 128;      // ... 1x1 kernel: one tap, so four 32-channel tiles share every staged dY tile (4x the MFMAs per byte)
+__host__ __device__ constexpr int wg_ci(int ks) { return ks == 1 ? WG_CI1 : WG_CI; }
 constexpr int WG_TILE = 64;      // pixels per tile = 4 MFMA k-steps of 16 (128 = 8 rows for the 3x3 kernel at width >= 16)
 constexpr int WG_DYP = 2 * WG_CO + 64;  // dY tile row pitch in bytes: 4 consecutive rows tile the 64 banks (320 = 64 mod 256)
-constexpr int WG_AP = 2 * WG_CI;        // A tile bytes per (halo) pixel
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -65,12 +66,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const __bf16*
     constexpr int HALO = HW_ * HH_;           // 108 (3x3 at W >= 16), 100 (3x3 at 8x8), 64 (1x1)
     constexpr int TAPS = KS * KS;
     constexpr int TCOLS = W / TW, TPI = (W / TH) * TCOLS;
+    constexpr int CI = wg_ci(KS), NCI = CI / 32;  // input channels per workgroup, 32-channel accumulator tiles per tap
+    constexpr int WG_AP = CI == 32 ? 64 : 2 * CI + 64;  // A tile bytes per (halo) pixel: 4 consecutive pixels tile the 64 banks
 
     __shared__ __attribute__((aligned(16))) char s_dy[TPX * WG_DYP];
     __shared__ __attribute__((aligned(16))) char s_a[HALO * WG_AP];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ci0 = blockIdx.x * WG_CI, split = blockIdx.y, cob = blockIdx.z * WG_CO;
+    const int ci0 = blockIdx.x * CI, split = blockIdx.y, cob = blockIdx.z * WG_CO;
     const int ntiles = B * TPI;
     const int t_begin = split * tiles_per_split, t_end = min(ntiles, t_begin + tiles_per_split);
 
@@ -82,9 +85,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const __bf16*
     const int a_pix = (TW == 16) ? 8 * (g >> 1) + q : (g >> 1) * HW_ + q;
     const char* const a_lane = s_a + a_pix * WG_AP + (16 * (g & 1) + 4 * p) * 2;
 
-    f32x16 acc[TAPS];
+    f32x16 acc[TAPS * NCI];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+    for (int t = 0; t < TAPS * NCI; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
@@ -100,8 +103,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const __bf16*
             const uint4 v = *reinterpret_cast<const uint4*>(dy + ((size_t)(n * W + y) * W + x) * Cout + cob + ch * 8);
             *reinterpret_cast<uint4*>(s_dy + k * WG_DYP + ch * 16) = v;
         }
-        for (int c = tid; c < HALO * 4; c += WG_THREADS) {
-            const int hp = c >> 2, ch = c & 3;
+        for (int c = tid; c < HALO * (CI / 8); c += WG_THREADS) {
+            const int hp = c / (CI / 8), ch = c % (CI / 8);
             const int y = row0 + hp / HW_ - PAD, x = col0 + hp % HW_ - PAD;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (y >= 0 && y < W && x >= 0 && x < W)
@@ -139,8 +142,11 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const __bf16*
                 const int ky = tap / KS, kx = tap % KS;
                 // first halo pixel of the k-step for this tap (compile-time), rows of the tile are HW_ halo pixels apart
                 const int hp0 = (TW == 16) ? (s + ky) * HW_ + kx : (2 * s + ky) * HW_ + kx;
-                const Frag8<__bf16> fb = tr_frag(a_lane + hp0 * WG_AP, a_lane + (hp0 + 4) * WG_AP);
-                mma16(acc[tap], fa, fb);
+#pragma unroll
+                for (int nt = 0; nt < NCI; ++nt) {
+                    const Frag8<__bf16> fb = tr_frag(a_lane + hp0 * WG_AP + nt * 64, a_lane + (hp0 + 4) * WG_AP + nt * 64);
+                    mma16(acc[tap * NCI + nt], fa, fb);
+                }
             }
         }
         __syncthreads();
@@ -152,10 +158,12 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const __bf16*
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int co = cob + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
-            dst[((size_t)tap * Cout + co) * Cin + ci] = acc[tap][i];
-        }
+        for (int nt = 0; nt < NCI; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = cob + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
+                dst[((size_t)tap * Cout + co) * Cin + ci + 32 * nt] = acc[tap * NCI + nt][i];
+            }
 }
 
 // dW[co][ci][tap] (+)= sum over splits of partial[split][tap][co][ci], fixed order; thread i walks the partial layout
@@ -177,7 +185,7 @@ int tiles_per_image(int res, int ks) { return res >= 16 ? (res / (ks == 3 ? 8 : 
 }  // namespace
 
 int conv_wgrad_splits(int B, int res, int cin, int cout, int ks) {
-    const int blocks = (cin / WG_CI) * (cout / WG_CO);
+    const int blocks = (cin / wg_ci(ks)) * (cout / WG_CO);
     const int ntiles = B * tiles_per_image(res, ks);
     int splits = 512 / blocks;  // at most two workgroups per CU in ONE round (528 workgroups would run a second, almost empty round) ...
     if (splits > ntiles / 8) splits = ntiles / 8;  // ... but at least 8 tiles per split: the partials cost HBM traffic
@@ -190,7 +198,7 @@ size_t conv_wgrad_workspace_bytes(int B, int res, int cin, int cout, int ks) {
 }
 
 int conv_wgrad_supported(int res, int cin, int cout, int ks) {
-    return (res == 8 || res == 16 || res == 32) && cin > 0 && cin % WG_CI == 0 && cout > 0 && cout % WG_CO == 0 && (ks == 1 || ks == 3);
+    return (res == 8 || res == 16 || res == 32) && cin > 0 && (ks == 1 || ks == 3) && cin % wg_ci(ks) == 0 && cout > 0 && cout % WG_CO == 0;
 }
 
 int launch_conv_wgrad(const void* act, const void* dy, float* dw, int B, int res, int cin, int cout, int ks, int accumulate,
@@ -199,7 +207,7 @@ int launch_conv_wgrad(const void* act, const void* dy, float* dw, int B, int res
     const int splits = conv_wgrad_splits(B, res, cin, cout, ks);
     const int ntiles = B * tiles_per_image(res, ks);
     const int tps = (ntiles + splits - 1) / splits;
-    dim3 grid(cin / WG_CI, splits, cout / WG_CO);
+    dim3 grid(cin / wg_ci(ks), splits, cout / WG_CO);
     const __bf16* a = (const __bf16*)act;
     const __bf16* d = (const __bf16*)dy;
     float* part = (float*)workspace;

@@ -171,7 +171,7 @@ int fg_op_x0_to_eps(const float* xt, const float* x0, double t, int schedule, fl
  * updates: dw[co][ci][ky][kx] (+)= sum_{n,y,x} dy[n,y,x,co] * act[n,y+ky-ks/2,x+kx-ks/2,ci], zero padding.
  * act [B,res,res,cin] and dy [B,res,res,cout] are NHWC bf16 (the conv's input operand and its output gradient),
  * dw is fp32 OIHW [cout,cin,ks,ks]; accumulate != 0 adds to dw.  Deterministic (fixed-order split-K reduction through
- * the workspace).  res in {8,16,32}, cin % 32 == 0, cout % 128 == 0, ks in {1,3}. */
+ * the workspace).  res in {8,16,32}, cin % 32 == 0 (ks = 3) / cin % 128 == 0 (ks = 1), cout % 128 == 0, ks in {1,3}. */
 size_t fg_op_conv_wgrad_workspace_bytes(int batch, int res, int cin, int cout, int ks);
 int fg_op_conv_wgrad(const void* act, const void* dy, float* dw, int batch, int res, int cin, int cout, int ks,
                      int accumulate, void* workspace, size_t workspace_bytes, void* stream);

@@ -182,7 +182,7 @@ def backward_fixture(edm_net):
     """Training-step pieces, recorded from the reference's own modules under autograd: the weight gradient
     of `Conv2d` (EDM/network.py:54-126) for a 3x3 and a 1x1 kernel."""
     fx = {}
-    for ks, cin, cout, res in ((3, 64, 128, 16), (1, 32, 128, 8)):
+    for ks, cin, cout, res in ((3, 64, 128, 16), (1, 128, 128, 8)):
         conv = edm_net.Conv2d(in_channels=cin, out_channels=cout, kernel=ks)
         with torch.no_grad():
             conv.weight.copy_(seeded(tuple(conv.weight.shape), 51 + ks) * 0.05)

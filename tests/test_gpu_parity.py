@@ -553,7 +553,7 @@ def _wgrad(act_nchw, dy_nchw, ks, accumulate_into=None):
 
 
 @pytest.mark.parametrize("B,res,cin,cout,ks", [(3, 32, 64, 128, 3), (2, 16, 96, 256, 3), (5, 8, 32, 128, 3), (1, 8, 64, 256, 3),
-                                               (3, 32, 32, 256, 1), (2, 16, 64, 128, 1), (4, 8, 96, 128, 1)])
+                                               (3, 32, 128, 256, 1), (2, 16, 256, 128, 1), (4, 8, 384, 128, 1)])
 def test_conv_wgrad_against_oracle(B, res, cin, cout, ks):
     """Weight gradient on the matrix cores (bf16 operands, fp32 accumulation) vs autograd on the same bf16-rounded operands
     in fp32: only the summation order differs — max |err| <= 2e-5 of the largest entry."""
