@@ -44,7 +44,7 @@ int conv_stat_slots(int W);
 // wave-specialised persistent kernel for the dominant bf16 3x3 shapes (conv_ws.hip); launch_conv_fused dispatches to it
 bool conv_ws_supported(int dtype, int ks, int pro, int res, int outmode, const ConvArgs& a);
 bool conv_ws_enabled();
-int launch_conv_ws(int res, const ConvArgs& a, hipStream_t stream, bool prepare_only);
+int launch_conv_ws(int res, const ConvArgs& a, hipStream_t stream, bool prepare_only, int pro = PRO_GN_SILU);
 bool conv_ws_shape_ok(int dtype, int cout, int cin, int res);
 int launch_pack_conv_weights_ws(const float* w_oihw, void* wpack_ws, int cout, int cin, hipStream_t stream);
 int launch_conv_ws_debug(const ConvArgs& a, int abl, hipStream_t stream);  // ablation builds of the 32x32 shape

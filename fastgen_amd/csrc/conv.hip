@@ -591,7 +591,7 @@ int launch_conv_fused(int dtype, int ks, int pro, int res, int outmode, const Co
     if (res == RES_UP && (2 * a.Hs != a.H || 2 * a.Ws != a.W)) return (int)hipErrorInvalidValue;
     if (pro != PRO_NONE && !a.ab) return (int)hipErrorInvalidValue;
     if (outmode == OUT_QKV && (a.Cout != 768 || a.W > 16)) return (int)hipErrorInvalidValue;
-    if (conv_ws_enabled() && conv_ws_supported(dtype, ks, pro, res, outmode, a)) return launch_conv_ws(res, a, stream, false);
+    if (conv_ws_enabled() && conv_ws_supported(dtype, ks, pro, res, outmode, a)) return launch_conv_ws(res, a, stream, false, pro);
     return dtype ? launch_t<__bf16>(ks, pro, res, outmode, a, stream) : launch_t<float>(ks, pro, res, outmode, a, stream);
 }
 

@@ -66,7 +66,9 @@ __device__ __forceinline__ void mma32(f32x4& acc, const Frag8<__bf16>& a, const 
 
 // ABL: compile-time ablation mask for scripts/conv_ablate.py (0 in production): 1 no staging, 2 no retire (drain),
 // 4 no accumulator hand-off, 8 no weight refill, 16 no MFMA / A reads
-template <int RES, int LOGW, int ABL = 0, int WS_NQ = 4>
+// PRO: PRO_GN_SILU, or PRO_NONE — the operand is staged as it lies (data gradients: the same conv on dY with the transposed,
+// flipped weights; tangent convolutions of the forward-mode pass)
+template <int RES, int LOGW, int ABL = 0, int WS_NQ = 4, int PRO = PRO_GN_SILU>
 __global__ __launch_bounds__(WS_NTHR) void conv3_ws_kernel(const ConvArgs a, const int ntiles) {
     constexpr int WS_QJ = 32 / WS_NQ;  // quads per lane and part
     typedef __bf16 T;
@@ -236,6 +238,7 @@ __global__ __launch_bounds__(WS_NTHR) void conv3_ws_kernel(const ConvArgs a, con
                                  : reinterpret_cast<const char*>(src2) + (c32 * WS_KC - a.C1) * 2;
 #pragma unroll
         for (int i = 0; i < 3; ++i) st.raw[i] = load_frag(reinterpret_cast<const T*>(base + (first ? off1[i] : off2[i])));
+        if (PRO == PRO_NONE) return;
         const float2* p = abn + c32 * WS_KC + oct * 8;
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
@@ -247,11 +250,13 @@ __global__ __launch_bounds__(WS_NTHR) void conv3_ws_kernel(const ConvArgs a, con
     auto stage_store = [&](const Staged& st, char* abuf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            float v[8];
-            widen8(st.raw[i], v);
-            bf16x8 pk;
+            bf16x8 pk = st.raw[i].v;
+            if (PRO != PRO_NONE) {
+                float v[8];
+                widen8(st.raw[i], v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pk[j] = (__bf16)silu_f<true>(fmaf(v[j], st.ab[j].x, st.ab[j].y));
+                for (int j = 0; j < 8; ++j) pk[j] = (__bf16)silu_f<true>(fmaf(v[j], st.ab[j].x, st.ab[j].y));
+            }
             // out-of-image halo pixels are zero: select on the four packed dwords, not on the eight floats
             typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
             u32x4 w = __builtin_bit_cast(u32x4, pk);
@@ -401,10 +406,10 @@ __global__ void pack_conv_weights_ws_kernel(const float* __restrict__ w, __bf16*
 
 int g_ws_cus = 0;
 
-template <int RES, int LOGW, int ABL = 0, int NQ = 4>
+template <int RES, int LOGW, int ABL = 0, int NQ = 4, int PRO = PRO_GN_SILU>
 int launch_ws_one(const ConvArgs& a, hipStream_t stream, bool prepare_only) {
     using G = WsGeom<LOGW>;
-    auto kern = conv3_ws_kernel<RES, LOGW, ABL, NQ>;
+    auto kern = conv3_ws_kernel<RES, LOGW, ABL, NQ, PRO>;
     const size_t lds = ws_lds_bytes();
     static bool attr_done = false;
     if (!attr_done) {
@@ -433,12 +438,21 @@ bool conv_ws_supported(int dtype, int ks, int pro, int res, int outmode, const C
     // the staged loads use 32-bit byte offsets into each source tensor
     const size_t src_bytes = (size_t)a.B * a.Hs * a.Ws * (size_t)(a.C1 > a.C2 ? a.C1 : a.C2) * 2;
     if (src_bytes >= (1ull << 32)) return false;
+    if (pro == PRO_NONE)  // operand taken as it lies: no resampling, at least 8 steps per tile
+        return dtype == 1 && ks == 3 && res == RES_NONE && outmode == OUT_NHWC && (a.W == 32 || a.W == 16) && a.H == a.W &&
+               a.Hs == a.H && a.Ws == a.W && a.Cout == 256 && (cin % 64) == 0 && cin / WS_KC >= 8 && (a.C1 % WS_KC) == 0 &&
+               a.wpack_ws != nullptr;
     return dtype == 1 && ks == 3 && pro == PRO_GN_SILU && (res == RES_NONE || res == RES_UP) && outmode == OUT_NHWC &&
            (a.W == 32 || a.W == 16) && a.H == a.W && a.Cout == 256 && (cin % 64) == 0 && cin / WS_KC >= 4 &&
            (a.C1 % WS_KC) == 0 && a.ab != nullptr && a.wpack_ws != nullptr;
 }
 
-int launch_conv_ws(int res, const ConvArgs& a, hipStream_t stream, bool prepare_only) {
+int launch_conv_ws(int res, const ConvArgs& a, hipStream_t stream, bool prepare_only, int pro) {
+    if (pro == PRO_NONE) {
+        if (res != RES_NONE || (a.C1 + a.C2) / WS_KC < 8) return (int)hipErrorInvalidValue;
+        return a.W == 32 ? launch_ws_one<RES_NONE, 5, 0, 4, PRO_NONE>(a, stream, prepare_only)
+                         : launch_ws_one<RES_NONE, 4, 0, 4, PRO_NONE>(a, stream, prepare_only);
+    }
     if ((a.C1 + a.C2) / WS_KC == 4 || (prepare_only && a.C1 == -128)) {
         // 128 input channels: four steps per tile, retire in two parts (the U-Net's first block, 32x32, no resampling)
         if (res != RES_NONE || a.W != 32) return (int)hipErrorInvalidValue;

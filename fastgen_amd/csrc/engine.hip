@@ -149,6 +149,7 @@ struct fg_edm {
     // data-gradient weights (transposed, flipped, packed), built on first use per weight version (fg_edm_pack_weights)
     struct DgradW {
         void* packed = nullptr;
+        void* packed_ws = nullptr;  // conv_ws.hip layout (3x3, 256 -> 256 at 32x32 / 16x16)
         uint64_t epoch = 0;
     };
     std::map<const float*, DgradW> dgrad_cache;
