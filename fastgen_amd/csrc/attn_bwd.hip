@@ -18,8 +18,14 @@ template <bool OUT_BF16>
 __global__ __launch_bounds__(64) void nt_gemm_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ Bm, void* __restrict__ C,
                                                       int M, int N, int K, float scale) {
     const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
-    const size_t b = blockIdx.z;
+    // Workgroup L (x fastest) runs on XCD L % 8: with N / 32 = 8 every XCD would own one column of tiles of EVERY batch element and
+    // fetch all of A (measured 4.5x the operands).  Re-deal so that the tiles of one batch element sit side by side on one XCD.
+    const int tpb = (int)(gridDim.x * gridDim.y), T = tpb * (int)gridDim.z;
+    const int L = (int)blockIdx.x + (int)gridDim.x * ((int)blockIdx.y + (int)gridDim.y * (int)blockIdx.z);
+    const int v = (L & 7) * (T >> 3) + min(L & 7, T & 7) + (L >> 3);
+    const size_t b = v / tpb;
+    const int tile = v - (int)b * tpb;
+    const int n0 = (tile % (int)gridDim.x) * 32, m0 = (tile / (int)gridDim.x) * 32;
     const __bf16* ap = A + (b * M + m0 + m) * K + 8 * h;
     const __bf16* bp = Bm + (b * N + n0 + m) * K + 8 * h;
     f32x16 acc;

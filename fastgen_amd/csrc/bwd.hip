@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float2* __restr
     const int cl = threadIdx.x & 63, nl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     float g = 0.f, b = 0.f;
     if (c < C)
-        for (int n = nl; n < B; n += 4) {
+#pragma unroll 8
+        for (int n = nl; n < B; n += 4) {  // unrolled: eight loads in flight per thread, the sum keeps its order
             const float2 p = P[(size_t)n * C + c];
             b += p.x;
             g += p.y;
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(256) void batchsum_add_kernel(const float* __restri
     const int cl = threadIdx.x & 63, nl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     float a = 0.f;
     if (c < C)
+#pragma unroll 8
         for (int n = nl; n < B; n += 4) a += in[(size_t)n * C + c];
     sa[nl][cl] = a;
     __syncthreads();
@@ -422,7 +424,16 @@ __global__ void linear_wgrad_kernel(const float* __restrict__ dy, const float* _
     if (i >= C * K) return;
     const int c = i / K, k = i - c * K;
     float a = 0.f;
-    for (int b = 0; b < B; ++b) a = fmaf(dy[(size_t)b * dy_stride + c], x[(size_t)b * K + k], a);
+    int b = 0;
+    // eight rows' loads in flight at once (the sum keeps its order): one dependent load per iteration made this latency-bound
+    for (; b + 8 <= B; b += 8) {
+        float d[8], v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = dy[(size_t)(b + j) * dy_stride + c], v[j] = x[(size_t)(b + j) * K + k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a = fmaf(d[j], v[j], a);
+    }
+    for (; b < B; ++b) a = fmaf(dy[(size_t)b * dy_stride + c], x[(size_t)b * K + k], a);
     dw[i] += a * scale;
 }
 
