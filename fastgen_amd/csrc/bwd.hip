@@ -357,7 +357,15 @@ __global__ void affine_dgrad_kernel(const float* __restrict__ dtemb, const float
     if (i >= B * K) return;
     const int b = i / K, k = i - b * K;
     float a = 0.f;
-    for (int c = 0; c < C; ++c) a = fmaf(dtemb[(size_t)b * C + c], w[(size_t)c * K + k], a);
+    int c = 0;
+    for (; c + 8 <= C; c += 8) {  // eight rows of w in flight per thread (the sum keeps its order)
+        float d[8], v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = dtemb[(size_t)b * C + c + j], v[j] = w[(size_t)(c + j) * K + k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a = fmaf(d[j], v[j], a);
+    }
+    for (; c < C; ++c) a = fmaf(dtemb[(size_t)b * C + c], w[(size_t)c * K + k], a);
     demb[i] += a;
 }
 

@@ -12,7 +12,8 @@ KW = dict(img_resolution=32, img_channels=3, label_dim=10, model_type="SongUNet"
           channel_mult=[2, 2, 2], num_blocks=4, attn_resolutions=[16], embedding_type="positional", encoder_type="standard",
           decoder_type="standard", resample_filter=[1, 1], dropout=0.0)
 net = EDMPrecond(compute_dtype="bf16", **KW).randomize_parameters_(seed=1).cuda().eval()
-for B in [int(a) for a in sys.argv[1:]] or [64, 128]:
+ONLY = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]  # e.g. --only=backward: time (profile) that leg alone
+for B in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [64, 128]:
     x = torch.randn(B, 3, 32, 32, device="cuda") * 3
     t = torch.full((B,), 2.5, dtype=torch.float64, device="cuda")
     cond = torch.nn.functional.one_hot(torch.arange(B, device="cuda") % 10, 10).float()
@@ -31,6 +32,8 @@ for B in [int(a) for a in sys.argv[1:]] or [64, 128]:
         return net.jvp(x, t, vx, torch.ones(B, device="cuda"), condition=cond)
 
     for name, fn, mult in (("forward", fwd, 1.0), ("forward + backward", fwd_bwd, 3.0), ("forward + jvp (fg_edm_jvp)", fwd_jvp, 2.0)):
+        if ONLY and not any(o in name for o in ONLY):
+            continue
         for _ in range(2):
             fn()
         torch.cuda.synchronize()
