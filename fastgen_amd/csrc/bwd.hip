@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void gn_act_kernel(const __bf16* __restrict__ 
                 float t = v[j];
                 if (MODE != 2) {
                     t = fmaf(t, abp[j].x, abp[j].y);
-                    if (MODE == 0) t = silu_fwd(t);
+                    if (MODE == 0) t = silu_f<true>(t);  // the bf16 conv prologue's SiLU, bit for bit: the kept forward's conv1 consumes this tensor
                 }
                 o[j] += t;
             }

@@ -93,7 +93,7 @@ struct Workspace {
     float *coef, *emb0, *emb1, *emb, *temb;
     float2 *ab0, *ab1, *ab2;
     float2 *mr0 = nullptr, *mr1 = nullptr, *mr2 = nullptr;  // {mean, rstd} of norm0 / norm1 / norm2, kept when a backward pass follows
-    void* a1d = nullptr;   // training forward with dropout: where the block's dropped conv1 operand goes
+    void* a1d = nullptr;   // kept (training) forward: where the block's conv1 operand (after dropout, if on) goes
     DropArgs drop;         // ... and its dropout parameters (p == 0: off)
     std::vector<Act> skip;  // encoder outputs
     Act xa, xb, h, xattn;
@@ -111,7 +111,7 @@ struct BlockStash {
     void* h = nullptr;                      // conv0 output
     float2 *ab0 = nullptr, *ab1 = nullptr, *ab2 = nullptr, *mr0 = nullptr, *mr1 = nullptr, *mr2 = nullptr;
     void *xattn = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *aout = nullptr;  // attention blocks
-    void* a1d = nullptr;   // conv1's operand silu(norm1(h)) * keep, materialised when dropout is on
+    void* a1d = nullptr;   // conv1's operand silu(norm1(h)) [* keep], materialised by the kept forward
     uint32_t index = 0;    // position in fg_edm::blocks: the block's Philox stream
 };
 struct TrainStash {
@@ -512,11 +512,11 @@ int run_block(fg_edm* h, const Block& b, const Act& x1, int c1, const Act& x2, i
     d.src1 = w.h.p; d.C1 = b.cout; d.Hs = d.Ws = d.H = d.W = b.res_out; d.B = B;
     d.ab = w.ab1; d.wpack = b.p_conv1; d.wpack_ws = b.p_conv1_ws; d.bias = h->P(b.conv1_b);
     d.resid = resid; d.scale = kSkipScale; d.out = x_mid.p; d.Cout = b.cout; d.stats = x_mid.st;
-    if (w.drop.p > 0.f && w.a1d) {
-        // training mode with dropout (EDM/network.py:283-284): the operand silu(norm1(h)) * keep is materialised once (the
-        // backward's weight gradient contracts with the same tensor) and the conv runs without a prologue
+    if (w.a1d) {
+        // kept (training) forward: the operand silu(norm1(h)) [* keep with dropout, EDM/network.py:283-284] is materialised once —
+        // the backward's weight gradient contracts with the same tensor — and the conv runs without a prologue
         HIP_TRY(launch_gn_act(0, w.h.p, b.cout, nullptr, 0, w.ab1, w.a1d, B, b.res_out, 0, s, w.drop));
-        d.src1 = w.a1d; d.ab = nullptr; d.wpack_ws = nullptr;
+        d.src1 = w.a1d; d.ab = nullptr;
         HIP_TRY(conv_launch(h, 3, PRO_NONE, RES_NONE, OUT_NHWC, d, s));
     } else {
         HIP_TRY(conv_launch(h, 3, PRO_GN_SILU, RES_NONE, OUT_NHWC, d, s));
