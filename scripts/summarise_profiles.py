@@ -6,7 +6,7 @@ from collections import defaultdict
 
 out, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOM = "conv3_ws_kernel<0, 5, 0, 4>"  # 3x3, 256 out, 32x32, no resampling (wave-specialised)
+DOM = "conv3_ws_kernel<0, 5, 0, 4, 2>"  # 3x3, 256 out, 32x32, no resampling (wave-specialised)
 
 
 def short(n):
