@@ -20,6 +20,34 @@ __device__ __forceinline__ float silu_grad(float y) {
     const float s = 1.0f / (1.0f + expf(-y));
     return s * fmaf(y, 1.0f - s, 1.0f);
 }
+// the same through v_exp_f32 / v_rcp_f32 (about 1 ulp each) for the bf16 streaming kernels, which the exact version made VALU-bound
+__device__ __forceinline__ float silu_grad_fast(float y) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * y));
+    return s * fmaf(y, 1.0f - s, 1.0f);
+}
+// Per-octet coefficients of the apply kernels: the 8 channels' {a, b} as four 16-byte loads, and the (at most two) groups an octet
+// touches — {mean, rstd} and {S1, S2} of group g0 and its successor — instead of 24 scalar loads and 8 integer divisions.
+// Requires cpg == 4 or cpg >= 8 (every width of this U-Net: 4, 8, 12, 16); `sel[j]` says which of the two groups channel j is in.
+struct OctCoef {
+    float2 t[8];
+    float2 m[2], s[2];
+    bool hi[8];
+};
+__device__ __forceinline__ void load_oct_coef(OctCoef& k, const float2* __restrict__ ab, const float2* __restrict__ mr,
+                                              const float2* __restrict__ S, int n, int C, int groups, int cpg, int c0) {
+    const f32x4* q = reinterpret_cast<const f32x4*>(ab + (size_t)n * C + c0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 v = q[j];
+        k.t[2 * j] = make_float2(v[0], v[1]);
+        k.t[2 * j + 1] = make_float2(v[2], v[3]);
+    }
+    const int g0 = c0 / cpg, rem = c0 - g0 * cpg, g1 = min(g0 + 1, groups - 1);
+    k.m[0] = mr[(size_t)n * groups + g0], k.m[1] = mr[(size_t)n * groups + g1];
+    if (S) k.s[0] = S[(size_t)n * groups + g0], k.s[1] = S[(size_t)n * groups + g1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k.hi[j] = rem + j >= cpg;
+}
 
 __device__ __forceinline__ void load8bf(const __bf16* p, float (&v)[8]) {
     const bf16x8 q = *reinterpret_cast<const bf16x8*>(p);
@@ -179,7 +207,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const __bf16* __rest
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float dy = MODE == 0 ? dv[j] * silu_grad(fmaf(xv[j], a[j], b[j])) : dv[j];
+                const float dy = MODE == 0 ? dv[j] * silu_grad_fast(fmaf(xv[j], a[j], b[j])) : dv[j];
                 p1[j] += dy;
                 p2[j] = fmaf(dy, (xv[j] - mean[j]) * rstd[j], p2[j]);
             }
@@ -259,13 +287,14 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const __bf16* __restr
         }
         if (add) fetch_res(add, Ca, n, p, c0, res, rm, av);
         float o[8];
+        OctCoef k;
+        load_oct_coef(k, ab, mr, S, n, C, groups, cpg, c0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = c0 + j, g = c / cpg;
-            const float2 t = ab[(size_t)n * C + c];
-            const float2 m = mr[(size_t)n * groups + g];
-            const float2 s = S[(size_t)n * groups + g];
-            const float dy = MODE == 0 ? dv[j] * silu_grad(fmaf(xv[j], t.x, t.y)) : dv[j];
+            const float2 t = k.t[j];
+            const float2 m = k.hi[j] ? k.m[1] : k.m[0];
+            const float2 s = k.hi[j] ? k.s[1] : k.s[0];
+            const float dy = MODE == 0 ? dv[j] * silu_grad_fast(fmaf(xv[j], t.x, t.y)) : dv[j];
             const float xhat = (xv[j] - m.x) * m.y;
             float r = fmaf(t.x, dy, -m.y * fmaf(xhat, s.y, s.x) * inv_m);
             if (add) r = fmaf(add_scale, av[j], r);
@@ -497,15 +526,16 @@ __global__ __launch_bounds__(256) void gn_jvp_apply_kernel(const __bf16* __restr
         float xv[8], dv[8], o[8];
         load8bf(cat_ptr(x1, C1, x2, C2, pix, c0), xv);
         load8bf(xd + pix * Cd + c0, dv);
+        OctCoef k;
+        load_oct_coef(k, ab, mr, S, n, C, groups, cpg, c0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = c0 + j, g = c / cpg;
-            const float2 t = ab[(size_t)n * C + c];
-            const float2 m = mr[(size_t)n * groups + g];
-            const float2 s = S[(size_t)n * groups + g];
+            const float2 t = k.t[j];
+            const float2 m = k.hi[j] ? k.m[1] : k.m[0];
+            const float2 s = k.hi[j] ? k.s[1] : k.s[0];
             const float xhat = (xv[j] - m.x) * m.y;
             float r = t.x * (dv[j] - fmaf(xhat, s.y, s.x) * inv_m);
-            if (MODE == 0) r *= silu_grad(fmaf(xv[j], t.x, t.y));
+            if (MODE == 0) r *= silu_grad_fast(fmaf(xv[j], t.x, t.y));
             o[j] = r;
         }
         if (drop.p > 0.f) {
@@ -631,6 +661,7 @@ int launch_gn_bwd(int mode, const void* x1, int c1, const void* x2, int c2, cons
     const int s1 = dx2 ? c1 : C, s2 = dx2 ? c2 : C;
     if ((c1 % 8) || (c2 % 8) || C < 16) return (int)hipErrorInvalidValue;
     const int groups = C / 4 < 32 ? C / 4 : 32;
+    if (C / groups != 4 && C / groups < 8) return (int)hipErrorInvalidValue;  // load_oct_coef: an octet spans at most two groups
     dim3 rg((C + 63) / 64, B);
     const __bf16 *X1 = (const __bf16*)x1, *X2 = (const __bf16*)x2, *D = (const __bf16*)dact, *A = (const __bf16*)add;
     if (mode == 0)
@@ -730,6 +761,10 @@ int launch_gn_jvp(int mode, const void* x1, int c1, const void* x2, int c2, cons
                   float2* P, float2* S, void* out, int B, int res, hipStream_t s, DropArgs drop) {
     const int C = c1 + c2, hw = res * res;
     if ((c1 % 8) || (c2 % 8) || C < 16) return (int)hipErrorInvalidValue;
+    {
+        const int groups = C / 4 < 32 ? C / 4 : 32;
+        if (C / groups != 4 && C / groups < 8) return (int)hipErrorInvalidValue;  // load_oct_coef
+    }
     const __bf16 *X1 = (const __bf16*)x1, *X2 = (const __bf16*)x2, *D = (const __bf16*)xd;
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<1>, dim3((C + 63) / 64, B), dim3(256), 0, s, X1, c1, X2, c2, D, C, ab, mr, P, res, 0, DropArgs{});
     hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(B), dim3(32), 0, s, P, (const float*)nullptr, S, C);
