@@ -239,15 +239,33 @@ __global__ void gn_bwd_group_kernel(const float2* __restrict__ P, const float* _
 }
 
 // ---- dgamma[c] += sum_n P2, dbeta[c] += sum_n P1 (fixed order) ---------------------------------------------------------------
-// 64 channels x 4 batch lanes per workgroup: the batch loop is B/4 deep, combined in a fixed order
-__global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float2* __restrict__ P, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int B, int C) {
+// 64 channels x 4 batch lanes per workgroup: the batch loop is B/4 deep (eight loads in flight per thread), combined in a fixed
+// order.  Lives in the second half of gn_bwd_group_param_kernel:
+// both in ONE launch (workgroups [0, B): group sums of image n; the rest: 64 channels' parameter sums): they only
+// depend on P, and a launch of its own costs each of these tiny kernels ~5 us on the stream's critical path.
+__global__ __launch_bounds__(256) void gn_bwd_group_param_kernel(const float2* __restrict__ P, const float* __restrict__ gamma,
+                                                                 float2* __restrict__ S, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, int B, int C) {
+    if ((int)blockIdx.x < B) {
+        const int groups = min(32, C / 4), cpg = C / groups;
+        const int n = blockIdx.x, g = threadIdx.x;
+        if (g >= groups) return;
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            const float2 p = P[(size_t)n * C + c];
+            const float gm = gamma ? gamma[c] : 1.0f;
+            s1 = fmaf(gm, p.x, s1);
+            s2 = fmaf(gm, p.y, s2);
+        }
+        S[(size_t)n * groups + g] = make_float2(s1, s2);
+        return;
+    }
     __shared__ float sg[4][64], sb[4][64];
-    const int cl = threadIdx.x & 63, nl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    const int cl = threadIdx.x & 63, nl = threadIdx.x >> 6, c = ((int)blockIdx.x - B) * 64 + cl;
     float g = 0.f, b = 0.f;
     if (c < C)
 #pragma unroll 8
-        for (int n = nl; n < B; n += 4) {  // unrolled: eight loads in flight per thread, the sum keeps its order
+        for (int n = nl; n < B; n += 4) {
             const float2 p = P[(size_t)n * C + c];
             b += p.x;
             g += p.y;
@@ -668,8 +686,10 @@ int launch_gn_bwd(int mode, const void* x1, int c1, const void* x2, int c2, cons
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<0>, rg, dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, P, res, rm, drop);
     else
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<1>, rg, dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, P, res, rm, drop);
-    hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(B), dim3(32), 0, s, P, gamma, S, C);
-    if (dgamma || dbeta) hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 63) / 64), dim3(256), 0, s, P, dgamma, dbeta, B, C);
+    if (dgamma || dbeta)
+        hipLaunchKernelGGL(gn_bwd_group_param_kernel, dim3(B + (C + 63) / 64), dim3(256), 0, s, P, gamma, S, dgamma, dbeta, B, C);
+    else
+        hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(B), dim3(32), 0, s, P, gamma, S, C);
     const int64_t total = (int64_t)B * hw * (C / 8);
     if (mode == 0)
         hipLaunchKernelGGL(gn_bwd_apply_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, S, A, ca, add_scale, d1, s1, d2, s2, accumulate, total, res, rm, drop);
