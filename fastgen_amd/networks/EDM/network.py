@@ -76,6 +76,9 @@ class _EDMForwardFn(torch.autograd.Function):
     def forward(ctx, net, x32, t64, r64, labels, taps_aug, early, *weights):
         taps, aug, drop = taps_aug
         ctx.aug, ctx.drop = aug, drop
+        # outputs nothing depends on (DMD2 detaches the teacher's prediction and keeps its taps) arrive in backward as None, not as
+        # zero tensors: the backward then leaves the decoder alone
+        ctx.set_materialize_grads(False)
         dev, B = x32.device, x32.shape[0]
         L = _lib.lib()
         dt, h = net._engine(dev)
@@ -140,8 +143,6 @@ class _EDMForwardFn(torch.autograd.Function):
         d32 = None
         if d_out is not None:
             d32 = d_out.detach().to(torch.float32).contiguous()
-        elif not ctx.early:
-            d32 = torch.zeros_like(x32)  # only the feature taps carry gradient
         dptrs = (ctypes.c_void_p * max(ctx.ntap, 1))()
         any_feat = False
         for i, g in zip(ctx.taps, douts):
@@ -150,8 +151,12 @@ class _EDMForwardFn(torch.autograd.Function):
                 keep.append(g32)
                 dptrs[i] = g32.data_ptr()
                 any_feat = True
+        if d32 is None and not ctx.early and not any_feat:
+            d32 = torch.zeros_like(x32)  # nothing carries gradient (autograd does not normally call us then)
+        # d32 None here: only the feature taps carry gradient (DMD2's GAN branch detaches the teacher's output, dmd2.py:137-146) —
+        # the engine then differentiates the encoder alone, as after an early return
         dx = torch.empty_like(x32) if ctx.needs_input_grad[1] else None
-        scratch_out = None if ctx.early else torch.empty_like(x32)
+        scratch_out = None if d32 is None else torch.empty_like(x32)
         try:
             for (n, _), g in zip(named, grads):
                 if g is not None:

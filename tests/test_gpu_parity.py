@@ -830,6 +830,18 @@ def test_module_autograd_feature_taps_and_input_gradient(nets, golden_dir):
         torch.autograd.backward([o, fe[0]], [dout, dfs[2]])
         assert rel(xg.grad, fx["gan/dx_both"]) <= 8e-2
         assert rel(smp(params[fx["gan/probe_names"][0]].grad), fx["gan/both/probe0/sample"]) <= 8e-2
+        # (d) DMD2's generator GAN loss as it is written (dmd2.py:137-146): the full forward returns prediction AND taps, the
+        # prediction is detached, only the taps carry gradient -> the same gradients as after the early return, and the decoder
+        # is not differentiated at all
+        net.zero_grad(set_to_none=True)
+        xg = x0.clone().to(dev()).requires_grad_(True)
+        o, fe = net(xg, t, condition=cond, feature_indices={0, 1, 2}, fwd_pred_type="x0")
+        torch.autograd.backward(fe, dfs)
+        assert rel(xg.grad, fx["gan/dx_early"]) <= 8e-2, rel(xg.grad, fx["gan/dx_early"])
+        for n in fx["gan/probe_names"]:
+            assert rel(smp(params[n].grad), fx[f"gan/early/{n}/sample"]) <= 8e-2, n
+        g = params["model.dec.8x8_in0.conv0.weight"].grad
+        assert g is None or float(g.abs().max()) == 0.0
     finally:
         net.requires_grad_(True)
         net.zero_grad(set_to_none=True)
