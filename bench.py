@@ -28,7 +28,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GFLOP_PER_IMAGE_FWD = 42.383  # BASELINE.md section 2 (conv 42.034 + attention 0.340 + linear 0.009), 2*MAC
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md:41-43
+# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md:41-43; bf16x3 issues three bf16 MFMAs per algorithmic product
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}
 EDM_CIFAR10 = dict(img_resolution=32, img_channels=3, label_dim=10, sigma_shift=0.0, sigma_data=0.5,
                    model_type="SongUNet", augment_dim=9, model_channels=128, channel_mult=[2, 2, 2],
                    channel_mult_noise=1, embedding_type="positional", encoder_type="standard",
@@ -136,7 +137,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="images per GPU per step")
     ap.add_argument("--sample-steps", type=int, default=4)
-    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--dtype", choices=["bf16x3", "fp32", "bf16"], default="bf16x3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
@@ -159,7 +160,7 @@ def main():
 
     # random-init weights of the named architecture; seeded N(0, 1/fan_in) so activations stay O(1) (the reference's
     # default init scales the residual branches by 1e-5, which makes the data trivial)
-    net = EDMPrecond(**EDM_CIFAR10).randomize_parameters_(seed=1234).to(dev).eval()
+    net = EDMPrecond(compute_dtype=args.dtype, **EDM_CIFAR10).randomize_parameters_(seed=1234).to(dev).eval()
     amp = torch.bfloat16 if args.dtype == "bf16" else None
 
     B = args.batch

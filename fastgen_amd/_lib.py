@@ -8,7 +8,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfastgen_amd.so")
 
 FG_MAX_LEVELS = 8
-FG_DTYPE_F32, FG_DTYPE_BF16 = 0, 1
+FG_DTYPE_F32, FG_DTYPE_BF16, FG_DTYPE_BF16X3 = 0, 1, 2
+DTYPE_NAMES = {"fp32": FG_DTYPE_F32, "bf16": FG_DTYPE_BF16, "bf16x3": FG_DTYPE_BF16X3}
 FG_SAMPLE_SDE, FG_SAMPLE_ODE = 0, 1
 FG_LOOP_X0, FG_LOOP_MEANFLOW = 0, 1
 FG_SCHEDULE_EDM, FG_SCHEDULE_RF = 0, 1

@@ -13,17 +13,44 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 // ---- compute-dtype traits -------------------------------------------------------------------------
 // KC = input channels per K-chunk; a chunk row is always 128 bytes in LDS (64 bf16 / 32 fp32).
+// ST = storage type of activation tensors, WT = element type of packed weights, WPARTS = weight planes per fragment,
+// FRAG_BYTES = LDS bytes of one lane's 8-element A fragment (of one plane).
 template <typename T>
 struct DT;
 template <>
 struct DT<__bf16> {
+    typedef __bf16 ST;
+    typedef __bf16 WT;
     static constexpr int KC = 64;
+    static constexpr int WPARTS = 1;
+    static constexpr int FRAG_BYTES = 16;
     static constexpr bool FAST = true;  // hardware exp2/rcp in the SiLU prologue and softmax
 };
 template <>
 struct DT<float> {
+    typedef float ST;
+    typedef float WT;
     static constexpr int KC = 32;
+    static constexpr int WPARTS = 1;
+    static constexpr int FRAG_BYTES = 32;
     static constexpr bool FAST = false;  // accurate expf + IEEE division (fp32 parity mode)
+};
+// Split-bf16 compute ("bf16x3", FG_DTYPE_BF16X3): tensors are fp32 in memory; every matrix operand is split into
+// hi = bf16(x), lo = bf16(x - hi) — activations on their way into LDS, weights at pack time — and a product is evaluated as
+// a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on the bf16 matrix pipe with fp32 accumulation.  hi + lo carries 16-17 significant bits
+// of x (|x - hi - lo| <= 2^-18 |x|), the dropped a_lo*b_lo term is <= 2^-18 |a b|: about 2^-17 relative per product, 64 times
+// tighter than the TF32 arithmetic (2^-11) the reference runs on NVIDIA GPUs (fastgen/utils/scripts.py:43-45), at a third
+// of the bf16 MFMA rate instead of the sixteenth that exact-fp32 MFMA runs at (gfx950 has no TF32 matrix instruction).
+// A K-chunk is 32 input channels: [32 hi | 32 lo] = 128 bytes per pixel in LDS, the same pitch as the other modes.
+struct bf16x3 {};
+template <>
+struct DT<bf16x3> {
+    typedef float ST;
+    typedef __bf16 WT;
+    static constexpr int KC = 32;
+    static constexpr int WPARTS = 2;
+    static constexpr int FRAG_BYTES = 16;
+    static constexpr bool FAST = true;  // v_exp / v_rcp are ~1 ulp: far inside the mode's 2^-17
 };
 
 // 8 consecutive K elements of one MFMA operand row, as held by one lane.
@@ -36,6 +63,10 @@ struct Frag8<__bf16> {
 template <>
 struct Frag8<float> {
     f32x4 lo, hi;
+};
+template <>
+struct Frag8<bf16x3> {
+    bf16x8 hi, lo;
 };
 
 // acc += A(32 x 16) * B(16 x 32) with this lane's 8-element slices of A and B.
@@ -53,6 +84,22 @@ __device__ __forceinline__ void mma16(f32x16& acc, const Frag8<float>& a, const 
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[1], b.hi[1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[2], b.hi[2], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[3], b.hi[3], acc, 0, 0, 0);
+}
+
+// bf16x3: small terms first, then the leading product (one accumulator chain: back-to-back MFMAs on one accumulator issue at
+// full rate on gfx950)
+__device__ __forceinline__ void mma16(f32x16& acc, const Frag8<bf16x3>& a, const Frag8<bf16x3>& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
+}
+// x = hi + lo (+ <= 2^-18 |x|): round-to-nearest-even both times
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        hi[j] = (__bf16)x[j];
+        lo[j] = (__bf16)(x[j] - (float)hi[j]);
+    }
 }
 
 // Fragment loads through a buffer resource: wave-uniform byte offset in an SGPR (soffset), lane part in one VGPR, so the
@@ -80,6 +127,50 @@ __device__ __forceinline__ void load_frag_rsrc(Frag8<__bf16>& f, __amdgpu_buffer
 __device__ __forceinline__ void load_frag_rsrc(Frag8<float>& f, __amdgpu_buffer_rsrc_t r, int lane_elems, int elem_off) {
     f.lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_elems * 4, elem_off * 4, 0));
     f.hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_elems * 4 + 16, elem_off * 4, 0));
+}
+// bf16x3: hi plane at elem_off, lo plane 512 elements (one fragment of 64 lanes x 8) behind it
+__device__ __forceinline__ void load_frag_rsrc(Frag8<bf16x3>& f, __amdgpu_buffer_rsrc_t r, int lane_elems, int elem_off) {
+    f.hi = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, lane_elems * 2, elem_off * 2, 0));
+    f.lo = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, lane_elems * 2, elem_off * 2 + 1024, 0));
+}
+// A fragment of 16-deep MFMA step kk out of a pixel's K-chunk in LDS (p: the lane's pixel + lane-half offset)
+template <typename T>
+__device__ __forceinline__ Frag8<T> lds_read_a(const char* p, int kk);
+template <>
+__device__ __forceinline__ Frag8<__bf16> lds_read_a<__bf16>(const char* p, int kk) {
+    Frag8<__bf16> f;
+    f.v = *reinterpret_cast<const bf16x8*>(p + kk * 32);
+    return f;
+}
+template <>
+__device__ __forceinline__ Frag8<float> lds_read_a<float>(const char* p, int kk) {
+    Frag8<float> f;
+    f.lo = *reinterpret_cast<const f32x4*>(p + kk * 64);
+    f.hi = *reinterpret_cast<const f32x4*>(p + kk * 64 + 16);
+    return f;
+}
+template <>
+__device__ __forceinline__ Frag8<bf16x3> lds_read_a<bf16x3>(const char* p, int kk) {
+    Frag8<bf16x3> f;
+    f.hi = *reinterpret_cast<const bf16x8*>(p + kk * 32);
+    f.lo = *reinterpret_cast<const bf16x8*>(p + 64 + kk * 32);
+    return f;
+}
+// park 8 transformed channels (one octet of a pixel's K-chunk) in LDS; p: pixel + octet * FRAG_BYTES
+template <typename T>
+__device__ __forceinline__ void lds_store_a(char* p, const float (&x)[8]);
+__device__ __forceinline__ void store_frag(__bf16* p, const float (&x)[8]);
+__device__ __forceinline__ void store_frag(float* p, const float (&x)[8]);
+template <>
+__device__ __forceinline__ void lds_store_a<__bf16>(char* p, const float (&x)[8]) { store_frag(reinterpret_cast<__bf16*>(p), x); }
+template <>
+__device__ __forceinline__ void lds_store_a<float>(char* p, const float (&x)[8]) { store_frag(reinterpret_cast<float*>(p), x); }
+template <>
+__device__ __forceinline__ void lds_store_a<bf16x3>(char* p, const float (&x)[8]) {
+    bf16x8 hi, lo;
+    split8(x, hi, lo);
+    *reinterpret_cast<bf16x8*>(p) = hi;
+    *reinterpret_cast<bf16x8*>(p + 64) = lo;
 }
 __device__ __forceinline__ void store_frag(__bf16* p, const float (&x)[8]) {
     bf16x8 v;

@@ -36,7 +36,8 @@ enum { PRO_NONE = 0, PRO_GN = 1, PRO_GN_SILU = 2 };
 enum { RES_NONE = 0, RES_DOWN = 1, RES_UP = 2 };
 enum { OUT_NHWC = 0, OUT_QKV = 1 };
 
-// dtype: 0 fp32, 1 bf16 — also the storage type of every activation tensor (src1/src2/resid/out).
+// dtype: 0 fp32, 1 bf16 — also the storage type of every activation tensor (src1/src2/resid/out); 2 = split-bf16 arithmetic
+// (common.h bf16x3) on fp32 tensors.
 // Returns hipError_t as int.
 int launch_conv_fused(int dtype, int ks, int pro, int res, int outmode, const ConvArgs& a, hipStream_t stream);
 // partial-statistics slots per image for an output of width W (= pixel tiles per image, 1 when a tile spans images)

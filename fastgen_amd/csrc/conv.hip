@@ -89,7 +89,11 @@ template <typename T, int KS, int PRO, int RES, int LOGW, int OUTMODE, int ABL =
 __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
     constexpr bool DBG = false;  // (runtime ablation flags retired: they perturbed the code they measured)
     using G = Geom<KS, LOGW>;
-    using ST = T;
+    using ST = typename DT<T>::ST;  // storage type of the activation tensors
+    using WT = typename DT<T>::WT;  // element type of the packed weights
+    constexpr int FB = DT<T>::FRAG_BYTES;
+    constexpr int WP = DT<T>::WPARTS;
+    constexpr bool SAME = (sizeof(ST) == FB / 8);  // LDS holds the storage type itself (no split, no conversion)
     constexpr int dbg = ABL;  // compile-time ablation mask: 1 no staging, 2 no weight refill, 4 no epilogue, 8 no MFMA
     constexpr int KC = DT<T>::KC;
     constexpr bool FAST = DT<T>::FAST;
@@ -101,9 +105,9 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
     constexpr int IPS = (NITEMS + G::TAPS - 1) / G::TAPS;             // items staged per (chunk, tap) step
     constexpr int ND = (RES == RES_DOWN) ? 4 : 1;                     // source pixels per staged pixel (2x2 mean when down-sampling)
     // split load / transform+write around the MFMAs; with down-sampling an item holds 4 raw fragments: bf16 3x3 only
-    constexpr bool DEFER = (RES != RES_DOWN || (KS == 3 && sizeof(T) == 2));
+    constexpr bool DEFER = (RES != RES_DOWN || (KS == 3 && sizeof(ST) == 2));
     constexpr bool AB_REGS = (PRO != PRO_NONE) && (G::IMGS == 1);     // per-chunk GN coefficients live in registers
-    constexpr bool PIPE_A = (sizeof(T) == 2);                         // two A-fragment register sets (bf16 only)
+    constexpr bool PIPE_A = (sizeof(ST) == 2);                        // two A-fragment register sets (bf16 only; bf16x3 holds hi+lo)
     constexpr int NT = conv_nt(KS, LOGW, OUTMODE);                    // 32-channel tiles per wave: 2, or 1 (N split over 2 workgroups)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -123,9 +127,9 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
     const int row0 = (slot / G::TCOLS) * G::TH, col0 = (slot % G::TCOLS) * G::TW;
 
     // this wave's packed weights: [cout/32][step][kk][lane][8], two consecutive 32-channel groups
-    const size_t wstride = (size_t)nsteps * (KK * 512);
+    const size_t wstride = (size_t)nsteps * (KK * 512 * WP);
     // weights through a buffer resource: SGPR offsets, no vector address arithmetic (common.h load_frag_rsrc)
-    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const T*>(a.wpack) + (size_t)(nblk * (4 * NT) + wave * NT) * wstride);
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const WT*>(a.wpack) + (size_t)(nblk * (4 * NT) + wave * NT) * wstride);
     const int wlane = lane * 8;
     const int wst = (int)wstride;
 
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         y = row0 + hy - G::PAD;
         x = col0 + hx - G::PAD;
         n = n_base + img;
-        lds_off = (img * G::HH_ + hy) * G::RS + hx * PITCH + oct * (8 * (int)sizeof(T));
+        lds_off = (img * G::HH_ + hy) * G::RS + hx * PITCH + oct * FB;
         return (hq < G::HALO_PIX) && (y >= 0) && (y < H) && (x >= 0) && (x < G::W) && (n < a.B);
     };
     auto src_ptr = [&](int chunk, int n, int sy, int sx) -> const ST* {
@@ -188,12 +192,12 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         if (hq >= G::HALO_PIX) return;
         int n, y, x, lo;
         const bool ok = decode(hq, n, y, x, lo);
-        if (DEFER && PRO == PRO_NONE && ND == 1) {
+        if constexpr (DEFER && PRO == PRO_NONE && ND == 1 && SAME) {
             // nothing to transform: park the loaded fragment as it is (zeros outside the image) — no widening, no
             // re-rounding, no vector arithmetic beyond the select
-            Frag8<T> z = rawp[0];
-            if (!valid) z = Frag8<T>{};
-            *reinterpret_cast<Frag8<T>*>(abuf + lo) = z;
+            Frag8<ST> z = rawp[0];
+            if (!valid) z = Frag8<ST>{};
+            *reinterpret_cast<Frag8<ST>*>(abuf + lo) = z;
             return;
         }
         float o[8];
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
                 for (int j = 0; j < 8; ++j) o[j] *= 0.25f;
             }
         }
-        store_frag(reinterpret_cast<T*>(abuf + lo), o);
+        lds_store_a<T>(abuf + lo, o);
     };
 
     // ---- prologue: chunk 0 of A, step 0 of B ------------------------------------------------------
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) load_frag_rsrc(bfr[nt][kk], wrs, wlane, nt * wst + kk * 512);
+        for (int kk = 0; kk < KK; ++kk) load_frag_rsrc(bfr[nt][kk], wrs, wlane, nt * wst + kk * (512 * WP));
 
     f32x16 acc[4][NT];
 #pragma unroll
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
-    const int lane_off = G::off0(r) + h * (8 * (int)sizeof(T));
+    const int lane_off = G::off0(r) + h * FB;
     __syncthreads();
 
     // ---- main loop ------------------------------------------------------------------------------------
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         for (int tap = 0; tap < G::TAPS; ++tap, ++step) {
             // (1) weights: each fragment is refilled in place for the NEXT step right after its last use below
             //     (clamped: the last step re-reads itself), so B needs 2*KK fragments with one step of prefetch distance
-            const int pnext = ((step + 1 < nsteps) ? step + 1 : step) * (KK * 512);
+            const int pnext = ((step + 1 < nsteps) ? step + 1 : step) * (KK * 512 * WP);
             // (2) issue this step's share of the next chunk's activation loads
             Frag8<ST> raw[IPS][ND];
             bool valid[IPS];
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
             auto read_a = [&](int kk, Frag8<T> (&af)[4]) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
-                    af[mt] = load_frag(reinterpret_cast<const T*>(abase + G::off0(mt * 32)) + kk * 16);
+                    af[mt] = lds_read_a<T>(abase + G::off0(mt * 32), kk);
             };
             auto mma8 = [&](int kk, const Frag8<T> (&af)[4]) {
 #pragma unroll
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
                     for (int nt = 0; nt < NT; ++nt) mma16(acc[mt][nt], af[mt], bfr[nt][kk]);
                 if (!(dbg & 2)) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) load_frag_rsrc(bfr[nt][kk], wrs, wlane, pnext + nt * wst + kk * 512);
+                    for (int nt = 0; nt < NT; ++nt) load_frag_rsrc(bfr[nt][kk], wrs, wlane, pnext + nt * wst + kk * (512 * WP));
                 }
             };
             if (dbg & 8) {
@@ -385,8 +389,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         const int c4 = lane % QPW, prow = lane / QPW;
         const int co0 = nblk * (128 * NT) + wave * (32 * NT) + c4 * 4;
         const bool qk = (OUTMODE == OUT_QKV);
-        T* out = reinterpret_cast<T*>(qk ? (nblk == 0 ? a.q_out : a.k_out) : a.out);
-        const T* resid = qk ? nullptr : reinterpret_cast<const T*>(a.resid);
+        ST* out = reinterpret_cast<ST*>(qk ? (nblk == 0 ? a.q_out : a.k_out) : a.out);
+        const ST* resid = qk ? nullptr : reinterpret_cast<const ST*>(a.resid);
         const int ostride = qk ? 256 : a.Cout;          // channels per pixel of the tensor written
         const int co_out = qk ? co0 - nblk * 256 : co0;  // channel within that tensor (co0 indexes bias / temb / stats)
         f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
             ok = n < a.B;
             return (((size_t)n * H + y) * G::W + x) * ostride + co_out;
         };
-        typedef typename Raw4<T>::type R4;
+        typedef typename Raw4<ST>::type R4;
         R4 rcur[NP], rnext[NP];  // residual quads: the loads for tile mt+1 are in flight while tile mt is processed
         auto issue_resid = [&](int mt, R4 (&rr)[NP]) {
 #pragma unroll
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         }
     } else {  // the v^T plane of the qkv projection: [B][256][HW], four consecutive pixels per 8/16-byte store
         static_assert(OUTMODE != OUT_QKV || NT == 2, "qkv epilogue assumes 64 channels per wave");
-        T* vt = reinterpret_cast<T*>(a.vt_out);
+        ST* vt = reinterpret_cast<ST*>(a.vt_out);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int cl = wave * 64 + nt * 32 + r;
@@ -486,10 +490,11 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
 
 // ---- weight packing ---------------------------------------------------------------------------------
 // packed[nt][chunk][tap][kk][lane][j] = W[cout = nt*32 + (lane&31)][cin = chunk*KC + kk*16 + 8*(lane>>5) + j][tap]
+// bf16x3: each fragment is followed by its lo plane, packed[...][kk][part][lane][j], part 0 = bf16(w), part 1 = bf16(w - hi)
 template <typename T>
-__global__ void pack_conv_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, int ks,
+__global__ void pack_conv_weights_kernel(const float* __restrict__ w, typename DT<T>::WT* __restrict__ out, int cout, int cin, int ks,
                                          int qkv_perm) {
-    constexpr int KC = DT<T>::KC, KK = KC / 16;
+    constexpr int KC = DT<T>::KC, KK = KC / 16, WP = DT<T>::WPARTS;
     const int taps = ks * ks;
     const size_t total = (size_t)cout * cin * taps;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -507,7 +512,15 @@ __global__ void pack_conv_weights_kernel(const float* __restrict__ w, T* __restr
             co = (co % C) * 3 + co / C;
         }
         const int ci = chunk * KC + kk * 16 + 8 * (lane >> 5) + j;
-        out[idx] = (T)w[((size_t)co * cin + ci) * taps + tap];
+        const float v = w[((size_t)co * cin + ci) * taps + tap];
+        if constexpr (WP == 1) {
+            out[idx] = (typename DT<T>::WT)v;
+        } else {
+            const size_t o = (idx / 512) * 1024 + (idx % 512);
+            const __bf16 hi = (__bf16)v;
+            out[o] = hi;
+            out[o + 512] = (__bf16)(v - (float)hi);
+        }
     }
 }
 
@@ -563,11 +576,20 @@ int launch_t(int ks, int pro, int res, int outmode, const ConvArgs& a, hipStream
     return (int)hipErrorInvalidValue;
 }
 
+int dispatch_t(int dtype, int ks, int pro, int res, int outmode, const ConvArgs& a, hipStream_t s) {
+    switch (dtype) {
+        case 0: return launch_t<float>(ks, pro, res, outmode, a, s);
+        case 1: return launch_t<__bf16>(ks, pro, res, outmode, a, s);
+        case 2: return launch_t<bf16x3>(ks, pro, res, outmode, a, s);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
 }  // namespace
 
 // compile-time ablation builds of the dominant shape (bf16, 3x3, no resample, 32x32): scripts/conv_ablate.py only
 int launch_conv_debug(int dtype, const ConvArgs& a, hipStream_t stream) {
-    if (!dtype || a.W != 32) return (int)hipErrorInvalidValue;
+    if (dtype != 1 || a.W != 32) return (int)hipErrorInvalidValue;
     g_debug_extra_lds = (a.dbg & 16) ? 48 * 1024 : 0;
     switch (a.dbg & 15) {
         case 0: return launch_one<__bf16, 3, PRO_GN_SILU, RES_NONE, 5, OUT_NHWC, 0>(a, stream);
@@ -583,7 +605,7 @@ int launch_conv_debug(int dtype, const ConvArgs& a, hipStream_t stream) {
 }
 
 int launch_conv_fused(int dtype, int ks, int pro, int res, int outmode, const ConvArgs& a, hipStream_t stream) {
-    const int kc = dtype ? DT<__bf16>::KC : DT<float>::KC;
+    const int kc = dtype == 1 ? DT<__bf16>::KC : DT<float>::KC;  // 32 for fp32 and bf16x3
     if (a.H != a.W || (a.W != 8 && a.W != 16 && a.W != 32)) return (int)hipErrorInvalidValue;
     if ((a.C1 % kc) || (a.C2 % kc) || (a.Cout % 256) || a.B <= 0) return (int)hipErrorInvalidValue;
     if (res == RES_NONE && (a.Hs != a.H || a.Ws != a.W)) return (int)hipErrorInvalidValue;
@@ -592,7 +614,7 @@ int launch_conv_fused(int dtype, int ks, int pro, int res, int outmode, const Co
     if (pro != PRO_NONE && !a.ab) return (int)hipErrorInvalidValue;
     if (outmode == OUT_QKV && (a.Cout != 768 || a.W > 16)) return (int)hipErrorInvalidValue;
     if (conv_ws_enabled() && conv_ws_supported(dtype, ks, pro, res, outmode, a)) return launch_conv_ws(res, a, stream, false, pro);
-    return dtype ? launch_t<__bf16>(ks, pro, res, outmode, a, stream) : launch_t<float>(ks, pro, res, outmode, a, stream);
+    return dispatch_t(dtype, ks, pro, res, outmode, a, stream);
 }
 
 // FASTGEN_AMD_CONV_WS=0 keeps every conv on conv_fused_kernel (A/B measurements); read once.
@@ -617,15 +639,14 @@ int conv_prepare_all(int dtype) {
         a.W = a.H = ws[wi];
         for (int res = 0; res < 3 && !rc; ++res) {
             if (res != RES_DOWN)
-                rc = dtype ? launch_t<__bf16>(3, PRO_GN_SILU, res, OUT_NHWC, a, nullptr) : launch_t<float>(3, PRO_GN_SILU, res, OUT_NHWC, a, nullptr);
-            if (!rc) rc = dtype ? launch_t<__bf16>(1, PRO_NONE, res, OUT_NHWC, a, nullptr) : launch_t<float>(1, PRO_NONE, res, OUT_NHWC, a, nullptr);
+                rc = dispatch_t(dtype, 3, PRO_GN_SILU, res, OUT_NHWC, a, nullptr);
+            if (!rc) rc = dispatch_t(dtype, 1, PRO_NONE, res, OUT_NHWC, a, nullptr);
         }
-        if (!rc) rc = dtype ? launch_t<__bf16>(3, PRO_NONE, RES_NONE, OUT_NHWC, a, nullptr) : launch_t<float>(3, PRO_NONE, RES_NONE, OUT_NHWC, a, nullptr);
-        if (!rc && a.W <= 16)
-            rc = dtype ? launch_t<__bf16>(1, PRO_GN, RES_NONE, OUT_QKV, a, nullptr) : launch_t<float>(1, PRO_GN, RES_NONE, OUT_QKV, a, nullptr);
+        if (!rc) rc = dispatch_t(dtype, 3, PRO_NONE, RES_NONE, OUT_NHWC, a, nullptr);
+        if (!rc && a.W <= 16) rc = dispatch_t(dtype, 1, PRO_GN, RES_NONE, OUT_QKV, a, nullptr);
     }
     g_prepare_only = false;
-    if (!rc && dtype) {
+    if (!rc && dtype == 1) {
         ConvArgs w{};
         for (int res : {RES_NONE, RES_UP}) {
             w.W = w.H = 32;
@@ -648,8 +669,10 @@ int launch_pack_conv_weights(int dtype, const float* w, void* out, int cout, int
                              hipStream_t stream) {
     const size_t total = conv_pack_elems(cout, cin, ks);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    if (dtype)
+    if (dtype == 1)
         hipLaunchKernelGGL(pack_conv_weights_kernel<__bf16>, dim3(grid), dim3(256), 0, stream, w, (__bf16*)out, cout, cin, ks, qkv_perm);
+    else if (dtype == 2)  // 2 x bf16 per weight: the same bytes as the fp32 packing
+        hipLaunchKernelGGL(pack_conv_weights_kernel<bf16x3>, dim3(grid), dim3(256), 0, stream, w, (__bf16*)out, cout, cin, ks, qkv_perm);
     else
         hipLaunchKernelGGL(pack_conv_weights_kernel<float>, dim3(grid), dim3(256), 0, stream, w, (float*)out, cout, cin, ks, qkv_perm);
     return (int)hipGetLastError();

@@ -137,7 +137,8 @@ struct GraphKey {
 
 struct fg_edm {
     fg_edm_config cfg;
-    int dtype = 0;
+    int dtype = 0;  // storage type of the activation tensors and mode of every non-conv kernel: 0 fp32, 1 bf16
+    int cmode = 0;  // arithmetic of the convolutions: FG_DTYPE_F32 / FG_DTYPE_BF16 / FG_DTYPE_BF16X3 (fp32 storage)
     int num_taps = 0;  // encoder `block3` outputs available as feature taps
     int emb_ch = 0, noise_ch = 0, cond_ch = 0;  // cond_ch = noise_ch * (1 + r_timestep), EDM/network.py:376
     std::vector<Param> params;
@@ -428,7 +429,7 @@ int conv_launch(fg_edm* h, int ks, int pro, int res, int outmode, const ConvArgs
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (int)hipErrorUnknown;
         (void)hipEventRecord(e0, s);
     }
-    const int rc = launch_conv_fused(h->dtype, ks, pro, res, outmode, a, s);
+    const int rc = launch_conv_fused(h->cmode, ks, pro, res, outmode, a, s);
     if (timed) {
         (void)hipEventRecord(e1, s);
         h->prof_ev.push_back(e0);
@@ -701,10 +702,10 @@ int ensure_device_state(fg_edm* h) {
     for (Block* b : h->blocks) {
         if ((rc = dev_alloc(h, &b->p_conv0, conv_pack_elems(b->cout, b->cin, 3) * tsz))) return rc;
         if ((rc = dev_alloc(h, &b->p_conv1, conv_pack_elems(b->cout, b->cout, 3) * tsz))) return rc;
-        if (conv_ws_shape_ok(h->dtype, b->cout, b->cin, b->res_out) && !b->down &&
+        if (conv_ws_shape_ok(h->cmode, b->cout, b->cin, b->res_out) && !b->down &&
             (rc = dev_alloc(h, &b->p_conv0_ws, conv_pack_elems(b->cout, b->cin, 3) * tsz)))
             return rc;
-        if (conv_ws_shape_ok(h->dtype, b->cout, b->cout, b->res_out) &&
+        if (conv_ws_shape_ok(h->cmode, b->cout, b->cout, b->res_out) &&
             (rc = dev_alloc(h, &b->p_conv1_ws, conv_pack_elems(b->cout, b->cout, 3) * tsz)))
             return rc;
         if (b->has_skip && (rc = dev_alloc(h, &b->p_skip, conv_pack_elems(b->cout, b->cin, 1) * tsz))) return rc;
@@ -728,7 +729,7 @@ int ensure_device_state(fg_edm* h) {
     for (int j = 0; j < half; ++j) fr[j] = powf(1.0f / 10000.0f, (float)j / (float)(half - 1));
     if ((rc = dev_alloc(h, (void**)&h->freqs, sizeof(float) * half))) return rc;
     HIP_TRY(hipMemcpy(h->freqs, fr.data(), sizeof(float) * half, hipMemcpyHostToDevice));
-    if (conv_prepare_all(h->dtype) != 0) return fail(FG_EHIP, "hipFuncSetAttribute(dynamic LDS) failed");
+    if (conv_prepare_all(h->cmode) != 0) return fail(FG_EHIP, "hipFuncSetAttribute(dynamic LDS) failed");
     if (launch_attention(h->dtype, nullptr, nullptr, nullptr, nullptr, 1, 256, nullptr) != 0) return fail(FG_EHIP, "attention prepare failed");
     HIP_TRY(hipHostMalloc((void**)&h->slots, sizeof(fg_edm::Slot) * fg_edm::kSlots));
     for (int i = 0; i < fg_edm::kSlots; ++i) HIP_TRY(hipEventCreateWithFlags(&h->slot_ev[i], hipEventDisableTiming));
@@ -749,7 +750,8 @@ int fg_edm_create(const fg_edm_config* cfg, fg_edm** out) {
     if (cfg->num_levels < 1 || cfg->num_levels > FG_MAX_LEVELS || cfg->num_attn_resolutions < 0 ||
         cfg->num_attn_resolutions > FG_MAX_LEVELS)
         return fail(FG_EINVAL, "bad num_levels / num_attn_resolutions");
-    if (cfg->compute_dtype != FG_DTYPE_F32 && cfg->compute_dtype != FG_DTYPE_BF16) return fail(FG_EINVAL, "bad compute_dtype");
+    if (cfg->compute_dtype != FG_DTYPE_F32 && cfg->compute_dtype != FG_DTYPE_BF16 && cfg->compute_dtype != FG_DTYPE_BF16X3)
+        return fail(FG_EINVAL, "bad compute_dtype");
     if ((cfg->drop_precond & ~3) || (cfg->schedule != FG_SCHEDULE_EDM && cfg->schedule != FG_SCHEDULE_RF) ||
         (cfg->r_timestep & ~1))
         return fail(FG_EINVAL, "bad r_timestep / drop_precond / schedule");
@@ -757,7 +759,8 @@ int fg_edm_create(const fg_edm_config* cfg, fg_edm** out) {
         return fail(FG_EINVAL, "bad channel configuration");
     fg_edm* h = new fg_edm();
     h->cfg = *cfg;
-    h->dtype = cfg->compute_dtype;
+    h->cmode = cfg->compute_dtype;
+    h->dtype = cfg->compute_dtype == FG_DTYPE_BF16 ? 1 : 0;
     h->emb_ch = cfg->model_channels * cfg->channel_mult_emb;
     h->noise_ch = cfg->model_channels * cfg->channel_mult_noise;
     h->cond_ch = h->noise_ch * (cfg->r_timestep ? 2 : 1);
@@ -817,14 +820,14 @@ int fg_edm_pack_weights(fg_edm* h, void* stream) {
     }
     ++h->pack_epoch;
     for (Block* b : h->blocks) {
-        HIP_TRY(launch_pack_conv_weights(h->dtype, h->P(b->conv0_w), b->p_conv0, b->cout, b->cin, 3, 0, s));
-        HIP_TRY(launch_pack_conv_weights(h->dtype, h->P(b->conv1_w), b->p_conv1, b->cout, b->cout, 3, 0, s));
+        HIP_TRY(launch_pack_conv_weights(h->cmode, h->P(b->conv0_w), b->p_conv0, b->cout, b->cin, 3, 0, s));
+        HIP_TRY(launch_pack_conv_weights(h->cmode, h->P(b->conv1_w), b->p_conv1, b->cout, b->cout, 3, 0, s));
         if (b->p_conv0_ws) HIP_TRY(launch_pack_conv_weights_ws(h->P(b->conv0_w), b->p_conv0_ws, b->cout, b->cin, s));
         if (b->p_conv1_ws) HIP_TRY(launch_pack_conv_weights_ws(h->P(b->conv1_w), b->p_conv1_ws, b->cout, b->cout, s));
-        if (b->has_skip) HIP_TRY(launch_pack_conv_weights(h->dtype, h->P(b->skip_w), b->p_skip, b->cout, b->cin, 1, 0, s));
+        if (b->has_skip) HIP_TRY(launch_pack_conv_weights(h->cmode, h->P(b->skip_w), b->p_skip, b->cout, b->cin, 1, 0, s));
         if (b->attn) {
-            HIP_TRY(launch_pack_conv_weights(h->dtype, h->P(b->qkv_w), b->p_qkv, 3 * b->cout, b->cout, 1, 1, s));
-            HIP_TRY(launch_pack_conv_weights(h->dtype, h->P(b->proj_w), b->p_proj, b->cout, b->cout, 1, 0, s));
+            HIP_TRY(launch_pack_conv_weights(h->cmode, h->P(b->qkv_w), b->p_qkv, 3 * b->cout, b->cout, 1, 1, s));
+            HIP_TRY(launch_pack_conv_weights(h->cmode, h->P(b->proj_w), b->p_proj, b->cout, b->cout, 1, 0, s));
             // bias o' = plane*C + c  <-  reference channel c*3 + plane: three strided 2-D copies
             for (int plane = 0; plane < 3; ++plane)
                 HIP_TRY(hipMemcpy2DAsync(b->qkv_bias + plane * b->cout, sizeof(float), h->P(b->qkv_b) + plane,
@@ -1033,6 +1036,7 @@ int fg_debug_conv_bench(int dtype, int batch, int cin, int res, int ks, int with
     float *x = nullptr, *out = nullptr, *resid = nullptr, *bias = nullptr;
     float2* ab = nullptr;
     void* wp = nullptr;
+    if (dtype < 0 || dtype > 2) return fail(FG_EINVAL, "bad dtype");
     HIP_TRY(hipMalloc((void**)&x, npix * cin * 4));
     HIP_TRY(hipMalloc((void**)&out, npix * 256 * 4));
     HIP_TRY(hipMalloc((void**)&resid, npix * 256 * 4));
@@ -1056,7 +1060,7 @@ int fg_debug_conv_bench(int dtype, int batch, int cin, int res, int ks, int with
         };
         int rc;
         if ((rc = fill(x, npix * cin * 4)) || (rc = fill(resid, npix * 256 * 4)) || (rc = fill(ab, (size_t)batch * cin * 8)) ||
-            (rc = fill(wp, (size_t)256 * cin * ks * ks * (dtype ? 2 : 4))))
+            (rc = fill(wp, (size_t)256 * cin * ks * ks * (dtype == 1 ? 2 : 4))))
             return rc;
     }
     HIP_TRY(hipMemset(bias, 0, 256 * 4));

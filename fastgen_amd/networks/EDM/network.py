@@ -38,6 +38,13 @@ from fastgen_amd.networks.network import FastGenNetwork
 from fastgen_amd.networks.noise_schedule import NET_PRED_TYPES, expand_like
 
 
+# How a call outside bf16 autocast computes (the reference's `precision="float32"`, configs/config.py:167-171, which on its CUDA
+# path is TF32 arithmetic, utils/scripts.py:43-45).  "fp32": exact fp32 products on the fp32 matrix instructions (157 TFLOP/s roof);
+# "bf16x3": fp32 tensors, convolutions as three bf16 MFMAs per product (hi/lo split, ~2^-17 per product: 64x tighter than TF32,
+# 833 TFLOP/s roof; held to the SAME parity tolerance as "fp32" in tests/test_gpu_parity.py).  Overridable per module (compute_dtype=...) or per process (FASTGEN_AMD_COMPUTE_DTYPE).
+DEFAULT_FP32_MODE = "bf16x3"
+
+
 class _Node(nn.Module):
     """Bare container: the parameter tree only has to reproduce the reference's state-dict key paths."""
 
@@ -194,7 +201,7 @@ class EDMPrecond(FastGenNetwork):
         drop_precond=None,
         net_pred_type="x0",
         schedule_type="edm",
-        compute_dtype: Optional[str] = None,  # extension: "fp32" | "bf16" | None (= follow torch.autocast)
+        compute_dtype: Optional[str] = None,  # extension: "fp32" | "bf16x3" | "bf16" | None (= follow torch.autocast)
         **model_kwargs,
     ):
         super().__init__(net_pred_type=net_pred_type, schedule_type=schedule_type, **model_kwargs)
@@ -223,8 +230,8 @@ class EDMPrecond(FastGenNetwork):
         self.r_timestep = bool(mk.get("r_timestep", False))
         self.dropout = mk.get("dropout", 0.10)
         self.compute_dtype = compute_dtype or os.environ.get("FASTGEN_AMD_COMPUTE_DTYPE") or None
-        if self.compute_dtype not in (None, "fp32", "bf16"):
-            raise ValueError(f"compute_dtype must be 'fp32', 'bf16' or None, got {self.compute_dtype!r}")
+        if self.compute_dtype not in (None, "fp32", "bf16x3", "bf16"):
+            raise ValueError(f"compute_dtype must be 'fp32', 'bf16x3', 'bf16' or None, got {self.compute_dtype!r}")
 
         cfg = _lib.fg_edm_config()
         cfg.img_resolution, cfg.img_channels, cfg.label_dim = img_resolution, img_channels, label_dim
@@ -299,14 +306,14 @@ class EDMPrecond(FastGenNetwork):
 
     def _select_dtype(self) -> int:
         if self.compute_dtype is not None:
-            return _lib.FG_DTYPE_BF16 if self.compute_dtype == "bf16" else _lib.FG_DTYPE_F32
+            return _lib.DTYPE_NAMES[self.compute_dtype]
         if torch.is_autocast_enabled():
             ad = torch.get_autocast_gpu_dtype()
             if ad == torch.bfloat16:
                 return _lib.FG_DTYPE_BF16
             if ad != torch.float32:
                 raise NotImplementedError(f"autocast dtype {ad} is not implemented (bf16 or fp32)")
-        return _lib.FG_DTYPE_F32
+        return _lib.DTYPE_NAMES[DEFAULT_FP32_MODE]
 
     def _engine(self, device: torch.device):
         """Engine for the active compute dtype with up-to-date weights bound and packed."""

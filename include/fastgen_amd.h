@@ -34,7 +34,13 @@ extern "C" {
 #define FG_ENOMEM 4      /* workspace too small */
 
 #define FG_DTYPE_F32 0   /* exact fp32: v_mfma_f32_32x32x2_f32, fp32 activations */
-#define FG_DTYPE_BF16 1  /* bf16 MFMA operands, fp32 accumulate, fp32 residual stream / norm statistics / softmax */
+#define FG_DTYPE_BF16 1  /* bf16 MFMA operands, fp32 accumulate, bf16 activation storage, fp32 norm statistics / softmax */
+/* Split-bf16 convolutions on fp32 tensors: every conv operand x is split into hi = bf16(x), lo = bf16(x - hi) and a product is
+ * a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on the bf16 matrix pipe with fp32 accumulate (about 2^-17 relative per product, against
+ * 2^-11 for the TF32 arithmetic the reference enables on NVIDIA GPUs, fastgen/utils/scripts.py:43-45, which gfx950 does not have);
+ * activations, statistics, attention, embedding MLP and preconditioning exactly as FG_DTYPE_F32.  Three bf16 MFMAs per product:
+ * roofline 2.5 PFLOP/s / 3, against 157 TFLOP/s for FG_DTYPE_F32. */
+#define FG_DTYPE_BF16X3 2
 
 #define FG_SAMPLE_SDE 0  /* student_sample_type='sde'  (methods/model.py:358-359) */
 #define FG_SAMPLE_ODE 1  /* student_sample_type='ode'  (methods/model.py:360-361) */

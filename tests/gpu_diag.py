@@ -47,7 +47,7 @@ def main():
     fx = torch.load(os.path.join(G, "blocks_full.pt"), weights_only=True)
     enc, dec = R.layout(cfg)
     blocks = [b for b in enc + dec if b.kind == "block"]
-    for mode in ("fp32", "bf16"):
+    for mode in (sys.argv[1:] or ("fp32", "bf16x3", "bf16")):
         print(f"==== {mode} ====")
         net = EDMPrecond(compute_dtype=mode, **kw)
         net.load_state_dict(sd)
