@@ -80,6 +80,7 @@ SIGNATURES = {
     "fg_edm_set_dropout": (c_int, [c_void_p, c_float, c_uint64]),
     "fg_op_dropout_mask": (c_int, [c_void_p, c_int64, c_float, ctypes.c_uint32, c_uint64, c_void_p]),
     "fg_edm_set_augment": (c_int, [c_void_p, c_void_p]),
+    "fg_edm_set_training": (c_int, [c_void_p, c_int]),
     "fg_op_images_to_u8": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "fg_op_randn": (c_int, [c_void_p, c_int64, c_uint64, c_uint64, c_void_p]),
 }

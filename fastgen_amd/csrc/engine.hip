@@ -156,6 +156,8 @@ struct fg_edm {
     std::map<const float*, DgradW> dgrad_cache;
     uint64_t pack_epoch = 0;
     const float* augment = nullptr;  // [B][augment_dim] augmentation labels of the next calls (fg_edm_set_augment), or none
+    bool training = false;           // the module is in train() mode: sigma_shift is not applied (fg_edm_set_training)
+    double shift() const { return training ? 0.0 : cfg.sigma_shift; }  // EDM/network.py:956
     float dropout_p = 0.f;           // training-mode dropout of conv1's operand (fg_edm_set_dropout); 0 = off
     uint64_t dropout_seed = 0;
     float* aff_wT = nullptr;  // [emb_ch][temb_total]: the stacked affine matrix transposed, for the batched embedding gradient
@@ -562,7 +564,7 @@ int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, cons
                 const float* labels, float* out, int B, Workspace& w, hipStream_t s, float* const* feats = nullptr,
                 bool early = false, TrainStash* ts = nullptr) {
     const fg_edm_config& c = h->cfg;
-    HIP_TRY(launch_precond_coef(t, t_stride, c.r_timestep ? r : nullptr, r_stride, c.sigma_data, c.sigma_shift, 1e-6,
+    HIP_TRY(launch_precond_coef(t, t_stride, c.r_timestep ? r : nullptr, r_stride, c.sigma_data, h->shift(), 1e-6,
                                 c.drop_precond, w.coef, B, s));
     int rc = run_mapping(h, labels, B, w, s);
     if (rc) return rc;
@@ -1031,7 +1033,7 @@ int fg_edm_profile_end(fg_edm* h, int64_t* launches, double* total_ms, double* t
 
 // Debug/ablation micro-benchmark of one fused 3x3 conv (bf16 or fp32): allocates its own buffers, times `iters`
 // launches with HIP events.  Not part of the product path; used by scripts/conv_ablate.py only.
-int fg_debug_conv_bench(int dtype, int batch, int cin, int res, int ks, int with_resid, int dbg, int iters, float* ms_out) {
+FG_API int fg_debug_conv_bench(int dtype, int batch, int cin, int res, int ks, int with_resid, int dbg, int iters, float* ms_out) {
     const size_t npix = (size_t)batch * res * res;
     float *x = nullptr, *out = nullptr, *resid = nullptr, *bias = nullptr;
     float2* ab = nullptr;
@@ -1161,6 +1163,12 @@ int fg_op_dropout_mask(float* out, int64_t total, float p, uint32_t block_index,
     DropArgs d;
     d.p = p, d.block = block_index, d.seed = seed;
     HIP_TRY(launch_dropout_mask(out, total, d, (hipStream_t)stream));
+    return FG_OK;
+}
+int fg_edm_set_training(fg_edm* h, int training) {
+    if (!h) return fail(FG_EINVAL, "null handle");
+    if ((training != 0) != h->training && h->cfg.sigma_shift != 0.0) drop_graph(h);  // a captured sampler baked the old shift in
+    h->training = training != 0;
     return FG_OK;
 }
 int fg_edm_set_augment(fg_edm* h, const float* augment_labels) {

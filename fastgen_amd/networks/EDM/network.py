@@ -19,7 +19,7 @@ config_mf_cifar10.py: r_timestep=True, drop_precond='both', schedule_type='rf', 
 `feature_indices` / `return_features_early` (the encoder `block3` taps the DMD2 discriminator reads,
 EDM/network.py:525-544) are served by the same engine, forward only.
 
-Not provided on this path (raises, never falls back): training backward, non-SongUNet model types, and any device but a
+Not provided on this path (raises, never falls back): non-SongUNet model types, and any device but a
 HIP GPU.
 """
 from __future__ import annotations
@@ -83,6 +83,7 @@ class _EDMForwardFn(torch.autograd.Function):
     def forward(ctx, net, x32, t64, r64, labels, taps_aug, early, *weights):
         taps, aug, drop = taps_aug
         ctx.aug, ctx.drop = aug, drop
+        ctx.training = net.training  # the backward differentiates the forward that ran, whatever mode the module is in by then
         # outputs nothing depends on (DMD2 detaches the teacher's prediction and keeps its taps) arrive in backward as None, not as
         # zero tensors: the backward then leaves the decoder alone
         ctx.set_materialize_grads(False)
@@ -129,6 +130,7 @@ class _EDMForwardFn(torch.autograd.Function):
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
             dt, h = net._engine(dev)
         assert dt == _lib.FG_DTYPE_BF16
+        _lib.check(L.fg_edm_set_training(h, int(ctx.training)))
         named = net._named_weights()
         # one zero-filled fp32 buffer, one view per trainable parameter (a fill per parameter costs 400+ launches)
         need_w = [p.requires_grad and ctx.needs_input_grad[7 + i] for i, (_, p) in enumerate(named)]
@@ -337,6 +339,8 @@ class EDMPrecond(FastGenNetwork):
             _lib.check(L.fg_edm_pack_weights(h, ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
             self._pack_refs[dt] = refs
             self._bound_sig[dt] = sig
+        # train() / eval() as far as the arithmetic sees it: sigma_shift applies in eval mode only (EDM/network.py:956)
+        _lib.check(_lib.lib().fg_edm_set_training(h, int(self.training)))
         return dt, h
 
     def _workspace(self, dt: int, h, batch: int, device) -> torch.Tensor:

@@ -27,6 +27,10 @@
 extern "C" {
 #endif
 
+/* Every entry point below is exported with default visibility; nothing else leaves the library (it is built with
+ * -fvisibility=hidden). */
+#define FG_API __attribute__((visibility("default")))
+
 #define FG_OK 0
 #define FG_EINVAL 1      /* bad argument / unsupported configuration */
 #define FG_ENOTREADY 2   /* a parameter is unbound or weights were not packed */
@@ -72,7 +76,7 @@ typedef struct fg_edm_config {
     int attn_resolutions[FG_MAX_LEVELS]; /* {16} */
     int channel_mult_noise;              /* 1 */
     double sigma_data;                   /* 0.5 */
-    double sigma_shift;                  /* 0.0 (applied in eval mode only, EDM/network.py:956) */
+    double sigma_shift;                  /* 0.0 (applied in eval mode only, EDM/network.py:956: see fg_edm_set_training) */
     int compute_dtype;                   /* FG_DTYPE_* */
     int r_timestep;                      /* 1: second (target-time) embedding, cond_channels doubled (EDM/network.py:376,401-408) */
     int drop_precond;                    /* bit mask of FG_DROP_PRECOND_* (0 = full EDM preconditioning) */
@@ -82,35 +86,35 @@ typedef struct fg_edm_config {
 typedef struct fg_edm fg_edm; /* opaque */
 
 /* Thread-local message of the last failing call on this thread ("" if none). */
-const char* fg_last_error(void);
+FG_API const char* fg_last_error(void);
 /* "fastgen_amd <version> gfx950" */
-const char* fg_version(void);
+FG_API const char* fg_version(void);
 
 /* ---- network object: replaces EDMPrecond.__init__ / state-dict ownership (EDM/network.py:808-839) ---- */
-int fg_edm_create(const fg_edm_config* cfg, fg_edm** out);
-void fg_edm_destroy(fg_edm* h);
+FG_API int fg_edm_create(const fg_edm_config* cfg, fg_edm** out);
+FG_API void fg_edm_destroy(fg_edm* h);
 
 /* State-dict view: the entries of the reference's EDMPrecond.state_dict() that carry weights (parameters
  * only; the constant resample_filter buffers are folded into the kernels).  Same names, same shapes. */
-int fg_edm_num_params(const fg_edm* h);
-int fg_edm_param_info(const fg_edm* h, int index, const char** name, int* ndim, int64_t shape[4]);
+FG_API int fg_edm_num_params(const fg_edm* h);
+FG_API int fg_edm_param_info(const fg_edm* h, int index, const char** name, int* ndim, int64_t shape[4]);
 
 /* Bind a parameter to caller-owned DEVICE memory (fp32, reference layout).  The pointer is borrowed: it is
  * read again by every fg_edm_pack_weights() and must stay valid until then.  Used instead of a one-shot
  * load so FSDP2 / optimizer updates can re-bind and re-pack. */
-int fg_edm_bind_param(fg_edm* h, const char* name, const float* device_ptr, int64_t numel);
+FG_API int fg_edm_bind_param(fg_edm* h, const char* name, const float* device_ptr, int64_t numel);
 /* Build the kernel-layout copies (MFMA fragment order, compute dtype) of all bound parameters. */
-int fg_edm_pack_weights(fg_edm* h, void* stream);
+FG_API int fg_edm_pack_weights(fg_edm* h, void* stream);
 
 /* Bytes of caller-provided scratch needed for a batch (activations, skip stack, norm statistics ...). */
-size_t fg_edm_workspace_bytes(const fg_edm* h, int batch);
+FG_API size_t fg_edm_workspace_bytes(const fg_edm* h, int batch);
 
 /* EDMPrecond.forward(x_t, t, condition=class_labels, r=r, fwd_pred_type=net_pred_type) in eval mode
  * (EDM/network.py:881-974).  x_t,out: [B,C,H,W] fp32; t: [B] fp64; r: [B] fp64, required iff cfg.r_timestep (else
  * NULL, :505-510); class_labels: [B,label_dim] fp32 or NULL (NULL = the reference's zeros([1,label_dim]) broadcast,
  * :919-925).  All device pointers.  x_t is not modified; out may not alias x_t.  emb_out (nullable):
  * [B, model_channels*channel_mult_emb] mapping-network output. */
-int fg_edm_forward(fg_edm* h, const float* x_t, const double* t, const double* r, const float* class_labels, float* out,
+FG_API int fg_edm_forward(fg_edm* h, const float* x_t, const double* t, const double* r, const float* class_labels, float* out,
                    float* emb_out, int batch, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same forward with the encoder feature taps of SongUNet.forward (EDM/network.py:525-544, 562-567): tap i is the i-th
@@ -118,9 +122,9 @@ int fg_edm_forward(fg_edm* h, const float* x_t, const double* t, const double* r
  * DMD2 discriminator reads (methods/distribution_matching/dmd2.py:142).  features: HOST array of
  * fg_edm_num_feature_taps() device pointers, each NULL (not requested: the reference's feature_indices set) or an
  * [B, channels, res, res] fp32 NCHW buffer.  out == NULL is return_features_early: the decoder is not run. */
-int fg_edm_num_feature_taps(const fg_edm* h);
-int fg_edm_feature_info(const fg_edm* h, int index, const char** key, int* channels, int* resolution);
-int fg_edm_forward_features(fg_edm* h, const float* x_t, const double* t, const double* r, const float* class_labels,
+FG_API int fg_edm_num_feature_taps(const fg_edm* h);
+FG_API int fg_edm_feature_info(const fg_edm* h, int index, const char** key, int* channels, int* resolution);
+FG_API int fg_edm_forward_features(fg_edm* h, const float* x_t, const double* t, const double* r, const float* class_labels,
                             float* out, float* const* features, int batch, void* workspace, size_t workspace_bytes,
                             void* stream);
 
@@ -135,83 +139,84 @@ int fg_edm_forward_features(fg_edm* h, const float* x_t, const double* t, const 
  * t_list: HOST array of steps+1 doubles, t_list[steps] must be 0 (model.py:410).  sample_type FG_SAMPLE_*.
  * eps: device [steps-1][B,C,H,W] noise to inject in 'sde' mode, or NULL to draw it on device from
  * (seed, step) with Philox4x32-10.  use_graph != 0 replays a cached hipGraph of the whole loop. */
-int fg_sampler_run(fg_edm* h, const float* noise, const float* class_labels, const double* t_list, int steps,
+FG_API int fg_sampler_run(fg_edm* h, const float* noise, const float* class_labels, const double* t_list, int steps,
                    int sample_type, int loop_kind, const float* eps, uint64_t seed, float* out, int batch,
                    void* workspace, size_t workspace_bytes, int use_graph, void* stream);
 
 /* EDMNoiseSchedule.get_t_list(sample_steps) (noise_schedule.py:940-973) -> steps+1 doubles on the host. */
-int fg_edm_t_list(int sample_steps, double* out_host);
+FG_API int fg_edm_t_list(int sample_steps, double* out_host);
 /* RFNoiseSchedule.get_t_list(sample_steps) = BaseNoiseSchedule.get_t_list (noise_schedule.py:259-272). */
-int fg_rf_t_list(int sample_steps, double* out_host);
+FG_API int fg_rf_t_list(int sample_steps, double* out_host);
 
 /* ---- measurement hook (bench.py): time every launch of the dominant kernel — the fused 3x3 conv at 32x32 output
  * without resampling — with a hipEvent pair on the stream it is launched on.  While active the sampler runs eagerly
  * (no graph replay).  profile_end() synchronises the events and returns launches, summed milliseconds and summed
  * algorithmic FLOPs (2 * B*H*W * Cout * 9*Cin per launch). */
-int fg_edm_profile_begin(fg_edm* h);
-int fg_edm_profile_end(fg_edm* h, int64_t* launches, double* total_ms, double* total_flops);
+FG_API int fg_edm_profile_begin(fg_edm* h);
+FG_API int fg_edm_profile_end(fg_edm* h, int64_t* launches, double* total_ms, double* total_flops);
 
 /* ---- single-op entry points (used by the parity tests; same kernels the network path launches) ---- */
 
 /* One UNetBlock (EDM/network.py:274-299) by index into the encoder+decoder block list.  Inputs NHWC fp32:
  * x1 [B,Hin,Win,c1] (+ optional x2 [B,Hin,Win,c2] = the skip tensor of the decoder's channel concat),
  * emb [B,emb_channels]; out [B,H,W,cout] NHWC. */
-int fg_edm_num_blocks(const fg_edm* h);
-int fg_edm_block_info(const fg_edm* h, int index, const char** key, int* cin, int* cout, int* res_in, int* res_out,
+FG_API int fg_edm_num_blocks(const fg_edm* h);
+FG_API int fg_edm_block_info(const fg_edm* h, int index, const char** key, int* cin, int* cout, int* res_in, int* res_out,
                       int* has_attention);
-int fg_edm_run_block(fg_edm* h, int index, const float* x1, int c1, const float* x2, int c2, const float* emb,
+FG_API int fg_edm_run_block(fg_edm* h, int index, const float* x1, int c1, const float* x2, int c2, const float* emb,
                      float* out, int batch, void* workspace, size_t workspace_bytes, void* stream);
 
 /* GroupNorm statistics folded with the affine parameters: ab[b][c] = {a, b} with y = a*x + b
  * (GroupNorm.forward, EDM/network.py:141-149; groups = min(32, C/4)).  x NHWC fp32 [B,HW,C]. */
-int fg_op_gn_coeffs(const float* x1, int c1, const float* x2, int c2, const float* gamma, const float* beta,
+FG_API int fg_op_gn_coeffs(const float* x1, int c1, const float* x2, int c2, const float* gamma, const float* beta,
                     float eps, float* ab_out, int batch, int hw, void* stream);
 
 /* Elementwise sampler steps in fp64 (noise_schedule.py:72-88, 425-449, 544-574); n = elements per sample. */
-int fg_op_latents(const float* noise, double t_init, float* out, int64_t total, void* stream);
-int fg_op_forward_process(const float* x0, const float* eps, double t, int schedule, float* out, int64_t total,
+FG_API int fg_op_latents(const float* noise, double t_init, float* out, int64_t total, void* stream);
+FG_API int fg_op_forward_process(const float* x0, const float* eps, double t, int schedule, float* out, int64_t total,
                           void* stream);
-int fg_op_x0_to_eps(const float* xt, const float* x0, double t, int schedule, float* out, int64_t total, void* stream);
+FG_API int fg_op_x0_to_eps(const float* xt, const float* x0, double t, int schedule, float* out, int64_t total, void* stream);
 /* ---- training step, first kernel (forward-only sampling does not use it) --------------------------------
  * Weight gradient of Conv2d.forward (EDM/network.py:93-126) as autograd computes it in the DMD2 student / fake-score
  * updates: dw[co][ci][ky][kx] (+)= sum_{n,y,x} dy[n,y,x,co] * act[n,y+ky-ks/2,x+kx-ks/2,ci], zero padding.
  * act [B,res,res,cin] and dy [B,res,res,cout] are NHWC bf16 (the conv's input operand and its output gradient),
  * dw is fp32 OIHW [cout,cin,ks,ks]; accumulate != 0 adds to dw.  Deterministic (fixed-order split-K reduction through
  * the workspace).  res in {8,16,32}, cin % 32 == 0 (ks = 3) / cin % 128 == 0 (ks = 1), cout % 128 == 0, ks in {1,3}. */
-size_t fg_op_conv_wgrad_workspace_bytes(int batch, int res, int cin, int cout, int ks);
-int fg_op_conv_wgrad(const void* act, const void* dy, float* dw, int batch, int res, int cin, int cout, int ks,
+FG_API size_t fg_op_conv_wgrad_workspace_bytes(int batch, int res, int cin, int cout, int ks);
+FG_API int fg_op_conv_wgrad(const void* act, const void* dy, float* dw, int batch, int res, int cin, int cout, int ks,
                      int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Backward of one UNetBlock (EDM/network.py:274-299) as autograd computes it, bf16 compute mode, blocks without attention
- * or resampling (27 of the 33).  Same tensor conventions as fg_edm_run_block (NHWC fp32 x1 / x2 / dout / dx1 / dx2, emb and
- * demb [B, emb_channels]).  The block's forward is recomputed first.  Parameter gradients are ACCUMULATED into the fp32
- * buffers bound with fg_edm_bind_grad (same names and shapes as the parameters; unbound = not computed); demb is
- * accumulated as well (zero it first); dx1 / dx2 are overwritten (either may be NULL). */
-int fg_edm_bind_grad(fg_edm* h, const char* name, float* grad, int64_t numel);
-size_t fg_edm_block_backward_workspace_bytes(const fg_edm* h, int index, int batch);
-int fg_edm_run_block_backward(fg_edm* h, int index, const float* x1, int c1, const float* x2, int c2, const float* emb,
+/* Backward of one UNetBlock (EDM/network.py:274-299) as autograd computes it (bf16 compute mode; every block variant: attention,
+ * 2x down / up resampling, channel-concat input).  Same tensor conventions as fg_edm_run_block (NHWC fp32 x1 / x2 / dout / dx1 / dx2,
+ * emb and demb [B, emb_channels]).  The block's forward is recomputed first.  Parameter gradients are ACCUMULATED into the fp32
+ * buffers bound with fg_edm_bind_grad (same names and shapes as the parameters; unbound = not computed); demb is accumulated as
+ * well (zero it first); dx1 / dx2 are overwritten (either may be NULL). */
+FG_API int fg_edm_bind_grad(fg_edm* h, const char* name, float* grad, int64_t numel);
+FG_API size_t fg_edm_block_backward_workspace_bytes(const fg_edm* h, int index, int batch);
+FG_API int fg_edm_run_block_backward(fg_edm* h, int index, const float* x1, int c1, const float* x2, int c2, const float* emb,
                               const float* dout, float* dx1, float* dx2, float* demb, int batch, void* workspace,
                               size_t workspace_bytes, void* stream);
 
-/* Whole-network backward (bf16 compute mode): runs EDMPrecond.forward (-> out, as fg_edm_forward) keeping every block input,
- * then differentiates it block by block in reverse (each block's forward is recomputed: activation checkpointing at block
- * granularity).  dout [B,C,H,W] fp32 is dL/d(out).  Gradients of all bound parameters (fg_edm_bind_grad) are ACCUMULATED;
- * the input x_t receives no gradient (the student's input is noise).  This is what autograd computes for the student /
- * fake-score network in fastgen/methods/distribution_matching/dmd2.py. */
-size_t fg_edm_backward_workspace_bytes(const fg_edm* h, int batch);
-int fg_edm_backward(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* dout,
+/* Whole-network backward (bf16 compute mode) of EDMPrecond.forward, what autograd computes for the student / fake-score network in
+ * fastgen/methods/distribution_matching/dmd2.py.  have_forward == 0: runs the kept forward itself first (-> out, as
+ * fg_edm_forward_train); have_forward != 0: a fg_edm_forward_train of the same batch / workspace / inputs precedes this call and its
+ * per-block stash is differentiated as it stands - nothing but the cheap conv operands silu(norm(x)) is recomputed.  dout [B,C,H,W]
+ * fp32 is dL/d(out).  Gradients of all bound parameters (fg_edm_bind_grad) are ACCUMULATED.  The gradient of x_t and gradients
+ * arriving at the feature taps are served by fg_edm_backward_ex below (this entry point = that one with dfeatures = dx_t = NULL). */
+FG_API size_t fg_edm_backward_workspace_bytes(const fg_edm* h, int batch);
+FG_API int fg_edm_backward(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* dout,
                     float* out, int have_forward, int batch, void* workspace, size_t workspace_bytes, void* stream);
 /* The forward half on its own (-> out), leaving in `workspace` (sized by fg_edm_backward_workspace_bytes) what the backward
  * reads.  A following fg_edm_backward(..., have_forward = 1, same batch, same workspace, same x_t / labels) skips its own
  * forward (out may then be NULL); nothing else may write to that workspace in between. */
-int fg_edm_forward_train(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, float* out,
+FG_API int fg_edm_forward_train(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, float* out,
                          float* const* features, int batch, void* workspace, size_t workspace_bytes, void* stream);
 /* fg_edm_backward with the gradient paths DMD2's GAN branch uses (dmd2.py:137-146: the frozen teacher's feature taps feed the
  * discriminator, whose loss is differentiated back to the teacher's INPUT): dfeatures[tap] (array as in fg_edm_forward_features,
  * entries nullable, NCHW fp32) joins the gradient of that encoder output; dout == NULL means the forward returned the taps early
  * and only the encoder is differentiated; dx_t (nullable, [B,C,H,W] fp32) receives dL/dx_t.  features / out of
  * fg_edm_forward_train follow fg_edm_forward_features (out == NULL: early return). */
-int fg_edm_backward_ex(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* dout,
+FG_API int fg_edm_backward_ex(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* dout,
                        const float* const* dfeatures, float* out, float* dx_t, int have_forward, int batch, void* workspace,
                        size_t workspace_bytes, void* stream);
 
@@ -220,38 +225,44 @@ int fg_edm_backward_ex(fg_edm* h, const float* x_t, const double* t, const doubl
  * device pointers in the reference's module order ({conv.weight, conv.bias, gn.weight, gn.bias} per strided conv, then the 1x1
  * conv's weight and bias), fp32, reference shapes.  dlogits == NULL: forward only.  Otherwise also the backward of the same call:
  * dfeat (nullable, overwritten) and grads (nullable array / entries; same order and shapes as params; accumulated). */
-int fg_disc_edm_num_params(int res);
-size_t fg_disc_edm_workspace_bytes(int res, int batch);
-int fg_disc_edm_run(const float* feat, int res, const float* const* params, float* logits, const float* dlogits, float* dfeat,
+FG_API int fg_disc_edm_num_params(int res);
+FG_API size_t fg_disc_edm_workspace_bytes(int res, int batch);
+FG_API int fg_disc_edm_run(const float* feat, int res, const float* const* params, float* logits, const float* dlogits, float* dfeat,
                     float* const* grads, int batch, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Forward-mode derivative (`torch.func.jvp(net, (x_t, t, r), tangents)` in MeanFlowModel._jvp / sCM,
  * consistency_model/mean_flow.py:240-250, sCM.py:179): out = EDMPrecond.forward(x_t, t, r), jvp = its directional derivative along
  * (vx [B,C,H,W], vt [B], vr [B]) (vt / vr nullable = 0; fp32).  bf16 compute mode; workspace sized by
  * fg_edm_backward_workspace_bytes (the pass runs next to the kept forward and reuses its per-block stash). */
-int fg_edm_jvp(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* vx, const float* vt,
+FG_API int fg_edm_jvp(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* vx, const float* vt,
                const float* vr, float* out, float* jvp, int batch, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The module's train()/eval() state as far as the arithmetic depends on it: `sigma_shift = None if self.training else
+ * self.sigma_shift` (EDM/network.py:956).  training != 0: every following forward / backward / jvp / sampler call of this handle
+ * evaluates precond_output without the shift; 0 (the state of a new handle): with cfg.sigma_shift.  Dropout is separate
+ * (fg_edm_set_dropout): the reference's F.dropout also follows self.training, the module mirrors that when it sets both. */
+FG_API int fg_edm_set_training(fg_edm* h, int training);
 
 /* Augmentation labels of the training-time augmentation pipeline (EDM/network.py:495, 518-519, 903-915: condition =
  * {"aug_condition", "orig_condition"}): [B, augment_dim] fp32, added to the mapping network's input through map_augment by every
  * following forward / backward / jvp call of this handle until reset with NULL (borrowed pointer; must cover the call's batch). */
-int fg_edm_set_augment(fg_edm* h, const float* augment_labels);
+FG_API int fg_edm_set_augment(fg_edm* h, const float* augment_labels);
 
 /* Training-mode dropout of conv1's operand in every UNetBlock (EDM/network.py:283-284; the SFT config trains with p = 0.13):
  * honoured by fg_edm_forward_train / fg_edm_backward(_ex) / fg_edm_jvp (never by the inference entry points), p = 0 turns it off.
  * The mask is Philox4x32-10(seed; element, block) - the backward regenerates it - so a forward and its backward must see the same
  * (p, seed); set p before sizing the workspace (one more tensor per block).  fg_op_dropout_mask writes the keep factors
  * (0 or 1/(1-p)) of one block's operand, flattened [B, H*W, C] (parity tests). */
-int fg_edm_set_dropout(fg_edm* h, float p, uint64_t seed);
-int fg_op_dropout_mask(float* out, int64_t total, float p, uint32_t block_index, uint64_t seed, void* stream);
+FG_API int fg_edm_set_dropout(fg_edm* h, float p, uint64_t seed);
+FG_API int fg_op_dropout_mask(float* out, int64_t total, float p, uint32_t block_index, uint64_t seed, void* stream);
 
 /* Samples to image bytes, the step after generator_fn in the reference's sample writer
  * (scripts/fid/compute_fid_from_ckpts.py:199): out[n,y,x,c] = uint8(clip(images[n,c,y,x] * 127.5 + 128, 0, 255)),
  * fp32 multiply then add, truncation; NaN -> 0.  images NCHW fp32, out NHWC bytes. */
-int fg_op_images_to_u8(const float* images, uint8_t* out, int64_t batch, int channels, int height, int width,
+FG_API int fg_op_images_to_u8(const float* images, uint8_t* out, int64_t batch, int channels, int height, int width,
                        void* stream);
 /* Standard normal draws: Philox4x32-10(key = seed, counter = (offset, index/4)) + Box-Muller. */
-int fg_op_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, void* stream);
+FG_API int fg_op_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, void* stream);
 
 #ifdef __cplusplus
 }

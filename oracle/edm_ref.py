@@ -334,8 +334,10 @@ def song_unet(sd, cfg: SongUNetConfig, x: Tensor, noise_labels: Tensor, class_la
 
 
 def edm_precond_forward(sd, cfg: SongUNetConfig, x_t: Tensor, t: Tensor, condition: Optional[Tensor], trace=None,
-                        r: Optional[Tensor] = None, augment_labels: Optional[Tensor] = None, drop_keeps=None) -> Tensor:
-    """EDMPrecond.forward with fwd_pred_type = net_pred_type (identity conversion), eval mode, EDM/network.py:881-974;
+                        r: Optional[Tensor] = None, augment_labels: Optional[Tensor] = None, drop_keeps=None,
+                        training: bool = False) -> Tensor:
+    """EDMPrecond.forward with fwd_pred_type = net_pred_type (identity conversion), EDM/network.py:881-974 (training=True:
+    the module in train() mode, which only changes sigma_shift here, :956 - dropout comes in through drop_keeps);
     precond_input :755-778 (clamp_min 1e-6 from the scheduler, :930), precond_output :781-805; drop_precond :929-934,
     :959-960.  t (and r) are float64 on entry; coefficients are computed in float64 and cast to x_t.dtype before use."""
     B = x_t.shape[0]
@@ -362,7 +364,7 @@ def edm_precond_forward(sd, cfg: SongUNetConfig, x_t: Tensor, t: Tensor, conditi
                     drop_keeps=drop_keeps)  # drop_keeps: {block key: keep factors} of a training-mode call, or None
     if cfg.drop_precond in ("output", "both"):
         return F_x
-    ts = t - cfg.sigma_shift  # eval mode
+    ts = t if training else t - cfg.sigma_shift  # the shift is applied in eval mode only (EDM/network.py:956)
     c_skip = (cfg.sigma_data**2 / (ts**2 + cfg.sigma_data**2)).to(x_t.dtype).reshape(B, 1, 1, 1)
     c_out = (ts * cfg.sigma_data / (ts**2 + cfg.sigma_data**2).sqrt()).to(x_t.dtype).reshape(B, 1, 1, 1)
     return c_skip * x_t + c_out * F_x

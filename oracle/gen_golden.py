@@ -12,6 +12,7 @@ Usage:  python oracle/gen_golden.py            (writes tests/golden/*.pt)
         python oracle/gen_golden.py meanflow   (only the MeanFlow / rectified-flow fixtures)
         python oracle/gen_golden.py sample     (only the teacher Euler-sampler fixture)
         python oracle/gen_golden.py train_schedule   (only the training-side schedule helpers)
+        python oracle/gen_golden.py sigma_shift   (only the eval- vs train-mode sigma_shift fixture)
         python oracle/gen_golden.py backward   (only the training-step fixtures: conv weight gradients)
 """
 import os
@@ -505,6 +506,32 @@ def augment_fixture(edm_net):
     torch.save(fx, os.path.join(OUT, "augment_b2.pt"))
 
 
+def sigma_shift_fixture(edm_net):
+    """sigma_shift is applied in eval mode only (EDM/network.py:956: `None if self.training else self.sigma_shift`): the
+    reference with sigma_shift = 0.003 (the value suggested in its consistency-model configs) in eval() and in train() mode
+    (dropout 0, so train() is deterministic), output and the gradient of <out, dout> with respect to x_t, B = 2, timesteps
+    small enough for the shift to matter."""
+    import dataclasses
+    cfg = dataclasses.replace(edm_ref.CIFAR10, sigma_shift=0.003)
+    sd = edm_ref.random_state_dict(cfg, seed=1234)
+    net = ref_net(edm_net, cfg, sd)
+    tt = torch.tensor([0.5, 0.0045], dtype=torch.float64)
+    xin = seeded((2, 3, 32, 32), 131)
+    cond = torch.nn.functional.one_hot(torch.tensor([2, 9]), 10).float()
+    dout = seeded((2, 3, 32, 32), 132)
+    fx = {"t": tt, "cond": cond, "sigma_shift": torch.tensor(cfg.sigma_shift)}
+    for mode in ("eval", "train"):
+        net.train(mode == "train")
+        x = (xin * (0.25 + tt.reshape(2, 1, 1, 1).float())).requires_grad_(True)
+        out = net(x, tt, condition=cond, fwd_pred_type="x0")
+        (dx,) = torch.autograd.grad((out * dout).sum(), x)
+        oo = edm_ref.edm_precond_forward(sd, cfg, x.detach(), tt, cond, training=(mode == "train"))
+        assert torch.allclose(oo, out, rtol=1e-4, atol=1e-5), mode
+        fx[f"out_{mode}"], fx[f"dx_{mode}"] = out.detach().clone(), dx.clone()
+    assert (fx["out_eval"] - fx["out_train"]).abs().max() > 1e-3  # the shift does change the result at these timesteps
+    torch.save(fx, os.path.join(OUT, "sigma_shift_b2.pt"))
+
+
 def dropout_fixture(edm_net):
     """Training-mode dropout (EDM/network.py:283-284; the SFT config trains with p = 0.13): the reference in train() mode with
     `torch.nn.functional.dropout` replaced by a deterministic stand-in that multiplies by explicit keep factors drawn from seeded
@@ -571,6 +598,10 @@ def main():
         augment_fixture(edm_net)
         dropout_fixture(edm_net)
         print("augment fixture written to", OUT)
+        return
+    if sys.argv[1:] == ["sigma_shift"]:
+        sigma_shift_fixture(edm_net)
+        print("sigma_shift fixture written to", OUT)
         return
     if sys.argv[1:] == ["jvp"]:
         jvp_fixture(edm_net)

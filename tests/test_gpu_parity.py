@@ -786,6 +786,45 @@ def test_module_autograd_through_the_hip_backward(nets, golden_dir):
         net.zero_grad(set_to_none=True)
 
 
+def test_sigma_shift_follows_train_eval_mode(sd, golden_dir):
+    """sigma_shift enters precond_output in eval mode only (EDM/network.py:956).  Module with sigma_shift = 0.003 against the
+    reference in both modes (tests/golden/sigma_shift_b2.pt): outputs in every compute mode, d<out, dout>/dx_t through the
+    bf16 backward, the forward-mode derivative along x consistent with it, and the fused sampler (eval mode by construction)."""
+    fx = load(golden_dir, "sigma_shift_b2.pt")
+    t, cond = fx["t"].to(dev()), fx["cond"].to(dev())
+    x = (seeded((2, 3, 32, 32), 131) * (0.25 + fx["t"].reshape(2, 1, 1, 1).float())).to(dev())
+    dout = seeded((2, 3, 32, 32), 132).to(dev())
+    for mode in ("fp32", "bf16x3", "bf16"):
+        net = EDMPrecond(compute_dtype=mode, **{**KW, "sigma_shift": float(fx["sigma_shift"])})
+        net.load_state_dict(sd, strict=True)
+        net = net.to(dev())
+        for tr in (False, True, False):  # and back: the flag is per call, not sticky
+            net.train(tr)
+            with torch.no_grad():
+                check(net(x, t, condition=cond, fwd_pred_type="x0"), fx["out_train" if tr else "out_eval"], mode, f"{mode} train={tr}")
+        if mode == "bf16":
+            net.requires_grad_(False)
+            for tr in (False, True):
+                net.train(tr)
+                xg = x.clone().requires_grad_(True)
+                net(xg, t, condition=cond, fwd_pred_type="x0").backward(dout)
+                want = fx["dx_train" if tr else "dx_eval"]
+                r = float((xg.grad.cpu() - want).norm() / want.norm())
+                assert r <= 8e-2, (tr, r)
+                # forward mode agrees: <jvp(v), dout> == <v, dx>
+                v = seeded((2, 3, 32, 32), 133).to(dev())
+                _, jv = net.jvp(x, t, v, condition=cond)
+                lhs, rhs = float((jv * dout).sum()), float((v.cpu() * want).sum())
+                assert abs(lhs - rhs) <= 5e-2 * abs(rhs) + 1e-3, (tr, lhs, rhs)
+            net.train(True)  # generator_fn switches to eval for the call and restores (utils/basic_utils.py:89-125)
+            noise = seeded((2, 3, 32, 32), 7).to(dev())
+            a = FastGenModel.generator_fn(net, noise, condition=cond, student_sample_steps=2, student_sample_type="ode")
+            assert net.training
+            net.eval()
+            b = FastGenModel.generator_fn(net, noise, condition=cond, student_sample_steps=2, student_sample_type="ode")
+            assert torch.equal(a, b)
+
+
 def test_module_autograd_feature_taps_and_input_gradient(nets, golden_dir):
     """The gradient paths of DMD2's GAN branch (dmd2.py:137-146): the frozen teacher's feature taps feed the discriminator and
     the loss is differentiated back to the teacher's INPUT.  d out / d x_t, early-returned taps -> x_t and encoder parameters,

@@ -35,6 +35,16 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in L.fg_version()
 
 
+def test_library_exports_nothing_but_its_api():
+    """Built with -fvisibility=hidden: the only functions in the dynamic symbol table are the fg_* entry points (no engine or
+    launcher helper that could collide with another library inside a PyTorch process)."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    funcs = [ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in ("T", "t")]
+    assert funcs and all(f.startswith("fg_") for f in funcs), [f for f in funcs if not f.startswith("fg_")]
+
+
 def test_create_rejects_unsupported_configs():
     L = _lib.lib()
     cfg = _lib.fg_edm_config()

@@ -318,3 +318,18 @@ def test_oracle_training_mode_dropout(golden_dir, full_sd):
     out = R.edm_precond_forward(full_sd, R.CIFAR10, x, fx["t"], fx["cond"], drop_keeps=keeps)
     assert torch.allclose(out, fx["out"], rtol=1e-4, atol=1e-5)
     assert not torch.allclose(R.edm_precond_forward(full_sd, R.CIFAR10, x, fx["t"], fx["cond"]), fx["out"], atol=1e-3)
+
+
+def test_oracle_sigma_shift_is_an_eval_mode_term(golden_dir):
+    """`sigma_shift = None if self.training else self.sigma_shift` (EDM/network.py:956): the reference with sigma_shift = 0.003 in
+    eval() and train() mode (tests/golden/sigma_shift_b2.pt, recorded by oracle/gen_golden.py sigma_shift)."""
+    import dataclasses
+
+    fx = torch.load(os.path.join(golden_dir, "sigma_shift_b2.pt"), weights_only=True)
+    cfg = dataclasses.replace(R.CIFAR10, sigma_shift=float(fx["sigma_shift"]))
+    sd = R.random_state_dict(cfg, seed=1234)
+    x = torch.randn((2, 3, 32, 32), generator=torch.Generator().manual_seed(131)) * (0.25 + fx["t"].reshape(2, 1, 1, 1).float())
+    for mode in ("eval", "train"):
+        out = R.edm_precond_forward(sd, cfg, x, fx["t"], fx["cond"], training=(mode == "train"))
+        assert (out - fx[f"out_{mode}"]).abs().max() < 1e-4, mode
+    assert (fx["out_eval"] - fx["out_train"]).abs().max() > 1e-3
