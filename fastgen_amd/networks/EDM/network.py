@@ -49,6 +49,16 @@ class _Node(nn.Module):
     """Bare container: the parameter tree only has to reproduce the reference's state-dict key paths."""
 
 
+class _UNet(_Node):
+    """The `model` node (SongUNet in the reference).  The fused engine call runs INSIDE this module's forward - `self.model(fn)`
+    just evaluates `fn()` - so that hooks registered on it fire around the call exactly as they do around SongUNet.forward in the
+    reference: FSDP2's, after `fully_shard` (pre-forward all-gather of the root group, pre-backward hook on the outputs, the
+    root's post-backward callback that reduce-scatters every group's gradients)."""
+
+    def forward(self, fn):
+        return fn()
+
+
 def _xavier_uniform(shape, fan_in, fan_out):
     return math.sqrt(6 / (fan_in + fan_out)) * (torch.rand(*shape) * 2 - 1)
 
@@ -81,7 +91,7 @@ class _EDMForwardFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, x32, t64, r64, labels, taps_aug, early, *weights):
-        taps, aug, drop = taps_aug
+        taps, aug, drop, ctx.names = taps_aug
         ctx.aug, ctx.drop = aug, drop
         ctx.training = net.training  # the backward differentiates the forward that ran, whatever mode the module is in by then
         # outputs nothing depends on (DMD2 detaches the teacher's prediction and keeps its taps) arrive in backward as None, not as
@@ -127,11 +137,14 @@ class _EDMForwardFn(torch.autograd.Function):
         x32, t64, r64, labels = ctx.saved_tensors
         dev, B = x32.device, x32.shape[0]
         L = _lib.lib()
+        # under FSDP2 the root group was all-gathered by its pre-backward hook; the blocks' groups are gathered here and stay
+        # unsharded until the root's post-backward callback reduce-scatters their gradients and reshards them
+        net._unshard_all()
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
             dt, h = net._engine(dev)
         assert dt == _lib.FG_DTYPE_BF16
         _lib.check(L.fg_edm_set_training(h, int(ctx.training)))
-        named = net._named_weights()
+        named = net._named_weights(ctx.names)
         # one zero-filled fp32 buffer, one view per trainable parameter (a fill per parameter costs 400+ launches)
         need_w = [p.requires_grad and ctx.needs_input_grad[7 + i] for i, (_, p) in enumerate(named)]
         flat = torch.zeros(sum(p.numel() for (_, p), nw in zip(named, need_w) if nw), dtype=torch.float32, device=dev)
@@ -266,7 +279,7 @@ class EDMPrecond(FastGenNetwork):
         self._noise_channels = cfg.model_channels * cfg.channel_mult_noise
 
         # parameter tree with the reference's key paths; names/shapes come from the library's own plan
-        self.model = _Node()
+        self.model = _UNet()
         self._param_names: List[str] = []
         h = self._make_engine(_lib.FG_DTYPE_F32)
         L = _lib.lib()
@@ -302,9 +315,17 @@ class EDMPrecond(FastGenNetwork):
         except Exception:
             pass
 
-    def _named_weights(self):
+    def _named_weights(self, names=None):
         sd = dict(self.named_parameters())
-        return [(n, sd[n]) for n in self._param_names]
+        return [(n, sd[n]) for n in (self._param_names if names is None else names)]
+
+    def _diff_names(self, with_augment: bool):
+        """Parameters the engine's forward reads, i.e. the inputs of the autograd Function.  The rest stays out of the graph and
+        keeps `.grad = None`, as in the reference (which trains with ddp_find_unused_parameters=True for exactly these,
+        configs/config.py:158-161): `logvar_linear` (differentiated by ordinary autograd when return_logvar is used) and
+        `map_augment` when the call carries no augmentation labels - so AdamW neither decays them nor advances their state."""
+        return tuple(n for n in self._param_names
+                     if not n.startswith("model.logvar_linear") and (with_augment or n != "model.map_augment.weight"))
 
     def _select_dtype(self) -> int:
         if self.compute_dtype is not None:
@@ -324,6 +345,11 @@ class EDMPrecond(FastGenNetwork):
             self._engines[dt] = self._make_engine(dt)
         h = self._engines[dt]
         weights = self._named_weights()
+        for n, p in weights:
+            if hasattr(p, "_local_tensor") or hasattr(p.data, "_local_tensor"):
+                raise RuntimeError(
+                    f"parameter {n} is a sharded DTensor: the engine reads whole parameters.  Call the network through "
+                    "forward() / jvp() / few_step_sample() / generator_fn(), which all-gather FSDP2 groups around the call")
         sig = tuple((p.data_ptr(), p._version, p.dtype) for _, p in weights)
         if self._bound_sig.get(dt) != sig:
             L = _lib.lib()
@@ -445,8 +471,17 @@ class EDMPrecond(FastGenNetwork):
         return self
 
     def fully_shard(self, **kwargs):
-        """Same wrapping granularity as the reference (EDM/network.py:861-879): every UNetBlock, then the U-Net.
-        The fused forward reads whole parameters, so callers must unshard (`self.model.unshard()`) around it."""
+        """FSDP2 with the reference's wrapping granularity (EDM/network.py:861-879): one parameter group per UNetBlock, then the
+        U-Net as the root group (embedding MLP, stem, head).  Between calls every parameter is a sharded DTensor, as in the
+        reference; the state dict, optimizer and checkpointing see exactly what they see there.
+
+        How the fused engine runs under it (`_fsdp_call`): the call is made inside `self.model`'s forward, so FSDP2's own hooks
+        all-gather / reshard the root group, hook the outputs for the backward and queue the root's post-backward callback; the
+        blocks' groups are all-gathered explicitly (`FSDPModule.unshard`, asynchronously, all in flight together) before the
+        engine binds the whole parameters, and resharded after it.  In the backward the same happens in reverse: the autograd
+        Function all-gathers the blocks, the engine writes whole gradients, autograd accumulates them into the unsharded
+        parameters' .grad, and FSDP2's post-backward callback reduce-scatters every group (reduce dtype fp32, as configured by
+        utils/distributed/fsdp.py:116-122) and reshards."""
         from torch.distributed.fsdp import fully_shard
 
         for group in (self.model._modules["enc"], self.model._modules["dec"]):
@@ -454,6 +489,45 @@ class EDMPrecond(FastGenNetwork):
                 if "conv0" in block._modules:
                     fully_shard(block, **kwargs)
         fully_shard(self.model, **kwargs)
+
+    def _fsdp_modules(self):
+        """FSDP2-managed modules of the tree, root (`self.model`) first; [] when `fully_shard` was not applied."""
+        try:
+            from torch.distributed.fsdp import FSDPModule
+        except ImportError:  # pragma: no cover
+            return []
+        return [m for m in self.model.modules() if isinstance(m, FSDPModule)]
+
+    def _unshard_all(self, skip_root: bool = False):
+        mods = self._fsdp_modules()
+        if skip_root:
+            mods = [m for m in mods if m is not self.model]
+        handles = [m.unshard(async_op=True) for m in mods]  # every all-gather in flight before the first wait
+        for hd in handles:
+            if hd is not None:
+                hd.wait()
+        return mods
+
+    def _fsdp_call(self, fn):
+        """Run `fn` (binds parameters, calls the engine) with whole parameters.  Plain module: just `fn()`."""
+        if not self._fsdp_modules():
+            return fn()
+
+        def run():
+            kids = self._unshard_all(skip_root=True)  # the root group is gathered by FSDP2's pre-forward hook of self.model
+            try:
+                return fn()
+            finally:
+                for m in kids:
+                    m.reshard()
+
+        res = self.model(run)
+        if not torch.is_grad_enabled():
+            # FSDP2 leaves the ROOT group gathered after a forward (a backward would need it next).  Without autograd there is no
+            # backward: reshard, so that inference leaves every parameter sharded (memory released, and an optimizer built
+            # afterwards sees the sharded parameters)
+            self.model.reshard()
+        return res
 
     # ------------------------------------------------------------------------------------------------
     def forward(
@@ -511,55 +585,64 @@ class EDMPrecond(FastGenNetwork):
                 raise ValueError(f"r has {r64.numel()} entries, expected {B}")
         labels = self._labels(condition, B, dev)
         aug = self._augment(condition, B, dev)
-        dt, h = self._engine(dev)
-        ws = self._workspace(dt, h, B, dev)
-        L = _lib.lib()
-        features: List[torch.Tensor] = []
-        if needs_grad or drop is not None:  # the training entry points (under no_grad the Function simply records nothing)
-            ntap = L.fg_edm_num_feature_taps(h)
-            taps = tuple(i for i in range(ntap) if i in feature_indices)
-            if return_features_early:
-                assert len(taps) == len(feature_indices), f"{len(taps)} != {len(feature_indices)}"
-            res = _EDMForwardFn.apply(self, x32, t64, r64, labels, (taps, aug, drop), bool(return_features_early),
-                                      *[p_ for _, p_ in self._named_weights()])
-            res = list(res)
-            out = None if return_features_early else res.pop(0)
-            features = [f.to(x_t.dtype) for f in res]
-            if return_features_early:
-                return features
-        elif len(feature_indices):
-            # tap i = the i-th encoder block named *block3* (EDM/network.py:535-539); indices beyond the taps are ignored by
-            # the reference's loop and trip its length assert only when returning early (:543)
-            ntap = L.fg_edm_num_feature_taps(h)
-            ptrs = (ctypes.c_void_p * max(ntap, 1))()
-            ch, res = ctypes.c_int(), ctypes.c_int()
-            for i in range(ntap):
-                if i in feature_indices:
-                    _lib.check(L.fg_edm_feature_info(h, i, None, ctypes.byref(ch), ctypes.byref(res)))
-                    f = torch.empty(B, ch.value, res.value, res.value, dtype=torch.float32, device=dev)
-                    ptrs[i] = f.data_ptr()
-                    features.append(f)
-            if return_features_early:
-                assert len(features) == len(feature_indices), f"{len(features)} != {len(feature_indices)}"
-            out = None if return_features_early else torch.empty_like(x32)
-            with self._AugmentScope(h, aug):
-                _lib.check(L.fg_edm_forward_features(
-                h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
-                ctypes.c_void_p(r64.data_ptr() if r64 is not None else None),
-                ctypes.c_void_p(labels.data_ptr() if labels is not None else None),
-                ctypes.c_void_p(out.data_ptr() if out is not None else None), ptrs, B, ctypes.c_void_p(ws.data_ptr()),
-                ws.numel(), self._stream(dev)))
-            features = [f.to(x_t.dtype) for f in features]
-            if return_features_early:
-                return features
-        else:
-            out = torch.empty_like(x32)
-            with self._AugmentScope(h, aug):
-                _lib.check(L.fg_edm_forward(
+
+        def engine_call():
+            """Everything that needs whole parameters: bind / pack, the engine call (or the autograd Function around it)."""
+            dt, h = self._engine(dev)
+            ws = self._workspace(dt, h, B, dev)
+            L = _lib.lib()
+            features: List[torch.Tensor] = []
+            if needs_grad or drop is not None:  # the training entry points (under no_grad the Function simply records nothing)
+                ntap = L.fg_edm_num_feature_taps(h)
+                taps = tuple(i for i in range(ntap) if i in feature_indices)
+                if return_features_early:
+                    assert len(taps) == len(feature_indices), f"{len(taps)} != {len(feature_indices)}"
+                names = self._diff_names(aug is not None)
+                res = _EDMForwardFn.apply(self, x32, t64, r64, labels, (taps, aug, drop, names), bool(return_features_early),
+                                          *[p_ for _, p_ in self._named_weights(names)])
+                res = list(res)
+                out = None if return_features_early else res.pop(0)
+                features = [f.to(x_t.dtype) for f in res]
+                if return_features_early:
+                    return None, features
+            elif len(feature_indices):
+                # tap i = the i-th encoder block named *block3* (EDM/network.py:535-539); indices beyond the taps are ignored by
+                # the reference's loop and trip its length assert only when returning early (:543)
+                ntap = L.fg_edm_num_feature_taps(h)
+                ptrs = (ctypes.c_void_p * max(ntap, 1))()
+                ch, res = ctypes.c_int(), ctypes.c_int()
+                for i in range(ntap):
+                    if i in feature_indices:
+                        _lib.check(L.fg_edm_feature_info(h, i, None, ctypes.byref(ch), ctypes.byref(res)))
+                        f = torch.empty(B, ch.value, res.value, res.value, dtype=torch.float32, device=dev)
+                        ptrs[i] = f.data_ptr()
+                        features.append(f)
+                if return_features_early:
+                    assert len(features) == len(feature_indices), f"{len(features)} != {len(feature_indices)}"
+                out = None if return_features_early else torch.empty_like(x32)
+                with self._AugmentScope(h, aug):
+                    _lib.check(L.fg_edm_forward_features(
                     h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
                     ctypes.c_void_p(r64.data_ptr() if r64 is not None else None),
-                    ctypes.c_void_p(labels.data_ptr() if labels is not None else None), ctypes.c_void_p(out.data_ptr()), None,
-                    B, ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream(dev)))
+                    ctypes.c_void_p(labels.data_ptr() if labels is not None else None),
+                    ctypes.c_void_p(out.data_ptr() if out is not None else None), ptrs, B, ctypes.c_void_p(ws.data_ptr()),
+                    ws.numel(), self._stream(dev)))
+                features = [f.to(x_t.dtype) for f in features]
+                if return_features_early:
+                    return None, features
+            else:
+                out = torch.empty_like(x32)
+                with self._AugmentScope(h, aug):
+                    _lib.check(L.fg_edm_forward(
+                        h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
+                        ctypes.c_void_p(r64.data_ptr() if r64 is not None else None),
+                        ctypes.c_void_p(labels.data_ptr() if labels is not None else None), ctypes.c_void_p(out.data_ptr()), None,
+                        B, ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream(dev)))
+            return out, features
+
+        out, features = self._fsdp_call(engine_call)
+        if return_features_early:
+            return features
         out = out.to(x_t.dtype)
         out = self.noise_scheduler.convert_model_output(x_t, out, t64, src_pred_type=self.net_pred_type,
                                                         target_pred_type=fwd_pred_type)
@@ -580,11 +663,14 @@ class EDMPrecond(FastGenNetwork):
             raise NotImplementedError("jvp is provided for the network's own prediction type")
         if r is None and self.r_timestep:
             raise ValueError("this network was built with r_timestep=True: jvp() needs r")
+        B, dev = x_t.shape[0], x_t.device
+        return self._fsdp_call(lambda: self._jvp_call(x_t, t, v_x, v_t, condition, r, v_r, B, dev))
+
+    def _jvp_call(self, x_t, t, v_x, v_t, condition, r, v_r, B, dev):
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            dt, h = self._engine(x_t.device)
+            dt, h = self._engine(dev)
         if dt != _lib.FG_DTYPE_BF16:
             raise NotImplementedError("fastgen_amd.EDMPrecond.jvp runs in the bf16 compute mode only")
-        B, dev = x_t.shape[0], x_t.device
         f32 = lambda a: None if a is None else torch.atleast_1d(a.detach()).to(device=dev, dtype=torch.float32).expand(B).contiguous()
         f64 = lambda a: None if a is None else torch.atleast_1d(a.detach()).to(device=dev, dtype=torch.float64).expand(B).contiguous()
         x32 = x_t.detach().to(torch.float32).contiguous()
@@ -621,7 +707,9 @@ class EDMPrecond(FastGenNetwork):
         ang = c_noise.ger(freqs)
         emb = torch.cat([ang.cos(), ang.sin()], dim=1)
         lv = self.model._modules["logvar_linear"]
-        return emb @ lv.weight.to(emb.dtype).t() + lv.bias.to(emb.dtype)
+        # under FSDP2 the two tensors are sharded DTensors between calls: full_tensor() all-gathers (and reduce-scatters the gradient)
+        w, b = (p.full_tensor() if hasattr(p, "full_tensor") else p for p in (lv.weight, lv.bias))
+        return emb @ w.to(emb.dtype).t() + b.to(emb.dtype)
 
     # ------------------------------------------------------------------------------------------------
     def fused_loop(self) -> Optional[str]:
@@ -668,12 +756,16 @@ class EDMPrecond(FastGenNetwork):
                 raise ValueError(f"eps must hold steps-1 = {steps - 1} noise tensors shaped like `noise`")
         if seed is None:
             seed = int(torch.randint(0, 2**62, (1,)).item())  # host RNG: follows torch.manual_seed / set_random_seed
-        dt, h = self._engine(dev)
-        ws = self._workspace(dt, h, B, dev)
         if out is None:
             out = torch.empty_like(n32)
         tl_arr = (ctypes.c_double * (steps + 1))(*tl)
         self._keep = (n32, labels, eps)  # graph replays read these buffers; keep them alive
+        self._fsdp_call(lambda: self._sampler_call(n32, labels, tl_arr, steps, sample_type, loop, eps, seed, out, B, dev, use_graph))
+        return out
+
+    def _sampler_call(self, n32, labels, tl_arr, steps, sample_type, loop, eps, seed, out, B, dev, use_graph):
+        dt, h = self._engine(dev)
+        ws = self._workspace(dt, h, B, dev)
         _lib.check(_lib.lib().fg_sampler_run(
             h, ctypes.c_void_p(n32.data_ptr()), ctypes.c_void_p(labels.data_ptr() if labels is not None else None),
             tl_arr, steps, _lib.FG_SAMPLE_SDE if sample_type == "sde" else _lib.FG_SAMPLE_ODE,
