@@ -1,14 +1,15 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence bench.py's roofline block refers to.  Run on the GPU box from the repo root:
-#   bash scripts/collect_profiles.sh <tag>        (writes gpurun_out/prof_<tag>/..., then scripts/summarise_profiles.py)
+#   bash scripts/collect_profiles.sh <tag> [bf16x3|bf16|fp32]        (writes gpurun_out/prof_<tag>/..., then scripts/summarise_profiles.py)
 # Counter passes are separate runs with --kernel-trace only (never combined with sys/hip/hsa traces).
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
+MODE=${2:-bf16x3}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+CMD="python3 $ROOT/bench.py --dtype $MODE --steps 2 --warmup 1 --no-cpu-baseline --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $CMD > $OUT/stats.log 2>&1
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" \

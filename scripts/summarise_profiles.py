@@ -6,7 +6,10 @@ from collections import defaultdict
 
 out, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOM = "conv3_ws_kernel<0, 5, 0, 4, 2>"  # 3x3, 256 out, 32x32, no resampling (wave-specialised)
+# the dominant kernel = the 3x3 conv at 32x32 without resampling, as a substring of the demangled name:
+#   bf16x3 (headline): conv_fused_kernel<bf16x3, 3, 2, 0, 5, 0, 0>     bf16: conv3_ws_kernel<0, 5, 0, 4, 2>
+DOM = sys.argv[3] if len(sys.argv) > 3 else "conv_fused_kernel<bf16x3, 3, 2, 0, 5, 0, 0>"
+MODE = sys.argv[4] if len(sys.argv) > 4 else "bf16x3"
 
 
 def short(n):
@@ -38,8 +41,8 @@ for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), r
 avg = {k: v[1] / v[0] for k, v in cnt.items() if v[0]}
 dom = [v for k, v in rows.items() if DOM in k]
 res = {
-    "kernel": DOM + " (dominant kernel of bench.py, bf16, batch 512)",
-    "command": "scripts/collect_profiles.sh: rocprofv3 --kernel-trace --pmc <group> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (one run per counter group)",
+    "kernel": DOM + f" (dominant kernel of bench.py, {MODE}, batch 512)",
+    "command": f"scripts/collect_profiles.sh: rocprofv3 --kernel-trace --pmc <group> --output-format csv -- python3 bench.py --dtype {MODE} --steps 2 --warmup 1 --no-cpu-baseline --no-secondary (one run per counter group)",
     "dispatches_per_pass": {k: v[0] for k, v in cnt.items()},
     "avg_launch_us_kernel_trace": (dom[0][1] / dom[0][0]) if dom else None,
     "counters_avg_per_dispatch": avg,
@@ -51,5 +54,10 @@ if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
     res["WRITE_SIZE_bytes"] = write_b
     res["fetch_correction"] = "x2: on gfx950 FETCH_SIZE counts 128-B requests at 64 B for 16-B/lane coalesced streams (MI355X_MICROARCH.md, HBM section)"
     res["hbm_bytes_per_launch"] = 2 * fetch_b + write_b
+if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg:
+    # busy cycles summed over 1024 SIMDs vs. shader-engine-active cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+    res["mfma_pipe_busy_frac"] = avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * avg["GRBM_GUI_ACTIVE"] / 8)
+    if dom:
+        res["effective_clock_GHz"] = avg["GRBM_GUI_ACTIVE"] / 8 / (dom[0][1] / dom[0][0]) / 1e3
 json.dump(res, open(os.path.join(root, "profiles", f"{tag}_pmc_dominant_kernel.json"), "w"), indent=1)
 print(json.dumps(res, indent=1)[:1500])
