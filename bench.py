@@ -31,15 +31,15 @@ GFLOP_PER_IMAGE_FWD = 42.383  # BASELINE.md section 2 (conv 42.034 + attention 0
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md:41-43; bf16x3 issues three bf16 MFMAs per algorithmic product
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}
 DOMINANT_KERNEL = {
-    "bf16x3": "conv_fused_kernel<bf16x3,3,PRO_GN_SILU,RES_NONE,32x32> (GroupNorm+SiLU -> hi/lo split -> 3x3 conv as 3 bf16 MFMAs per "
-              "product -> bias/temb/residual/scale + GN statistics)",
+    "bf16x3": "conv3_x3ws_kernel<RES_NONE,32x32> (GroupNorm+SiLU -> hi/lo split -> 3x3 conv as 3 bf16 16x16x32 MFMAs per product -> "
+              "bias/temb/residual/scale + GN statistics)",
     "bf16": "conv3_ws_kernel<RES_NONE,32x32> (GroupNorm+SiLU -> 3x3 conv -> bias/temb/residual/scale + GN statistics)",
     "fp32": "conv_fused_kernel<float,3,PRO_GN_SILU,RES_NONE,32x32>",
 }
 # how the JSON line names the arithmetic: bf16x3 is the fp32-grade mode (fp32 tensors and accumulation, every conv product from
 # hi/lo-split operands on the bf16 matrix pipe, held to the exact-fp32 parity tolerance in tests/test_gpu_parity.py)
 DTYPE_LABEL = {"bf16x3": "fp32 (tensors, accumulate) with split-bf16 x3 MFMA conv products", "fp32": "fp32", "bf16": "bf16"}
-TRAFFIC_FILE = {"bf16x3": "r02_x3_pmc_dominant_kernel.json", "bf16": "r01_ws_pmc_dominant_kernel.json", "fp32": "none"}
+TRAFFIC_FILE = {"bf16x3": "r02_x3b_pmc_dominant_kernel.json", "bf16": "r01_ws_pmc_dominant_kernel.json", "fp32": "none"}
 EDM_CIFAR10 = dict(img_resolution=32, img_channels=3, label_dim=10, sigma_shift=0.0, sigma_data=0.5,
                    model_type="SongUNet", augment_dim=9, model_channels=128, channel_mult=[2, 2, 2],
                    channel_mult_noise=1, embedding_type="positional", encoder_type="standard",

@@ -48,6 +48,14 @@ bool conv_ws_enabled();
 int launch_conv_ws(int res, const ConvArgs& a, hipStream_t stream, bool prepare_only, int pro = PRO_GN_SILU);
 bool conv_ws_shape_ok(int dtype, int cout, int cin, int res);
 int launch_pack_conv_weights_ws(const float* w_oihw, void* wpack_ws, int cout, int cin, hipStream_t stream);
+// conv_ws3.hip: the wave-specialised kernel of the split-bf16 mode (dtype 2), same dispatch rule
+bool conv_x3ws_supported(int ks, int pro, int res, int outmode, const ConvArgs& a);
+bool conv_x3ws_shape_ok(int cout, int cin, int res);
+int conv_x3ws_stat_slots(int W);
+int launch_conv_x3ws(int res, const ConvArgs& a, hipStream_t stream, bool prepare_only, int pro = PRO_GN_SILU);
+int launch_pack_conv_weights_x3ws(const float* w_oihw, void* wpack_ws, int cout, int cin, hipStream_t stream);
+// statistics slots per image that launch_conv_fused will write for this call (depends on the kernel the dispatch picks)
+int conv_launch_stat_slots(int dtype, int ks, int pro, int res, int outmode, const ConvArgs& a);
 int launch_conv_ws_debug(const ConvArgs& a, int abl, hipStream_t stream);  // ablation builds of the 32x32 shape
 int launch_conv_debug(int dtype, const ConvArgs& a, hipStream_t stream);  // ablation build, honours a.dbg
 // set the dynamic-LDS attribute of every instantiation of this dtype (call once, outside stream capture)

@@ -614,6 +614,7 @@ int launch_conv_fused(int dtype, int ks, int pro, int res, int outmode, const Co
     if (pro != PRO_NONE && !a.ab) return (int)hipErrorInvalidValue;
     if (outmode == OUT_QKV && (a.Cout != 768 || a.W > 16)) return (int)hipErrorInvalidValue;
     if (conv_ws_enabled() && conv_ws_supported(dtype, ks, pro, res, outmode, a)) return launch_conv_ws(res, a, stream, false, pro);
+    if (dtype == 2 && conv_ws_enabled() && conv_x3ws_supported(ks, pro, res, outmode, a)) return launch_conv_x3ws(res, a, stream, false, pro);
     return dispatch_t(dtype, ks, pro, res, outmode, a, stream);
 }
 
@@ -624,6 +625,11 @@ bool conv_ws_enabled() {
         return !(e && e[0] == '0');
     }();
     return on;
+}
+
+int conv_launch_stat_slots(int dtype, int ks, int pro, int res, int outmode, const ConvArgs& a) {
+    if (dtype == 2 && conv_ws_enabled() && conv_x3ws_supported(ks, pro, res, outmode, a)) return conv_x3ws_stat_slots(a.W);
+    return conv_stat_slots(a.W);
 }
 
 int conv_stat_slots(int W) { return W == 32 ? Geom<3, 5>::TPI : (W == 16 ? Geom<3, 4>::TPI : Geom<3, 3>::TPI); }
@@ -646,6 +652,15 @@ int conv_prepare_all(int dtype) {
         if (!rc && a.W <= 16) rc = dispatch_t(dtype, 1, PRO_GN, RES_NONE, OUT_QKV, a, nullptr);
     }
     g_prepare_only = false;
+    if (!rc && dtype == 2) {
+        ConvArgs w{};
+        for (int res : {RES_NONE, RES_UP})
+            for (int ww : {32, 16}) {
+                w.W = w.H = ww;
+                if (!rc) rc = launch_conv_x3ws(res, w, nullptr, true, PRO_GN_SILU);
+                if (!rc && res == RES_NONE) rc = launch_conv_x3ws(res, w, nullptr, true, PRO_NONE);
+            }
+    }
     if (!rc && dtype == 1) {
         ConvArgs w{};
         for (int res : {RES_NONE, RES_UP}) {

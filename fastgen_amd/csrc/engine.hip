@@ -385,7 +385,7 @@ size_t plan_workspace(const fg_edm* h, int B, Arena& A, Workspace& w) {
     w.ab0 = A.get<float2>((size_t)B * max_c);
     w.ab1 = A.get<float2>((size_t)B * max_c);
     w.ab2 = A.get<float2>((size_t)B * max_c);
-    const size_t st_elems = (size_t)B * 8 * 64;  // [B][<= 8 slots][256/4 quads]
+    const size_t st_elems = (size_t)B * 32 * 64;  // [B][<= 32 slots][256/4 quads] (8 tiles x 4 producer waves in conv_ws3.hip)
     auto act = [&](size_t elems, size_t st_n) {
         Act a;
         a.p = A.take(elems * tsz);
@@ -479,7 +479,7 @@ int run_block(fg_edm* h, const Block& b, const Act& x1, int c1, const Act& x2, i
     if (c1 + c2 != b.cin) return fail(FG_EINVAL, "%s: got %d+%d input channels, expected %d", b.key.c_str(), c1, c2, b.cin);
     const int hw_in = b.res_in * b.res_in, hw = b.res_out * b.res_out;
     const int res_mode = b.down ? RES_DOWN : (b.up ? RES_UP : RES_NONE);
-    const int slots = conv_stat_slots(b.res_out);
+    const int slots = conv_stat_slots(b.res_out);  // of the 1x1 convs; the 3x3 convs report theirs per launch
     int rc;
     // h = conv0(silu(norm0(x))) + affine(emb)
     if ((rc = norm_coeffs(h->dtype, x1, c1, x2, c2, h->P(b.norm0_w), h->P(b.norm0_b), w.ab0, B, hw_in, s, w.mr0))) return rc;
@@ -493,11 +493,12 @@ int run_block(fg_edm* h, const Block& b, const Act& x1, int c1, const Act& x2, i
         // pooled silu(norm0(x)) written once by a small pass (4x less transform work than pooling inside the conv)
         HIP_TRY(launch_gn_silu_pool(h->dtype, x1.p, w.ab0, w.pool, B, b.res_out, b.res_out, c1, s));
         a.src1 = w.pool; a.Hs = a.Ws = b.res_out; a.ab = nullptr;
+        w.h.slots = conv_launch_stat_slots(h->cmode, 3, PRO_NONE, RES_NONE, OUT_NHWC, a);
         HIP_TRY(conv_launch(h, 3, PRO_NONE, RES_NONE, OUT_NHWC, a, s));
     } else {
+        w.h.slots = conv_launch_stat_slots(h->cmode, 3, PRO_GN_SILU, res_mode, OUT_NHWC, a);
         HIP_TRY(conv_launch(h, 3, PRO_GN_SILU, res_mode, OUT_NHWC, a, s));
     }
-    w.h.slots = slots;
     // skip path
     const void* resid = x1.p;
     if (b.has_skip) {
@@ -509,7 +510,7 @@ int run_block(fg_edm* h, const Block& b, const Act& x1, int c1, const Act& x2, i
         resid = w.sbuf;
     }
     // x = (conv1(silu(norm1(h))) + skip) * sqrt(.5)
-    HIP_TRY(launch_gn_finalize(w.h.st, b.cout, slots, nullptr, 0, 0, h->P(b.norm1_w), h->P(b.norm1_b), kBlockEps, w.ab1, B, hw, s, w.mr1));
+    HIP_TRY(launch_gn_finalize(w.h.st, b.cout, w.h.slots, nullptr, 0, 0, h->P(b.norm1_w), h->P(b.norm1_b), kBlockEps, w.ab1, B, hw, s, w.mr1));
     Act& x_mid = b.attn ? w.xattn : out;
     ConvArgs d{};
     d.src1 = w.h.p; d.C1 = b.cout; d.Hs = d.Ws = d.H = d.W = b.res_out; d.B = B;
@@ -520,13 +521,14 @@ int run_block(fg_edm* h, const Block& b, const Act& x1, int c1, const Act& x2, i
         // the backward's weight gradient contracts with the same tensor — and the conv runs without a prologue
         HIP_TRY(launch_gn_act(0, w.h.p, b.cout, nullptr, 0, w.ab1, w.a1d, B, b.res_out, 0, s, w.drop));
         d.src1 = w.a1d; d.ab = nullptr;
+        x_mid.slots = conv_launch_stat_slots(h->cmode, 3, PRO_NONE, RES_NONE, OUT_NHWC, d);
         HIP_TRY(conv_launch(h, 3, PRO_NONE, RES_NONE, OUT_NHWC, d, s));
     } else {
+        x_mid.slots = conv_launch_stat_slots(h->cmode, 3, PRO_GN_SILU, RES_NONE, OUT_NHWC, d);
         HIP_TRY(conv_launch(h, 3, PRO_GN_SILU, RES_NONE, OUT_NHWC, d, s));
     }
-    x_mid.slots = slots;
     if (b.attn) {
-        HIP_TRY(launch_gn_finalize(x_mid.st, b.cout, slots, nullptr, 0, 0, h->P(b.norm2_w), h->P(b.norm2_b), kBlockEps, w.ab2, B, hw, s, w.mr2));
+        HIP_TRY(launch_gn_finalize(x_mid.st, b.cout, x_mid.slots, nullptr, 0, 0, h->P(b.norm2_w), h->P(b.norm2_b), kBlockEps, w.ab2, B, hw, s, w.mr2));
         ConvArgs q{};
         q.src1 = x_mid.p; q.C1 = b.cout; q.Hs = q.Ws = q.H = q.W = b.res_out; q.B = B;
         q.ab = w.ab2; q.wpack = b.p_qkv; q.bias = b.qkv_bias; q.scale = 1.0f; q.Cout = 3 * b.cout;
@@ -704,10 +706,11 @@ int ensure_device_state(fg_edm* h) {
     for (Block* b : h->blocks) {
         if ((rc = dev_alloc(h, &b->p_conv0, conv_pack_elems(b->cout, b->cin, 3) * tsz))) return rc;
         if ((rc = dev_alloc(h, &b->p_conv1, conv_pack_elems(b->cout, b->cout, 3) * tsz))) return rc;
-        if (conv_ws_shape_ok(h->cmode, b->cout, b->cin, b->res_out) && !b->down &&
+        const bool x3 = h->cmode == FG_DTYPE_BF16X3;  // conv_ws3.hip packing: two bf16 planes per weight = 4 bytes, as tsz
+        if ((x3 ? conv_x3ws_shape_ok(b->cout, b->cin, b->res_out) : conv_ws_shape_ok(h->cmode, b->cout, b->cin, b->res_out)) && !b->down &&
             (rc = dev_alloc(h, &b->p_conv0_ws, conv_pack_elems(b->cout, b->cin, 3) * tsz)))
             return rc;
-        if (conv_ws_shape_ok(h->cmode, b->cout, b->cout, b->res_out) &&
+        if ((x3 ? conv_x3ws_shape_ok(b->cout, b->cout, b->res_out) : conv_ws_shape_ok(h->cmode, b->cout, b->cout, b->res_out)) &&
             (rc = dev_alloc(h, &b->p_conv1_ws, conv_pack_elems(b->cout, b->cout, 3) * tsz)))
             return rc;
         if (b->has_skip && (rc = dev_alloc(h, &b->p_skip, conv_pack_elems(b->cout, b->cin, 1) * tsz))) return rc;
@@ -824,8 +827,13 @@ int fg_edm_pack_weights(fg_edm* h, void* stream) {
     for (Block* b : h->blocks) {
         HIP_TRY(launch_pack_conv_weights(h->cmode, h->P(b->conv0_w), b->p_conv0, b->cout, b->cin, 3, 0, s));
         HIP_TRY(launch_pack_conv_weights(h->cmode, h->P(b->conv1_w), b->p_conv1, b->cout, b->cout, 3, 0, s));
-        if (b->p_conv0_ws) HIP_TRY(launch_pack_conv_weights_ws(h->P(b->conv0_w), b->p_conv0_ws, b->cout, b->cin, s));
-        if (b->p_conv1_ws) HIP_TRY(launch_pack_conv_weights_ws(h->P(b->conv1_w), b->p_conv1_ws, b->cout, b->cout, s));
+        if (h->cmode == FG_DTYPE_BF16X3) {
+            if (b->p_conv0_ws) HIP_TRY(launch_pack_conv_weights_x3ws(h->P(b->conv0_w), b->p_conv0_ws, b->cout, b->cin, s));
+            if (b->p_conv1_ws) HIP_TRY(launch_pack_conv_weights_x3ws(h->P(b->conv1_w), b->p_conv1_ws, b->cout, b->cout, s));
+        } else {
+            if (b->p_conv0_ws) HIP_TRY(launch_pack_conv_weights_ws(h->P(b->conv0_w), b->p_conv0_ws, b->cout, b->cin, s));
+            if (b->p_conv1_ws) HIP_TRY(launch_pack_conv_weights_ws(h->P(b->conv1_w), b->p_conv1_ws, b->cout, b->cout, s));
+        }
         if (b->has_skip) HIP_TRY(launch_pack_conv_weights(h->cmode, h->P(b->skip_w), b->p_skip, b->cout, b->cin, 1, 0, s));
         if (b->attn) {
             HIP_TRY(launch_pack_conv_weights(h->cmode, h->P(b->qkv_w), b->p_qkv, 3 * b->cout, b->cout, 1, 1, s));
