@@ -61,6 +61,7 @@ SIGNATURES = {
     "fg_op_x0_to_eps": (c_int, [c_void_p, c_void_p, c_double, c_int, c_void_p, c_int64, c_void_p]),
     "fg_op_conv_wgrad_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "fg_op_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, ctypes.c_size_t, c_void_p]),
+    "fg_op_conv_wgrad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, ctypes.c_size_t, c_void_p]),
     "fg_edm_bind_grad": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
     "fg_edm_block_backward_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "fg_edm_run_block_backward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

@@ -60,9 +60,19 @@ __device__ __forceinline__ void store8bf(__bf16* p, const float (&v)[8]) {
     for (int j = 0; j < 8; ++j) q[j] = (__bf16)v[j];
     *reinterpret_cast<bf16x8*>(p) = q;
 }
+// the same for fp32 activation storage (the fp32 / split-bf16 compute modes): two 16-byte accesses per octet
+__device__ __forceinline__ void load8bf(const float* p, float (&v)[8]) {
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+    v[0] = lo[0], v[1] = lo[1], v[2] = lo[2], v[3] = lo[3], v[4] = hi[0], v[5] = hi[1], v[6] = hi[2], v[7] = hi[3];
+}
+__device__ __forceinline__ void store8bf(float* p, const float (&v)[8]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
 
 // element pointer of channel octet c0 of pixel `pix` in the virtual concat [x1 | x2]
-__device__ __forceinline__ const __bf16* cat_ptr(const __bf16* x1, int C1, const __bf16* x2, int C2, size_t pix, int c0) {
+template <typename T>
+__device__ __forceinline__ const T* cat_ptr(const T* x1, int C1, const T* x2, int C2, size_t pix, int c0) {
     return (c0 < C1) ? x1 + pix * C1 + c0 : x2 + pix * C2 + (c0 - C1);
 }
 
@@ -100,7 +110,8 @@ __device__ __forceinline__ void dropout_keep8(const DropArgs& d, uint64_t e0, fl
 // Gradient tensor t lives at the conv's OUTPUT resolution; fetch what reaches input pixel p (row-major, width `res`) of image n.
 // rm 0: same resolution.  rm 1: the forward averaged 2x2 input pixels (down-sampling) -> a quarter of the coarse value.
 // rm 2: the forward repeated each input pixel 2x2 (nearest up-sampling) -> the sum of the four fine values.
-__device__ __forceinline__ void fetch_res(const __bf16* t, int Ct, int n, int p, int c0, int res, int rm, float (&v)[8]) {
+template <typename T>
+__device__ __forceinline__ void fetch_res(const T* t, int Ct, int n, int p, int c0, int res, int rm, float (&v)[8]) {
     if (rm == 0) {
         load8bf(t + ((size_t)n * res * res + p) * Ct + c0, v);
     } else if (rm == 1) {
@@ -126,9 +137,9 @@ __device__ __forceinline__ void fetch_res(const __bf16* t, int Ct, int n, int p,
 // the weight-gradient kernel contracts with -----------------------------------------------------------------------------------
 // `res` is the OUTPUT resolution; rm 1: output pixel = mean of the 2x2 activated input pixels (input resolution 2 res), rm 2:
 // output pixel (y, x) = activated input pixel (y/2, x/2) (input resolution res/2) - Conv2d.forward's resampling, :114-123.
-template <int MODE>
-__global__ __launch_bounds__(256) void gn_act_kernel(const __bf16* __restrict__ x1, int C1, const __bf16* __restrict__ x2, int C2,
-                                                     const float2* __restrict__ ab, __bf16* __restrict__ out, int64_t total_oct,
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void gn_act_kernel(const T* __restrict__ x1, int C1, const T* __restrict__ x2, int C2,
+                                                     const float2* __restrict__ ab, T* __restrict__ out, int64_t total_oct,
                                                      int res, int rm, DropArgs drop) {
     const int C = C1 + C2, OC = C >> 3, HW = res * res;
     const int ri = rm == 1 ? res * 2 : (rm == 2 ? res / 2 : res);
@@ -173,9 +184,9 @@ __global__ __launch_bounds__(256) void gn_act_kernel(const __bf16* __restrict__ 
 
 // ---- P1, P2: one workgroup per (64 channels, image); 8 octets x 32 pixel lanes ------------------------------------------------
 // x (concat) NHWC, dact [B,HW,Cd] with this tensor's channels at [0, C); MODE as above.  P[n][c] = {P1, P2}.
-template <int MODE>
-__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const __bf16* __restrict__ x1, int C1, const __bf16* __restrict__ x2,
-                                                            int C2, const __bf16* __restrict__ dact, int Cd,
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x1, int C1, const T* __restrict__ x2,
+                                                            int C2, const T* __restrict__ dact, int Cd,
                                                             const float2* __restrict__ ab, const float2* __restrict__ mr,
                                                             float2* __restrict__ P, int res, int rm, DropArgs drop) {
     const int C = C1 + C2, HW = res * res;
@@ -279,12 +290,12 @@ __global__ __launch_bounds__(256) void gn_bwd_group_param_kernel(const float2* _
 }
 
 // ---- dx = a dy - rstd (S1 + xhat S2) / m  [+ add_scale * add]; dx is [B,HW,C] over the whole concat ---------------------------
-template <int MODE>
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const __bf16* __restrict__ x1, int C1, const __bf16* __restrict__ x2,
-                                                           int C2, const __bf16* __restrict__ dact, int Cd,
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x1, int C1, const T* __restrict__ x2,
+                                                           int C2, const T* __restrict__ dact, int Cd,
                                                            const float2* __restrict__ ab, const float2* __restrict__ mr,
-                                                           const float2* __restrict__ S, const __bf16* __restrict__ add, int Ca,
-                                                           float add_scale, __bf16* __restrict__ dx, int dxs, __bf16* __restrict__ dx2,
+                                                           const float2* __restrict__ S, const T* __restrict__ add, int Ca,
+                                                           float add_scale, T* __restrict__ dx, int dxs, T* __restrict__ dx2,
                                                            int dxs2, int accumulate, int64_t total_oct, int res, int rm, DropArgs drop) {
     // destination: channels [0, C1) -> dx (pixel stride dxs), channels [C1, C) -> dx2 (pixel stride dxs2); accumulate: +=
     const int C = C1 + C2, OC = C >> 3, HW = res * res;
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const __bf16* __restr
             if (add) r = fmaf(add_scale, av[j], r);
             o[j] = r;
         }
-        __bf16* dst = (c0 < C1) ? dx + pix * dxs + c0 : dx2 + pix * dxs2 + (c0 - C1);
+        T* dst = (c0 < C1) ? dx + pix * dxs + c0 : dx2 + pix * dxs2 + (c0 - C1);
         if (accumulate) {
             float old[8];
             load8bf(dst, old);
@@ -330,7 +341,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const __bf16* __restr
 }
 
 // ---- out[n][c] (+)= scale * sum_p t[n,p,c]: bias and embedding-affine gradients -------------------------------------------
-__global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ t, int Ct, int C, float* __restrict__ out, int HW,
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ t, int Ct, int C, float* __restrict__ out, int HW,
                                                      float scale, int out_stride) {
     const int n = blockIdx.y, oct = threadIdx.x & 7, pl = threadIdx.x >> 3;
     const int c0 = blockIdx.x * 64 + oct * 8;
@@ -375,11 +387,13 @@ __global__ __launch_bounds__(256) void batchsum_add_kernel(const float* __restri
 }
 
 // fp32 -> bf16 with a scale (gradient entering the block: dOut * skip_scale)
-__global__ void scale_to_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, float scale, int64_t total) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) out[i] = (__bf16)(in[i] * scale);
+template <typename T>
+__global__ void scale_to_bf16_kernel(const float* __restrict__ in, T* __restrict__ out, float scale, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) out[i] = (T)(in[i] * scale);
 }
 // bf16 [.., Cs] channels [c_off, c_off + C) -> fp32 [.., C]
-__global__ void slice_to_f32_kernel(const __bf16* __restrict__ in, int Cs, int c_off, float* __restrict__ out, int C, int64_t npix) {
+template <typename T>
+__global__ void slice_to_f32_kernel(const T* __restrict__ in, int Cs, int c_off, float* __restrict__ out, int C, int64_t npix) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix * C; i += (int64_t)gridDim.x * 256) {
         const int64_t p = i / C;
         const int c = (int)(i - p * C);
@@ -431,23 +445,25 @@ __global__ void dgrad_weights_kernel(const float* __restrict__ w, float* __restr
 // ---- whole-network pieces ------------------------------------------------------------------------------------------------------
 // gradient entering the output head: dF = c_out[n] * dout (precond_output, EDM/network.py:798-805), NCHW fp32 -> NHWC bf16 padded
 // with zero channels to Cp (the matrix-core kernels' granularity)
-__global__ void head_grad_kernel(const float* __restrict__ dout, const float* __restrict__ c_out, __bf16* __restrict__ out, int C,
+template <typename T>
+__global__ void head_grad_kernel(const float* __restrict__ dout, const float* __restrict__ c_out, T* __restrict__ out, int C,
                                  int Cp, int HW, int64_t total) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % Cp);
         const int64_t pix = i / Cp;
         const int64_t n = pix / HW, p = pix - n * HW;
-        out[i] = c < C ? (__bf16)(c_out[n] * dout[(n * C + c) * HW + p]) : (__bf16)0.f;
+        out[i] = c < C ? (T)(c_out[n] * dout[(n * C + c) * HW + p]) : (T)0.f;
     }
 }
 // the stem conv's operand: c_in[n] * x_t (precond_input :771-773), NCHW fp32 -> NHWC bf16 padded to Cp channels
-__global__ void stem_operand_kernel(const float* __restrict__ x, const float* __restrict__ c_in, __bf16* __restrict__ out, int C,
+template <typename T>
+__global__ void stem_operand_kernel(const float* __restrict__ x, const float* __restrict__ c_in, T* __restrict__ out, int C,
                                     int Cp, int HW, int64_t total) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % Cp);
         const int64_t pix = i / Cp;
         const int64_t n = pix / HW, p = pix - n * HW;
-        out[i] = c < C ? (__bf16)(c_in[n] * x[(n * C + c) * HW + p]) : (__bf16)0.f;
+        out[i] = c < C ? (T)(c_in[n] * x[(n * C + c) * HW + p]) : (T)0.f;
     }
 }
 // dst[o][i][t] += src[o][i][t] for o < O, i < I out of a padded [Os][Is][T] tensor
@@ -463,9 +479,10 @@ __global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict
     if (idx >= Op * IT) return;
     dst[idx] = (idx / IT) < O ? src[idx] : 0.f;
 }
-__global__ void add_bf16_kernel(__bf16* __restrict__ dst, const __bf16* __restrict__ src, int64_t total) {
+template <typename T>
+__global__ void add_bf16_kernel(T* __restrict__ dst, const T* __restrict__ src, int64_t total) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
-        dst[i] = (__bf16)((float)dst[i] + (float)src[i]);
+        dst[i] = (T)((float)dst[i] + (float)src[i]);
 }
 // dpre = dy * silu'(pre)   (map_layer0 / map_layer1, EDM/network.py:520-521)
 __global__ void silu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dpre, int total) {
@@ -504,16 +521,18 @@ __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restr
 }
 
 // dst[n][p][c] (bf16 NHWC) += src[n][c][p] (fp32 NCHW): a feature tap's gradient joins the encoder output's gradient
-__global__ void add_nchw_to_nhwc_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int C, int HW, int64_t total) {
+template <typename T>
+__global__ void add_nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int C, int HW, int64_t total) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % C);
         const int64_t pix = i / C;
         const int64_t n = pix / HW, p = pix - n * HW;
-        dst[i] = (__bf16)((float)dst[i] + src[(n * C + c) * HW + p]);
+        dst[i] = (T)((float)dst[i] + src[(n * C + c) * HW + p]);
     }
 }
 // dx[n][c][p] = c_in[n] * da[n][p][c] (+ c_skip[n] * dout[n][c][p]): gradient of the network input (precond_input / precond_output)
-__global__ void input_grad_kernel(const __bf16* __restrict__ da, int Cd, const float* __restrict__ c_in, const float* __restrict__ c_skip,
+template <typename T>
+__global__ void input_grad_kernel(const T* __restrict__ da, int Cd, const float* __restrict__ c_in, const float* __restrict__ c_skip,
                                   const float* __restrict__ dout, float* __restrict__ dx, int C, int HW, int64_t total) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t p = i % HW;
@@ -528,11 +547,11 @@ __global__ void input_grad_kernel(const __bf16* __restrict__ da, int Cd, const f
 // ---- forward-mode (JVP) pieces: tangents of (x_t, t, r) pushed through the network (mean_flow.py:240-250, sCM.py:179) -------------
 // GroupNorm(+SiLU) tangent: with P = {sum_p xd, sum_p xd*xhat} per (n, c) and S their UNWEIGHTED group sums,
 //   yd = a (xd - (S1 + xhat S2) / m),  actd = silu'(a x + b) yd (MODE 0) | yd (MODE 1);   xd [B,HW,Cd] covers the concat.
-template <int MODE>
-__global__ __launch_bounds__(256) void gn_jvp_apply_kernel(const __bf16* __restrict__ x1, int C1, const __bf16* __restrict__ x2,
-                                                           int C2, const __bf16* __restrict__ xd, int Cd,
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void gn_jvp_apply_kernel(const T* __restrict__ x1, int C1, const T* __restrict__ x2,
+                                                           int C2, const T* __restrict__ xd, int Cd,
                                                            const float2* __restrict__ ab, const float2* __restrict__ mr,
-                                                           const float2* __restrict__ S, __bf16* __restrict__ out, int64_t total_oct,
+                                                           const float2* __restrict__ S, T* __restrict__ out, int64_t total_oct,
                                                            int HW, DropArgs drop) {
     const int C = C1 + C2, OC = C >> 3;
     const int groups = min(32, C / 4), cpg = C / groups;
@@ -615,7 +634,8 @@ __global__ void jvp_input_kernel(const float* __restrict__ vx, const float* __re
 }
 // jvp[n][c][p] = c_out Fd + dc_out F + c_skip vx + dc_skip x,  F = the network's raw output (kept by the forward that precedes);
 // Fd is NHWC bf16 with channel stride Cf
-__global__ void jvp_output_kernel(const __bf16* __restrict__ fd, int Cf, const float* __restrict__ F_raw, const float* __restrict__ x,
+template <typename T>
+__global__ void jvp_output_kernel(const T* __restrict__ fd, int Cf, const float* __restrict__ F_raw, const float* __restrict__ x,
                                   const float* __restrict__ vx, const float* __restrict__ ct, float* __restrict__ jvp, int B, int C, int HW,
                                   int64_t total) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -653,68 +673,79 @@ inline unsigned ew_blocks(int64_t n) {
 }  // namespace
 
 #define BWD_RET() return (int)hipGetLastError()
+// storage type of the activation tensors: dtype 1 = bf16 (bf16 compute mode), 0 = fp32 (fp32 / split-bf16 modes)
+#define ACT_T(dtype, ...)         \
+    do {                          \
+        if (dtype) {              \
+            typedef __bf16 T;     \
+            __VA_ARGS__;          \
+        } else {                  \
+            typedef float T;      \
+            __VA_ARGS__;          \
+        }                         \
+    } while (0)
 
-int launch_gn_act(int mode, const void* x1, int c1, const void* x2, int c2, const float2* ab, void* out, int B, int res, int rm,
+int launch_gn_act(int dtype, int mode, const void* x1, int c1, const void* x2, int c2, const float2* ab, void* out, int B, int res, int rm,
                   hipStream_t s, DropArgs drop) {
     if ((c1 % 8) || (c2 % 8)) return (int)hipErrorInvalidValue;
     const int hw = res * res;
     const int64_t total = (int64_t)B * hw * ((c1 + c2) / 8);
     if (mode == 0)
-        hipLaunchKernelGGL(gn_act_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, ab, (__bf16*)out, total, res, rm, drop);
+        ACT_T(dtype, hipLaunchKernelGGL((gn_act_kernel<0, T>), dim3(ew_blocks(total)), dim3(256), 0, s, (const T*)x1, c1, (const T*)x2, c2, ab, (T*)out, total, res, rm, drop));
     else if (mode == 2)
-        hipLaunchKernelGGL(gn_act_kernel<2>, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, ab, (__bf16*)out, total, res, rm, drop);
+        ACT_T(dtype, hipLaunchKernelGGL((gn_act_kernel<2, T>), dim3(ew_blocks(total)), dim3(256), 0, s, (const T*)x1, c1, (const T*)x2, c2, ab, (T*)out, total, res, rm, drop));
     else
-        hipLaunchKernelGGL(gn_act_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)x1, c1, (const __bf16*)x2, c2, ab, (__bf16*)out, total, res, rm, drop);
+        ACT_T(dtype, hipLaunchKernelGGL((gn_act_kernel<1, T>), dim3(ew_blocks(total)), dim3(256), 0, s, (const T*)x1, c1, (const T*)x2, c2, ab, (T*)out, total, res, rm, drop));
     BWD_RET();
 }
 
 // GroupNorm(+SiLU) backward.  P: [B][C] float2 scratch, S: [B][groups] float2 scratch.  dgamma / dbeta are accumulated.
-int launch_gn_bwd(int mode, const void* x1, int c1, const void* x2, int c2, const void* dact, int cd, const float2* ab,
+int launch_gn_bwd(int dtype, int mode, const void* x1, int c1, const void* x2, int c2, const void* dact, int cd, const float2* ab,
                   const float2* mr, const float* gamma, float2* P, float2* S, float* dgamma, float* dbeta, const void* add, int ca,
                   float add_scale, void* dx, int B, int res, int rm, hipStream_t s, void* dx2, int accumulate, DropArgs drop) {
     const int C = c1 + c2, hw = res * res;
     // default destination: one [B, hw, C] tensor; with dx2 the two halves of the concat go to their own (dense) tensors
-    __bf16* d1 = (__bf16*)dx;
-    __bf16* d2 = dx2 ? (__bf16*)dx2 : d1 + c1;
+    const size_t esz = dtype ? 2 : 4;
+    char* d1 = (char*)dx;
+    char* d2 = dx2 ? (char*)dx2 : d1 + (size_t)c1 * esz;
     const int s1 = dx2 ? c1 : C, s2 = dx2 ? c2 : C;
     if ((c1 % 8) || (c2 % 8) || C < 16) return (int)hipErrorInvalidValue;
     const int groups = C / 4 < 32 ? C / 4 : 32;
     if (C / groups != 4 && C / groups < 8) return (int)hipErrorInvalidValue;  // load_oct_coef: an octet spans at most two groups
     dim3 rg((C + 63) / 64, B);
-    const __bf16 *X1 = (const __bf16*)x1, *X2 = (const __bf16*)x2, *D = (const __bf16*)dact, *A = (const __bf16*)add;
     if (mode == 0)
-        hipLaunchKernelGGL(gn_bwd_reduce_kernel<0>, rg, dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, P, res, rm, drop);
+        ACT_T(dtype, hipLaunchKernelGGL((gn_bwd_reduce_kernel<0, T>), rg, dim3(256), 0, s, (const T*)x1, c1, (const T*)x2, c2, (const T*)dact, cd, ab, mr, P, res, rm, drop));
     else
-        hipLaunchKernelGGL(gn_bwd_reduce_kernel<1>, rg, dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, P, res, rm, drop);
+        ACT_T(dtype, hipLaunchKernelGGL((gn_bwd_reduce_kernel<1, T>), rg, dim3(256), 0, s, (const T*)x1, c1, (const T*)x2, c2, (const T*)dact, cd, ab, mr, P, res, rm, drop));
     if (dgamma || dbeta)
         hipLaunchKernelGGL(gn_bwd_group_param_kernel, dim3(B + (C + 63) / 64), dim3(256), 0, s, P, gamma, S, dgamma, dbeta, B, C);
     else
         hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(B), dim3(32), 0, s, P, gamma, S, C);
     const int64_t total = (int64_t)B * hw * (C / 8);
     if (mode == 0)
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, S, A, ca, add_scale, d1, s1, d2, s2, accumulate, total, res, rm, drop);
+        ACT_T(dtype, hipLaunchKernelGGL((gn_bwd_apply_kernel<0, T>), dim3(ew_blocks(total)), dim3(256), 0, s, (const T*)x1, c1, (const T*)x2, c2, (const T*)dact, cd, ab, mr, S, (const T*)add, ca, add_scale, (T*)d1, s1, (T*)d2, s2, accumulate, total, res, rm, drop));
     else
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, cd, ab, mr, S, A, ca, add_scale, d1, s1, d2, s2, accumulate, total, res, rm, drop);
+        ACT_T(dtype, hipLaunchKernelGGL((gn_bwd_apply_kernel<1, T>), dim3(ew_blocks(total)), dim3(256), 0, s, (const T*)x1, c1, (const T*)x2, c2, (const T*)dact, cd, ab, mr, S, (const T*)add, ca, add_scale, (T*)d1, s1, (T*)d2, s2, accumulate, total, res, rm, drop));
     (void)groups;
     BWD_RET();
 }
 
-int launch_colsum(const void* t, int ct, int C, float* out, int B, int hw, float scale, hipStream_t s, int out_stride) {
+int launch_colsum(int dtype, const void* t, int ct, int C, float* out, int B, int hw, float scale, hipStream_t s, int out_stride) {
     if (C % 8) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, (const __bf16*)t, ct, C, out, hw, scale,
-                       out_stride > 0 ? out_stride : C);
+    ACT_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, dim3((C + 63) / 64, B), dim3(256), 0, s, (const T*)t, ct, C, out, hw, scale,
+                                    out_stride > 0 ? out_stride : C));
     BWD_RET();
 }
 int launch_batchsum_add(const float* in, float* out, int B, int C, hipStream_t s, float* out2) {
     hipLaunchKernelGGL(batchsum_add_kernel, dim3((C + 63) / 64), dim3(256), 0, s, in, out, out2, B, C);
     BWD_RET();
 }
-int launch_scale_to_bf16(const float* in, void* out, float scale, int64_t total, hipStream_t s) {
-    hipLaunchKernelGGL(scale_to_bf16_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, in, (__bf16*)out, scale, total);
+int launch_scale_to_act(int dtype, const float* in, void* out, float scale, int64_t total, hipStream_t s) {
+    ACT_T(dtype, hipLaunchKernelGGL(scale_to_bf16_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, s, in, (T*)out, scale, total));
     BWD_RET();
 }
-int launch_slice_to_f32(const void* in, int cs, int c_off, float* out, int C, int64_t npix, hipStream_t s) {
-    hipLaunchKernelGGL(slice_to_f32_kernel, dim3(ew_blocks(npix * C)), dim3(256), 0, s, (const __bf16*)in, cs, c_off, out, C, npix);
+int launch_slice_to_f32(int dtype, const void* in, int cs, int c_off, float* out, int C, int64_t npix, hipStream_t s) {
+    ACT_T(dtype, hipLaunchKernelGGL(slice_to_f32_kernel<T>, dim3(ew_blocks(npix * C)), dim3(256), 0, s, (const T*)in, cs, c_off, out, C, npix));
     BWD_RET();
 }
 int launch_affine_bwd(const float* dtemb, const float* emb, const float* w, float* dw, float* demb, int B, int C, int K, hipStream_t s) {
@@ -726,14 +757,14 @@ int launch_dgrad_weights(const float* w, float* wt, int cout, int cin, int cin_p
     hipLaunchKernelGGL(dgrad_weights_kernel, dim3(ew_blocks((int64_t)cin_pad * cout * taps)), dim3(256), 0, s, w, wt, cout, cin, cin_pad, taps);
     BWD_RET();
 }
-int launch_head_grad(const float* dout, const float* c_out, void* out, int B, int C, int Cp, int hw, hipStream_t s) {
+int launch_head_grad(int dtype, const float* dout, const float* c_out, void* out, int B, int C, int Cp, int hw, hipStream_t s) {
     const int64_t total = (int64_t)B * hw * Cp;
-    hipLaunchKernelGGL(head_grad_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dout, c_out, (__bf16*)out, C, Cp, hw, total);
+    ACT_T(dtype, hipLaunchKernelGGL(head_grad_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, s, dout, c_out, (T*)out, C, Cp, hw, total));
     BWD_RET();
 }
-int launch_stem_operand(const float* x, const float* c_in, void* out, int B, int C, int Cp, int hw, hipStream_t s) {
+int launch_stem_operand(int dtype, const float* x, const float* c_in, void* out, int B, int C, int Cp, int hw, hipStream_t s) {
     const int64_t total = (int64_t)B * hw * Cp;
-    hipLaunchKernelGGL(stem_operand_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, c_in, (__bf16*)out, C, Cp, hw, total);
+    ACT_T(dtype, hipLaunchKernelGGL(stem_operand_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, s, x, c_in, (T*)out, C, Cp, hw, total));
     BWD_RET();
 }
 int launch_add_sub_tensor(const float* src, int Is, float* dst, int O, int I, int T, hipStream_t s) {
@@ -744,8 +775,8 @@ int launch_pad_rows(const float* src, float* dst, int O, int Op, int IT, hipStre
     hipLaunchKernelGGL(pad_rows_kernel, dim3((Op * IT + 255) / 256), dim3(256), 0, s, src, dst, O, Op, IT);
     BWD_RET();
 }
-int launch_add_bf16(void* dst, const void* src, int64_t total, hipStream_t s) {
-    hipLaunchKernelGGL(add_bf16_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, (__bf16*)dst, (const __bf16*)src, total);
+int launch_add_act(int dtype, void* dst, const void* src, int64_t total, hipStream_t s) {
+    ACT_T(dtype, hipLaunchKernelGGL(add_bf16_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, s, (T*)dst, (const T*)src, total));
     BWD_RET();
 }
 int launch_silu_bwd(const float* dy, const float* pre, float* dpre, int total, hipStream_t s) {
@@ -765,19 +796,19 @@ int launch_transpose_f32(const float* in, float* out, int R, int Cc, hipStream_t
     hipLaunchKernelGGL(transpose_f32_kernel, dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, s, in, out, R, Cc);
     BWD_RET();
 }
-int launch_add_nchw_to_nhwc(const float* src, void* dst, int B, int C, int hw, hipStream_t s) {
+int launch_add_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int hw, hipStream_t s) {
     const int64_t total = (int64_t)B * C * hw;
-    hipLaunchKernelGGL(add_nchw_to_nhwc_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, src, (__bf16*)dst, C, hw, total);
+    ACT_T(dtype, hipLaunchKernelGGL(add_nchw_to_nhwc_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, s, src, (T*)dst, C, hw, total));
     BWD_RET();
 }
-int launch_input_grad(const void* da, int cd, const float* c_in, const float* c_skip, const float* dout, float* dx, int B, int C, int hw,
+int launch_input_grad(int dtype, const void* da, int cd, const float* c_in, const float* c_skip, const float* dout, float* dx, int B, int C, int hw,
                       hipStream_t s) {
     const int64_t total = (int64_t)B * C * hw;
-    hipLaunchKernelGGL(input_grad_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)da, cd, c_in, c_skip, dout, dx, C, hw, total);
+    ACT_T(dtype, hipLaunchKernelGGL(input_grad_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, s, (const T*)da, cd, c_in, c_skip, dout, dx, C, hw, total));
     BWD_RET();
 }
 // GroupNorm(+SiLU) tangent of xd (dense [B, hw, C] over the concat) -> out [B, hw, C]; P / S scratch as in launch_gn_bwd
-int launch_gn_jvp(int mode, const void* x1, int c1, const void* x2, int c2, const void* xd, const float2* ab, const float2* mr,
+int launch_gn_jvp(int dtype, int mode, const void* x1, int c1, const void* x2, int c2, const void* xd, const float2* ab, const float2* mr,
                   float2* P, float2* S, void* out, int B, int res, hipStream_t s, DropArgs drop) {
     const int C = c1 + c2, hw = res * res;
     if ((c1 % 8) || (c2 % 8) || C < 16) return (int)hipErrorInvalidValue;
@@ -785,14 +816,13 @@ int launch_gn_jvp(int mode, const void* x1, int c1, const void* x2, int c2, cons
         const int groups = C / 4 < 32 ? C / 4 : 32;
         if (C / groups != 4 && C / groups < 8) return (int)hipErrorInvalidValue;  // load_oct_coef
     }
-    const __bf16 *X1 = (const __bf16*)x1, *X2 = (const __bf16*)x2, *D = (const __bf16*)xd;
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel<1>, dim3((C + 63) / 64, B), dim3(256), 0, s, X1, c1, X2, c2, D, C, ab, mr, P, res, 0, DropArgs{});
+    ACT_T(dtype, hipLaunchKernelGGL((gn_bwd_reduce_kernel<1, T>), dim3((C + 63) / 64, B), dim3(256), 0, s, (const T*)x1, c1, (const T*)x2, c2, (const T*)xd, C, ab, mr, P, res, 0, DropArgs{}));
     hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(B), dim3(32), 0, s, P, (const float*)nullptr, S, C);
     const int64_t total = (int64_t)B * hw * (C / 8);
     if (mode == 0)
-        hipLaunchKernelGGL(gn_jvp_apply_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, C, ab, mr, S, (__bf16*)out, total, hw, drop);
+        ACT_T(dtype, hipLaunchKernelGGL((gn_jvp_apply_kernel<0, T>), dim3(ew_blocks(total)), dim3(256), 0, s, (const T*)x1, c1, (const T*)x2, c2, (const T*)xd, C, ab, mr, S, (T*)out, total, hw, drop));
     else
-        hipLaunchKernelGGL(gn_jvp_apply_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, s, X1, c1, X2, c2, D, C, ab, mr, S, (__bf16*)out, total, hw, drop);
+        ACT_T(dtype, hipLaunchKernelGGL((gn_jvp_apply_kernel<1, T>), dim3(ew_blocks(total)), dim3(256), 0, s, (const T*)x1, c1, (const T*)x2, c2, (const T*)xd, C, ab, mr, S, (T*)out, total, hw, drop));
     BWD_RET();
 }
 int launch_jvp_coef(const double* t, const double* r, const float* vt, const float* vr, double sigma_data, double sigma_shift, int drop,
@@ -810,10 +840,10 @@ int launch_jvp_input(const float* vx, const float* x, const float* c_in, const f
     hipLaunchKernelGGL(jvp_input_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, vx, x, c_in, dc_in, out, chw, total);
     BWD_RET();
 }
-int launch_jvp_output(const void* fd, int cf, const float* out, const float* x, const float* vx, const float* ct, float* jvp, int B, int C,
+int launch_jvp_output(int dtype, const void* fd, int cf, const float* out, const float* x, const float* vx, const float* ct, float* jvp, int B, int C,
                       int hw, hipStream_t s) {
     const int64_t total = (int64_t)B * C * hw;
-    hipLaunchKernelGGL(jvp_output_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, (const __bf16*)fd, cf, out, x, vx, ct, jvp, B, C, hw, total);
+    ACT_T(dtype, hipLaunchKernelGGL(jvp_output_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, s, (const T*)fd, cf, out, x, vx, ct, jvp, B, C, hw, total));
     BWD_RET();
 }
 int launch_fill_f32(float* p, float v, int n, hipStream_t s) {

@@ -230,7 +230,7 @@ int disc_run(const float* feat, int res, const float* const* params, float* logi
         if ((rc = launch_nt_gemm(g.cols, g.wb, g.accf, g.Mp, DC, DK, 1.0f, 0, s))) return rc;
         hipLaunchKernelGGL(bias_bf16_kernel, dim3(eb((int64_t)g.M * DC)), dim3(256), 0, s, g.accf, bias, g.y, (int64_t)g.M * DC);
         if ((rc = launch_gn_coeffs(1, g.y, DC, nullptr, 0, gam, bet, DEPS, g.ab, B, g.Ro * g.Ro, s, g.mr))) return rc;
-        if ((rc = launch_gn_act(0, g.y, DC, nullptr, 0, g.ab, g.act, B, g.Ro, 0, s))) return rc;
+        if ((rc = launch_gn_act(1, 0, g.y, DC, nullptr, 0, g.ab, g.act, B, g.Ro, 0, s))) return rc;
         x = g.act;
     }
     const float *w1 = params[4 * ns], *b1 = params[4 * ns + 1];
@@ -245,10 +245,10 @@ int disc_run(const float* feat, int res, const float* const* params, float* logi
         float *gg = grads ? grads[4 * i + 2] : nullptr, *gbt = grads ? grads[4 * i + 3] : nullptr;
         // GroupNorm + SiLU: da (gradient of the activation) -> dy (gradient of the conv output); rows beyond M stay zero
         if (g.Mp != g.M) (void)hipMemsetAsync(dy, 0, (size_t)g.Mp * DC * 2, s);
-        if ((rc = launch_gn_bwd(0, g.y, DC, nullptr, 0, da, DC, g.ab, g.mr, params[4 * i + 2], P, S, gg, gbt, nullptr, 0, 0.f, dy, B, g.Ro, 0, s)))
+        if ((rc = launch_gn_bwd(1, 0, g.y, DC, nullptr, 0, da, DC, g.ab, g.mr, params[4 * i + 2], P, S, gg, gbt, nullptr, 0, 0.f, dy, B, g.Ro, 0, s)))
             return rc;
         if (gb) {
-            if ((rc = launch_colsum(dy, DC, DC, vec, B, g.Ro * g.Ro, 1.0f, s))) return rc;
+            if ((rc = launch_colsum(1, dy, DC, DC, vec, B, g.Ro * g.Ro, 1.0f, s))) return rc;
             if ((rc = launch_batchsum_add(vec, gb, B, DC, s))) return rc;
         }
         if (gW) {  // dWp[n][k] = sum_m dy[m][n] cols[m][k]

@@ -519,7 +519,7 @@ int run_block(fg_edm* h, const Block& b, const Act& x1, int c1, const Act& x2, i
     if (w.a1d) {
         // kept (training) forward: the operand silu(norm1(h)) [* keep with dropout, EDM/network.py:283-284] is materialised once —
         // the backward's weight gradient contracts with the same tensor — and the conv runs without a prologue
-        HIP_TRY(launch_gn_act(0, w.h.p, b.cout, nullptr, 0, w.ab1, w.a1d, B, b.res_out, 0, s, w.drop));
+        HIP_TRY(launch_gn_act(h->dtype, 0, w.h.p, b.cout, nullptr, 0, w.ab1, w.a1d, B, b.res_out, 0, s, w.drop));
         d.src1 = w.a1d; d.ab = nullptr;
         x_mid.slots = conv_launch_stat_slots(h->cmode, 3, PRO_NONE, RES_NONE, OUT_NHWC, d);
         HIP_TRY(conv_launch(h, 3, PRO_NONE, RES_NONE, OUT_NHWC, d, s));
@@ -1212,7 +1212,18 @@ int fg_op_conv_wgrad(const void* act, const void* dy, float* dw, int batch, int 
     if (workspace_bytes < conv_wgrad_workspace_bytes(batch, res, cin, cout, ks))
         return fail(FG_EINVAL, "fg_op_conv_wgrad: workspace too small (%zu < %zu bytes)", workspace_bytes,
                     conv_wgrad_workspace_bytes(batch, res, cin, cout, ks));
-    HIP_TRY(launch_conv_wgrad(act, dy, dw, batch, res, cin, cout, ks, accumulate, workspace, (hipStream_t)stream));
+    HIP_TRY(launch_conv_wgrad(FG_DTYPE_BF16, act, dy, dw, batch, res, cin, cout, ks, accumulate, workspace, (hipStream_t)stream));
+    return FG_OK;
+}
+int fg_op_conv_wgrad_f32(const float* act, const float* dy, float* dw, int batch, int res, int cin, int cout, int ks,
+                         int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!conv_wgrad_supported(res, cin, cout, ks))
+        return fail(FG_EINVAL, "fg_op_conv_wgrad_f32: unsupported shape res=%d cin=%d cout=%d ks=%d", res, cin, cout, ks);
+    if (batch <= 0 || !act || !dy || !dw || !workspace) return fail(FG_EINVAL, "fg_op_conv_wgrad_f32: bad argument");
+    if (workspace_bytes < conv_wgrad_workspace_bytes(batch, res, cin, cout, ks))
+        return fail(FG_EINVAL, "fg_op_conv_wgrad_f32: workspace too small (%zu < %zu bytes)", workspace_bytes,
+                    conv_wgrad_workspace_bytes(batch, res, cin, cout, ks));
+    HIP_TRY(launch_conv_wgrad(FG_DTYPE_BF16X3, act, dy, dw, batch, res, cin, cout, ks, accumulate, workspace, (hipStream_t)stream));
     return FG_OK;
 }
 int fg_op_images_to_u8(const float* images, uint8_t* out, int64_t batch, int channels, int height, int width, void* stream) {

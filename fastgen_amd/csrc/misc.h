@@ -37,50 +37,51 @@ struct DropArgs {
     uint64_t seed = 0;
 };
 int launch_dropout_mask(float* out, int64_t total, DropArgs drop, hipStream_t s);
-// bwd.hip: elementwise / reduction pieces of the block backward pass (bf16 activations)
-int launch_gn_act(int mode, const void* x1, int c1, const void* x2, int c2, const float2* ab, void* out, int B, int res, int rm,
+// bwd.hip: elementwise / reduction pieces of the block backward pass; dtype = storage type of the activation / gradient tensors
+// (1 bf16, 0 fp32), as everywhere in this header
+int launch_gn_act(int dtype, int mode, const void* x1, int c1, const void* x2, int c2, const float2* ab, void* out, int B, int res, int rm,
                   hipStream_t s, DropArgs drop = DropArgs{});  // res = output resolution; rm 0 none, 1 down (avg 2x2), 2 up (nearest)
-int launch_gn_bwd(int mode, const void* x1, int c1, const void* x2, int c2, const void* dact, int cd, const float2* ab,
+int launch_gn_bwd(int dtype, int mode, const void* x1, int c1, const void* x2, int c2, const void* dact, int cd, const float2* ab,
                   const float2* mr, const float* gamma, float2* P, float2* S, float* dgamma, float* dbeta, const void* add, int ca,
                   float add_scale, void* dx, int B, int res, int rm, hipStream_t s, void* dx2 = nullptr, int accumulate = 0,
                   DropArgs drop = DropArgs{});
                   // res = the norm's (input) resolution; dx2: separate dense tensor for the second concat source; accumulate: +=
-int launch_colsum(const void* t, int ct, int C, float* out, int B, int hw, float scale, hipStream_t s, int out_stride = 0);
+int launch_colsum(int dtype, const void* t, int ct, int C, float* out, int B, int hw, float scale, hipStream_t s, int out_stride = 0);
 int launch_transpose_f32(const float* in, float* out, int R, int Cc, hipStream_t s);
 int launch_batchsum_add(const float* in, float* out, int B, int C, hipStream_t s, float* out2 = nullptr);
-int launch_scale_to_bf16(const float* in, void* out, float scale, int64_t total, hipStream_t s);
-int launch_slice_to_f32(const void* in, int cs, int c_off, float* out, int C, int64_t npix, hipStream_t s);
+int launch_scale_to_act(int dtype, const float* in, void* out, float scale, int64_t total, hipStream_t s);
+int launch_slice_to_f32(int dtype, const void* in, int cs, int c_off, float* out, int C, int64_t npix, hipStream_t s);
 int launch_affine_bwd(const float* dtemb, const float* emb, const float* w, float* dw, float* demb, int B, int C, int K, hipStream_t s);
 int launch_dgrad_weights(const float* w, float* wt, int cout, int cin, int cin_pad, int taps, hipStream_t s);
-int launch_head_grad(const float* dout, const float* c_out, void* out, int B, int C, int Cp, int hw, hipStream_t s);
-int launch_stem_operand(const float* x, const float* c_in, void* out, int B, int C, int Cp, int hw, hipStream_t s);
+int launch_head_grad(int dtype, const float* dout, const float* c_out, void* out, int B, int C, int Cp, int hw, hipStream_t s);
+int launch_stem_operand(int dtype, const float* x, const float* c_in, void* out, int B, int C, int Cp, int hw, hipStream_t s);
 int launch_add_sub_tensor(const float* src, int Is, float* dst, int O, int I, int T, hipStream_t s);
 int launch_pad_rows(const float* src, float* dst, int O, int Op, int IT, hipStream_t s);
-int launch_add_bf16(void* dst, const void* src, int64_t total, hipStream_t s);
+int launch_add_act(int dtype, void* dst, const void* src, int64_t total, hipStream_t s);
 int launch_silu_bwd(const float* dy, const float* pre, float* dpre, int total, hipStream_t s);
 int launch_linear_bwd(const float* dy, const float* x, const float* w, float* dw, float* db, float* dx, int B, int C, int K,
                       float scale, hipStream_t s, int dy_stride = 0);
-int launch_add_nchw_to_nhwc(const float* src, void* dst, int B, int C, int hw, hipStream_t s);
-int launch_input_grad(const void* da, int cd, const float* c_in, const float* c_skip, const float* dout, float* dx, int B, int C, int hw,
+int launch_add_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int hw, hipStream_t s);
+int launch_input_grad(int dtype, const void* da, int cd, const float* c_in, const float* c_skip, const float* dout, float* dx, int B, int C, int hw,
                       hipStream_t s);
-int launch_gn_jvp(int mode, const void* x1, int c1, const void* x2, int c2, const void* xd, const float2* ab, const float2* mr,
+int launch_gn_jvp(int dtype, int mode, const void* x1, int c1, const void* x2, int c2, const void* xd, const float2* ab, const float2* mr,
                   float2* P, float2* S, void* out, int B, int res, hipStream_t s, DropArgs drop = DropArgs{});
 int launch_jvp_coef(const double* t, const double* r, const float* vt, const float* vr, double sigma_data, double sigma_shift, int drop,
                     float* ct, int B, hipStream_t s);
 int launch_jvp_embed(const float* c_noise, const float* r_noise, const float* dc, const float* dr, const float* freqs, float* out, int B,
                      int N, int noise_ch, hipStream_t s);
 int launch_jvp_input(const float* vx, const float* x, const float* c_in, const float* dc_in, float* out, int B, int chw, hipStream_t s);
-int launch_jvp_output(const void* fd, int cf, const float* out, const float* x, const float* vx, const float* ct, float* jvp, int B, int C,
+int launch_jvp_output(int dtype, const void* fd, int cf, const float* out, const float* x, const float* vx, const float* ct, float* jvp, int B, int C,
                       int hw, hipStream_t s);
 int launch_fill_f32(float* p, float v, int n, hipStream_t s);
 int launch_fill_f2(float2* p, float a, float b, int n, hipStream_t s);
-int launch_attention_jvp(const void* q, const void* k, const void* vt, const void* qd, const void* kd, const void* vtd, void* od,
+int launch_attention_jvp(int dtype, const void* q, const void* k, const void* vt, const void* qd, const void* kd, const void* vtd, void* od,
                          void* scratch, int B, int T, int C, hipStream_t s);
 // attn_bwd.hip
-size_t attention_backward_scratch_bytes(int B, int T, int C);
-int launch_attention_backward(const void* q, const void* k, const void* vt, const void* dO, void* dq, void* dk, void* dvt,
+size_t attention_backward_scratch_bytes(int dtype, int B, int T, int C);
+int launch_attention_backward(int dtype, const void* q, const void* k, const void* vt, const void* dO, void* dq, void* dk, void* dvt,
                               void* scratch, int B, int T, int C, hipStream_t s);
-int launch_qkv_interleave(const void* dq, const void* dk, const void* dvt, void* out, int B, int T, int C, hipStream_t s);
+int launch_qkv_interleave(int dtype, const void* dq, const void* dk, const void* dvt, void* out, int B, int T, int C, hipStream_t s);
 int launch_nt_gemm(const void* A, const void* Bm, void* C, int M, int N, int K, float scale, int out_bf16, hipStream_t s);
 int launch_transpose_bf16(const void* in, void* out, int R, int Cc, hipStream_t s);
 // disc.hip: Discriminator_EDM heads (networks/discriminators.py:62-137)
@@ -91,7 +92,7 @@ int disc_run(const float* feat, int res, const float* const* params, float* logi
 // wgrad.hip: weight gradient of a 3x3 / 1x1 convolution (training step)
 int conv_wgrad_supported(int res, int cin, int cout, int ks);
 size_t conv_wgrad_workspace_bytes(int B, int res, int cin, int cout, int ks);
-int launch_conv_wgrad(const void* act, const void* dy, float* dw, int B, int res, int cin, int cout, int ks, int accumulate,
+int launch_conv_wgrad(int mode, const void* act, const void* dy, float* dw, int B, int res, int cin, int cout, int ks, int accumulate,
                       void* workspace, hipStream_t s, float scale = 1.0f);  // dw (+)= scale * sum
 int launch_images_to_u8(const float* x, uint8_t* out, int64_t B, int C, int HW, hipStream_t s);
 int launch_act_to_nchw(int dtype, const void* in, float* out, int B, int C, int HW, hipStream_t s);  // HW, C multiples of 32

@@ -18,6 +18,8 @@
 // grid = (Cin/32) x KSPLIT x (Cout/128).  Each split writes its partial sums to a workspace and a second kernel adds the
 // KSPLIT partials in a fixed order — deterministic, no atomics.  Two workgroups fit a CU, so one's loads overlap the
 // other's MFMAs; the tile loop itself is the plain load -> barrier -> MFMA -> barrier form (first correct version).
+#include <type_traits>
+
 #include "common.h"
 #include "misc.h"
 
@@ -51,11 +53,31 @@ __device__ __forceinline__ Frag8<__bf16> tr_frag(const char* p0, const char* p1)
     return f;
 }
 
-// LOGW: log2 of the image width (5, 4, 3).  KS: 3 or 1.
-template <int LOGW, int KS>
-__global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const __bf16* __restrict__ act, const __bf16* __restrict__ dy,
-                                                                   float* __restrict__ partial, int B, int Cin, int Cout,
-                                                                   int tiles_per_split) {
+// Operand pair of one MFMA side: bf16 mode = one fragment; split-bf16 mode (X3) = the hi and lo planes of the fp32 tensor.
+template <bool X3>
+struct WFrag {
+    Frag8<__bf16> hi, lo;
+};
+template <bool X3>
+__device__ __forceinline__ void wg_mma(f32x16& acc, const WFrag<X3>& a, const WFrag<X3>& b) {
+    if constexpr (X3) {
+        mma16(acc, a.lo, b.hi);
+        mma16(acc, a.hi, b.lo);
+    }
+    mma16(acc, a.hi, b.hi);
+}
+
+// LOGW: log2 of the image width (5, 4, 3).  KS: 3 or 1.  X3: act / dy are fp32 (the split-bf16 compute mode): every 8-channel
+// piece is split into hi = bf16(x), lo = bf16(x - hi) on its way into LDS (two images of each tile), and a product is
+// dy_lo*a_hi + dy_hi*a_lo + dy_hi*a_hi (common.h bf16x3).  Its LDS (2 x the bf16 tiles) is dynamic: one workgroup per CU for
+// the 3x3 kernel at width >= 16, two otherwise.
+template <int LOGW, int KS, bool X3>
+__global__ __launch_bounds__(WG_THREADS, X3 ? 1 : 2) void conv_wgrad_kernel(const void* __restrict__ act_v, const void* __restrict__ dy_v,
+                                                                            float* __restrict__ partial, int B, int Cin, int Cout,
+                                                                            int tiles_per_split) {
+    typedef typename std::conditional<X3, float, __bf16>::type ST;
+    const ST* __restrict__ act = reinterpret_cast<const ST*>(act_v);
+    const ST* __restrict__ dy = reinterpret_cast<const ST*>(dy_v);
     constexpr int W = 1 << LOGW;
     constexpr int TW = (W >= 16) ? 16 : 8;    // tile width; a k-step is 16 pixels = one tile row (two rows at 8x8)
     constexpr bool ROLL = (KS == 3 && TW == 16);  // 8-row tiles with a rolling window of halo-row fragments
@@ -69,8 +91,11 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const __bf16*
     constexpr int CI = wg_ci(KS), NCI = CI / 32;  // input channels per workgroup, 32-channel accumulator tiles per tap
     constexpr int WG_AP = CI == 32 ? 64 : 2 * CI + 64;  // A tile bytes per (halo) pixel: 4 consecutive pixels tile the 64 banks
 
-    __shared__ __attribute__((aligned(16))) char s_dy[TPX * WG_DYP];
-    __shared__ __attribute__((aligned(16))) char s_a[HALO * WG_AP];
+    constexpr int SZ_DY = TPX * WG_DYP, SZ_A = HALO * WG_AP;
+    extern __shared__ __attribute__((aligned(16))) char wg_smem[];  // [dy hi][a hi] ([dy lo][a lo])
+    char* const s_dy = wg_smem;
+    char* const s_a = wg_smem + SZ_DY;
+    constexpr int LO = SZ_DY + ((SZ_A + 255) & ~255);  // byte distance from a hi image to its lo image
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Workgroup L (dispatch order, x fastest) runs on XCD L % 8, each with its own L2.  All (ci block, co block) workgroups of one
@@ -93,6 +118,13 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const __bf16*
     const int a_pix = (TW == 16) ? 8 * (g >> 1) + q : (g >> 1) * HW_ + q;
     const char* const a_lane = s_a + a_pix * WG_AP + (16 * (g & 1) + 4 * p) * 2;
 
+    // one operand of an MFMA from its LDS image(s): the hi image at p0 / p1, the lo image LO bytes behind it
+    auto frag2 = [&](const char* p0, const char* p1) __attribute__((always_inline)) -> WFrag<X3> {
+        WFrag<X3> f;
+        f.hi = tr_frag(p0, p1);
+        if constexpr (X3) f.lo = tr_frag(p0 + LO, p1 + LO);
+        return f;
+    };
     f32x16 acc[TAPS * NCI];
 #pragma unroll
     for (int t = 0; t < TAPS * NCI; ++t)
@@ -108,16 +140,36 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const __bf16*
             const int c = tid + WG_THREADS * i;
             const int k = c >> 4, ch = c & 15;  // 16 chunks of 8 channels per pixel
             const int y = row0 + k / TW, x = col0 + k % TW;
-            const uint4 v = *reinterpret_cast<const uint4*>(dy + ((size_t)(n * W + y) * W + x) * Cout + cob + ch * 8);
-            *reinterpret_cast<uint4*>(s_dy + k * WG_DYP + ch * 16) = v;
+            const ST* src = dy + ((size_t)(n * W + y) * W + x) * Cout + cob + ch * 8;
+            if constexpr (X3) {
+                float v[8];
+                widen8(load_frag(src), v);
+                bf16x8 hi, lo;
+                split8(v, hi, lo);
+                *reinterpret_cast<bf16x8*>(s_dy + k * WG_DYP + ch * 16) = hi;
+                *reinterpret_cast<bf16x8*>(s_dy + LO + k * WG_DYP + ch * 16) = lo;
+            } else {
+                *reinterpret_cast<uint4*>(s_dy + k * WG_DYP + ch * 16) = *reinterpret_cast<const uint4*>(src);
+            }
         }
         for (int c = tid; c < HALO * (CI / 8); c += WG_THREADS) {
             const int hp = c / (CI / 8), ch = c % (CI / 8);
             const int y = row0 + hp / HW_ - PAD, x = col0 + hp % HW_ - PAD;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (y >= 0 && y < W && x >= 0 && x < W)
-                v = *reinterpret_cast<const uint4*>(act + ((size_t)(n * W + y) * W + x) * Cin + ci0 + ch * 8);
-            *reinterpret_cast<uint4*>(s_a + hp * WG_AP + ch * 16) = v;
+            const bool in = y >= 0 && y < W && x >= 0 && x < W;
+            const ST* src = act + ((size_t)(n * W + (in ? y : 0)) * W + (in ? x : 0)) * Cin + ci0 + ch * 8;
+            if constexpr (X3) {
+                float v[8];
+                widen8(load_frag(src), v);
+                bf16x8 hi, lo;
+                split8(v, hi, lo);
+                if (!in) hi = lo = bf16x8{};
+                *reinterpret_cast<bf16x8*>(s_a + hp * WG_AP + ch * 16) = hi;
+                *reinterpret_cast<bf16x8*>(s_a + LO + hp * WG_AP + ch * 16) = lo;
+            } else {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (in) v = *reinterpret_cast<const uint4*>(src);
+                *reinterpret_cast<uint4*>(s_a + hp * WG_AP + ch * 16) = v;
+            }
         }
         __syncthreads();
         // ---- k-steps x taps MFMAs ------------------------------------------------------------------------------------
@@ -126,25 +178,24 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const __bf16*
             // (s+2, ky-2).  Keep three halo rows x three shifts in registers (slot = halo row % 3); each k-step fetches only
             // the row that enters (s + 2), early enough that the six MFMAs of rows s and s + 1 cover the LDS latency:
             // 8 transposed reads per 9 MFMAs instead of 20 - the LDS read port was the bottleneck of the plain form.
-            Frag8<__bf16> F[3][3];
+            WFrag<X3> F[3][3];
             auto load_row = [&](int hr) __attribute__((always_inline)) {
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
-                    F[hr % 3][kx] = tr_frag(a_lane + (hr * HW_ + kx) * WG_AP, a_lane + (hr * HW_ + kx + 4) * WG_AP);
+                for (int kx = 0; kx < 3; ++kx) F[hr % 3][kx] = frag2(a_lane + (hr * HW_ + kx) * WG_AP, a_lane + (hr * HW_ + kx + 4) * WG_AP);
             };
             load_row(0);
             load_row(1);
 #pragma unroll
             for (int s = 0; s < TH; ++s) {
                 load_row(s + 2);
-                const Frag8<__bf16> fa = tr_frag(dy_lane + (16 * s) * WG_DYP, dy_lane + (16 * s + 4) * WG_DYP);
+                const WFrag<X3> fa = frag2(dy_lane + (16 * s) * WG_DYP, dy_lane + (16 * s + 4) * WG_DYP);
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) mma16(acc[tap], fa, F[(s + tap / 3) % 3][tap % 3]);
+                for (int tap = 0; tap < 9; ++tap) wg_mma<X3>(acc[tap], fa, F[(s + tap / 3) % 3][tap % 3]);
             }
         } else
 #pragma unroll
         for (int s = 0; s < TPX / 16; ++s) {
-            const Frag8<__bf16> fa = tr_frag(dy_lane + (16 * s) * WG_DYP, dy_lane + (16 * s + 4) * WG_DYP);
+            const WFrag<X3> fa = frag2(dy_lane + (16 * s) * WG_DYP, dy_lane + (16 * s + 4) * WG_DYP);
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
                 const int ky = tap / KS, kx = tap % KS;
@@ -152,8 +203,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const __bf16*
                 const int hp0 = (TW == 16) ? (s + ky) * HW_ + kx : (2 * s + ky) * HW_ + kx;
 #pragma unroll
                 for (int nt = 0; nt < NCI; ++nt) {
-                    const Frag8<__bf16> fb = tr_frag(a_lane + hp0 * WG_AP + nt * 64, a_lane + (hp0 + 4) * WG_AP + nt * 64);
-                    mma16(acc[tap * NCI + nt], fa, fb);
+                    const WFrag<X3> fb = frag2(a_lane + hp0 * WG_AP + nt * 64, a_lane + (hp0 + 4) * WG_AP + nt * 64);
+                    wg_mma<X3>(acc[tap * NCI + nt], fa, fb);
                 }
             }
         }
@@ -209,17 +260,48 @@ int conv_wgrad_supported(int res, int cin, int cout, int ks) {
     return (res == 8 || res == 16 || res == 32) && cin > 0 && (ks == 1 || ks == 3) && cin % wg_ci(ks) == 0 && cout > 0 && cout % WG_CO == 0;
 }
 
-int launch_conv_wgrad(const void* act, const void* dy, float* dw, int B, int res, int cin, int cout, int ks, int accumulate,
+// LDS bytes of one instantiation (mirrors the kernel's constants)
+template <int LOGW, int KS, bool X3>
+constexpr int wgrad_lds_bytes() {
+    constexpr int W = 1 << LOGW, TW = (W >= 16) ? 16 : 8;
+    constexpr bool ROLL = (KS == 3 && TW == 16);
+    constexpr int TPX = ROLL ? 128 : WG_TILE, TH = TPX / TW, PAD = KS / 2;
+    constexpr int HALO = (TW + 2 * PAD) * (TH + 2 * PAD);
+    constexpr int CI = wg_ci(KS);
+    constexpr int AP = CI == 32 ? 64 : 2 * CI + 64;
+    constexpr int SZ_DY = TPX * WG_DYP, SZ_A = HALO * AP;
+    return X3 ? 2 * (SZ_DY + ((SZ_A + 255) & ~255)) : SZ_DY + SZ_A;
+}
+template <int LOGW, int KS, bool X3>
+int wgrad_launch(dim3 grid, hipStream_t s, const void* a, const void* d, float* part, int B, int cin, int cout, int tps) {
+    auto kern = conv_wgrad_kernel<LOGW, KS, X3>;
+    constexpr int lds = wgrad_lds_bytes<LOGW, KS, X3>();
+    if (lds > 64 * 1024) {  // above the default cap: raise it once per device
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return (int)hipErrorInvalidDevice;
+        static bool done[16] = {};
+        if (!done[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return (int)e;
+            done[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(WG_THREADS), lds, s, a, d, part, B, cin, cout, tps);
+    return (int)hipGetLastError();
+}
+
+// mode: FG_DTYPE_BF16 (1): act / dy bf16; FG_DTYPE_BF16X3 (2): act / dy fp32, split-bf16 products
+int launch_conv_wgrad(int mode, const void* act, const void* dy, float* dw, int B, int res, int cin, int cout, int ks, int accumulate,
                       void* workspace, hipStream_t s, float scale) {
-    if (!conv_wgrad_supported(res, cin, cout, ks) || B <= 0) return (int)hipErrorInvalidValue;
+    if (!conv_wgrad_supported(res, cin, cout, ks) || B <= 0 || (mode != 1 && mode != 2)) return (int)hipErrorInvalidValue;
     const int splits = conv_wgrad_splits(B, res, cin, cout, ks);
     const int ntiles = B * tiles_per_image(res, ks);
     const int tps = (ntiles + splits - 1) / splits;
     dim3 grid(cin / wg_ci(ks), splits, cout / WG_CO);
-    const __bf16* a = (const __bf16*)act;
-    const __bf16* d = (const __bf16*)dy;
     float* part = (float*)workspace;
-#define WG_LAUNCH(LW, KS) hipLaunchKernelGGL((conv_wgrad_kernel<LW, KS>), grid, dim3(WG_THREADS), 0, s, a, d, part, B, cin, cout, tps)
+    int rc;
+#define WG_LAUNCH(LW, KS) \
+    rc = (mode == 2) ? wgrad_launch<LW, KS, true>(grid, s, act, dy, part, B, cin, cout, tps) : wgrad_launch<LW, KS, false>(grid, s, act, dy, part, B, cin, cout, tps)
     if (ks == 3) {
         if (res == 32) WG_LAUNCH(5, 3);
         else if (res == 16) WG_LAUNCH(4, 3);
@@ -230,8 +312,7 @@ int launch_conv_wgrad(const void* act, const void* dy, float* dw, int B, int res
         else WG_LAUNCH(3, 1);
     }
 #undef WG_LAUNCH
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
+    if (rc) return rc;
     const size_t n = (size_t)cout * cin * ks * ks;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, dw, n, splits, accumulate,
                        cout * cin, ks * ks, scale);

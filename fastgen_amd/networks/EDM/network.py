@@ -100,6 +100,7 @@ class _EDMForwardFn(torch.autograd.Function):
         dev, B = x32.device, x32.shape[0]
         L = _lib.lib()
         dt, h = net._engine(dev)
+        ctx.dt = dt  # the backward differentiates in the mode the forward ran in, whatever autocast state it is called under
         if drop is not None:  # before the workspace is sized: one more tensor per block
             _lib.check(L.fg_edm_set_dropout(h, drop[0], drop[1]))
         ws = net._train_workspace(h, B, dev)
@@ -140,9 +141,8 @@ class _EDMForwardFn(torch.autograd.Function):
         # under FSDP2 the root group was all-gathered by its pre-backward hook; the blocks' groups are gathered here and stay
         # unsharded until the root's post-backward callback reduce-scatters their gradients and reshards them
         net._unshard_all()
-        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-            dt, h = net._engine(dev)
-        assert dt == _lib.FG_DTYPE_BF16
+        with torch.no_grad():
+            dt, h = net._engine(dev, ctx.dt)
         _lib.check(L.fg_edm_set_training(h, int(ctx.training)))
         named = net._named_weights(ctx.names)
         # one zero-filled fp32 buffer, one view per trainable parameter (a fill per parameter costs 400+ launches)
@@ -338,9 +338,10 @@ class EDMPrecond(FastGenNetwork):
                 raise NotImplementedError(f"autocast dtype {ad} is not implemented (bf16 or fp32)")
         return _lib.DTYPE_NAMES[DEFAULT_FP32_MODE]
 
-    def _engine(self, device: torch.device):
-        """Engine for the active compute dtype with up-to-date weights bound and packed."""
-        dt = self._select_dtype()
+    def _engine(self, device: torch.device, dt: Optional[int] = None):
+        """Engine for the active (or the given) compute dtype with up-to-date weights bound and packed."""
+        if dt is None:
+            dt = self._select_dtype()
         if dt not in self._engines:
             self._engines[dt] = self._make_engine(dt)
         h = self._engines[dt]
@@ -395,12 +396,13 @@ class EDMPrecond(FastGenNetwork):
 
     def _check_trainable_call(self, return_logvar=False):
         """Autograd through the module (fg_edm_backward_ex): gradients of the prediction and of the feature taps with respect to
-        the parameters and to x_t, in the bf16 compute mode - what the DMD2 student / fake-score updates and its GAN branch need
-        (dmd2.py).  Everything else raises."""
-        if self._select_dtype() != _lib.FG_DTYPE_BF16:
+        the parameters and to x_t - what the DMD2 student / fake-score updates and its GAN branch need (dmd2.py) - in the
+        split-bf16 mode (fp32 tensors, the default outside autocast: the reference's `precision="float32"` training,
+        configs/config.py:167-169) and in the bf16 mode (under bf16 autocast).  The exact-fp32 mode has no backward."""
+        if self._select_dtype() == _lib.FG_DTYPE_F32:
             raise NotImplementedError(
-                "fastgen_amd.EDMPrecond: the backward pass runs in the bf16 compute mode only - call under "
-                "torch.autocast('cuda', dtype=torch.bfloat16) (or compute_dtype='bf16'), or under torch.no_grad() for inference")
+                "fastgen_amd.EDMPrecond: the backward pass runs in the 'bf16x3' (default) and 'bf16' compute modes, not in the "
+                "exact-fp32 mode (compute_dtype='fp32'); use torch.no_grad() for inference in that mode")
         # return_logvar needs no special handling: logvar_linear(posemb(c_noise)) is a [B, 128] x [128, 1] product evaluated with
         # torch on the module's own parameters (host-side plumbing) and differentiates through ordinary autograd
 
@@ -667,10 +669,9 @@ class EDMPrecond(FastGenNetwork):
         return self._fsdp_call(lambda: self._jvp_call(x_t, t, v_x, v_t, condition, r, v_r, B, dev))
 
     def _jvp_call(self, x_t, t, v_x, v_t, condition, r, v_r, B, dev):
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            dt, h = self._engine(dev)
-        if dt != _lib.FG_DTYPE_BF16:
-            raise NotImplementedError("fastgen_amd.EDMPrecond.jvp runs in the bf16 compute mode only")
+        dt, h = self._engine(dev)
+        if dt == _lib.FG_DTYPE_F32:
+            raise NotImplementedError("fastgen_amd.EDMPrecond.jvp runs in the 'bf16x3' and 'bf16' compute modes, not in exact fp32")
         f32 = lambda a: None if a is None else torch.atleast_1d(a.detach()).to(device=dev, dtype=torch.float32).expand(B).contiguous()
         f64 = lambda a: None if a is None else torch.atleast_1d(a.detach()).to(device=dev, dtype=torch.float64).expand(B).contiguous()
         x32 = x_t.detach().to(torch.float32).contiguous()

@@ -186,7 +186,13 @@ FG_API size_t fg_op_conv_wgrad_workspace_bytes(int batch, int res, int cin, int 
 FG_API int fg_op_conv_wgrad(const void* act, const void* dy, float* dw, int batch, int res, int cin, int cout, int ks,
                      int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Backward of one UNetBlock (EDM/network.py:274-299) as autograd computes it (bf16 compute mode; every block variant: attention,
+/* The same weight gradient in the split-bf16 compute mode (FG_DTYPE_BF16X3): act and dy are NHWC fp32, each split into hi / lo
+ * bf16 planes on the way into LDS, dy_lo*a_hi + dy_hi*a_lo + dy_hi*a_hi with fp32 accumulation.  Same shapes, workspace size
+ * (fg_op_conv_wgrad_workspace_bytes) and determinism. */
+FG_API int fg_op_conv_wgrad_f32(const float* act, const float* dy, float* dw, int batch, int res, int cin, int cout, int ks,
+                                int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of one UNetBlock (EDM/network.py:274-299) as autograd computes it (bf16 or bf16x3 compute mode; every block variant: attention,
  * 2x down / up resampling, channel-concat input).  Same tensor conventions as fg_edm_run_block (NHWC fp32 x1 / x2 / dout / dx1 / dx2,
  * emb and demb [B, emb_channels]).  The block's forward is recomputed first.  Parameter gradients are ACCUMULATED into the fp32
  * buffers bound with fg_edm_bind_grad (same names and shapes as the parameters; unbound = not computed); demb is accumulated as
@@ -197,7 +203,7 @@ FG_API int fg_edm_run_block_backward(fg_edm* h, int index, const float* x1, int 
                               const float* dout, float* dx1, float* dx2, float* demb, int batch, void* workspace,
                               size_t workspace_bytes, void* stream);
 
-/* Whole-network backward (bf16 compute mode) of EDMPrecond.forward, what autograd computes for the student / fake-score network in
+/* Whole-network backward (bf16 or bf16x3 compute mode; the exact-fp32 mode has none) of EDMPrecond.forward, what autograd computes for the student / fake-score network in
  * fastgen/methods/distribution_matching/dmd2.py.  have_forward == 0: runs the kept forward itself first (-> out, as
  * fg_edm_forward_train); have_forward != 0: a fg_edm_forward_train of the same batch / workspace / inputs precedes this call and its
  * per-block stash is differentiated as it stands - nothing but the cheap conv operands silu(norm(x)) is recomputed.  dout [B,C,H,W]
@@ -232,7 +238,7 @@ FG_API int fg_disc_edm_run(const float* feat, int res, const float* const* param
 
 /* Forward-mode derivative (`torch.func.jvp(net, (x_t, t, r), tangents)` in MeanFlowModel._jvp / sCM,
  * consistency_model/mean_flow.py:240-250, sCM.py:179): out = EDMPrecond.forward(x_t, t, r), jvp = its directional derivative along
- * (vx [B,C,H,W], vt [B], vr [B]) (vt / vr nullable = 0; fp32).  bf16 compute mode; workspace sized by
+ * (vx [B,C,H,W], vt [B], vr [B]) (vt / vr nullable = 0; fp32).  bf16 or bf16x3 compute mode; workspace sized by
  * fg_edm_backward_workspace_bytes (the pass runs next to the kept forward and reuses its per-block stash). */
 FG_API int fg_edm_jvp(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* vx, const float* vt,
                const float* vr, float* out, float* jvp, int batch, void* workspace, size_t workspace_bytes, void* stream);

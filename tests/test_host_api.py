@@ -130,8 +130,14 @@ def test_constructor_errors():
 
 def test_product_path_fails_loudly_without_gpu(net):
     x, t = torch.zeros(2, 3, 32, 32), torch.ones(2, dtype=torch.float64)
-    with pytest.raises(NotImplementedError):  # autograd requested
+    with pytest.raises(RuntimeError, match="HIP GPU only"):  # autograd requested: the training path has no CPU fallback either
         net(x, t)
+    prev, net.compute_dtype = net.compute_dtype, "fp32"
+    try:
+        with pytest.raises(NotImplementedError):  # the exact-fp32 mode has no backward pass
+            net(x, t)
+    finally:
+        net.compute_dtype = prev
     with torch.no_grad():
         with pytest.raises(RuntimeError, match="HIP GPU only"):
             net(x, t)
