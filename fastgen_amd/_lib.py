@@ -14,6 +14,7 @@ FG_SAMPLE_SDE, FG_SAMPLE_ODE = 0, 1
 FG_LOOP_X0, FG_LOOP_MEANFLOW = 0, 1
 FG_SCHEDULE_EDM, FG_SCHEDULE_RF = 0, 1
 FG_DROP_PRECOND_INPUT, FG_DROP_PRECOND_OUTPUT = 1, 2
+FG_BWD_DECODER, FG_BWD_ENCODER, FG_BWD_EMBED = 1, 2, 4
 
 
 class fg_edm_config(ctypes.Structure):
@@ -73,6 +74,8 @@ SIGNATURES = {
                                      c_size_t, c_void_p]),
     "fg_edm_backward_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                    c_int, c_void_p, c_size_t, c_void_p]),
+    "fg_edm_backward_part": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "fg_disc_edm_num_params": (c_int, [c_int]),
     "fg_disc_edm_workspace_bytes": (c_size_t, [c_int, c_int]),
     "fg_disc_edm_run": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),

@@ -370,13 +370,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ t, in
 // out[c] += sum_n in[n][c]
 // (two destinations: a block's conv1 and skip biases receive the same sum)
 __global__ __launch_bounds__(256) void batchsum_add_kernel(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ out2,
-                                                           int B, int C) {
+                                                           int B, int C, int in_stride) {
     __shared__ float sa[4][64];
     const int cl = threadIdx.x & 63, nl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     float a = 0.f;
     if (c < C)
 #pragma unroll 8
-        for (int n = nl; n < B; n += 4) a += in[(size_t)n * C + c];
+        for (int n = nl; n < B; n += 4) a += in[(size_t)n * in_stride + c];
     sa[nl][cl] = a;
     __syncthreads();
     if (nl == 0 && c < C) {
@@ -736,8 +736,8 @@ int launch_colsum(int dtype, const void* t, int ct, int C, float* out, int B, in
                                     out_stride > 0 ? out_stride : C));
     BWD_RET();
 }
-int launch_batchsum_add(const float* in, float* out, int B, int C, hipStream_t s, float* out2) {
-    hipLaunchKernelGGL(batchsum_add_kernel, dim3((C + 63) / 64), dim3(256), 0, s, in, out, out2, B, C);
+int launch_batchsum_add(const float* in, float* out, int B, int C, hipStream_t s, float* out2, int in_stride) {
+    hipLaunchKernelGGL(batchsum_add_kernel, dim3((C + 63) / 64), dim3(256), 0, s, in, out, out2, B, C, in_stride > 0 ? in_stride : C);
     BWD_RET();
 }
 int launch_scale_to_act(int dtype, const float* in, void* out, float scale, int64_t total, hipStream_t s) {
@@ -788,7 +788,7 @@ int launch_linear_bwd(const float* dy, const float* x, const float* w, float* dw
                       float scale, hipStream_t s, int dy_stride) {
     if ((db || dx) && dy_stride > 0 && dy_stride != C) return (int)hipErrorInvalidValue;  // only the weight part takes a stride
     if (dw) hipLaunchKernelGGL(linear_wgrad_kernel, dim3((C * K + 255) / 256), dim3(256), 0, s, dy, x, dw, B, C, K, scale, dy_stride > 0 ? dy_stride : C);
-    if (db) hipLaunchKernelGGL(batchsum_add_kernel, dim3((C + 63) / 64), dim3(256), 0, s, dy, db, (float*)nullptr, B, C);
+    if (db) hipLaunchKernelGGL(batchsum_add_kernel, dim3((C + 63) / 64), dim3(256), 0, s, dy, db, (float*)nullptr, B, C, C);
     if (dx) hipLaunchKernelGGL(affine_dgrad_kernel, dim3((B * K + 255) / 256), dim3(256), 0, s, dy, w, dx, B, C, K);
     BWD_RET();
 }

@@ -48,7 +48,7 @@ int launch_gn_bwd(int dtype, int mode, const void* x1, int c1, const void* x2, i
                   // res = the norm's (input) resolution; dx2: separate dense tensor for the second concat source; accumulate: +=
 int launch_colsum(int dtype, const void* t, int ct, int C, float* out, int B, int hw, float scale, hipStream_t s, int out_stride = 0);
 int launch_transpose_f32(const float* in, float* out, int R, int Cc, hipStream_t s);
-int launch_batchsum_add(const float* in, float* out, int B, int C, hipStream_t s, float* out2 = nullptr);
+int launch_batchsum_add(const float* in, float* out, int B, int C, hipStream_t s, float* out2 = nullptr, int in_stride = 0);  // in row stride (0 = C)
 int launch_scale_to_act(int dtype, const float* in, void* out, float scale, int64_t total, hipStream_t s);
 int launch_slice_to_f32(int dtype, const void* in, int cs, int c_off, float* out, int C, int64_t npix, hipStream_t s);
 int launch_affine_bwd(const float* dtemb, const float* emb, const float* w, float* dw, float* demb, int B, int C, int K, hipStream_t s);

@@ -83,24 +83,103 @@ def _init_value(name: str, shape) -> torch.Tensor:
     return w
 
 
+class _TrainCall:
+    """State of ONE differentiable forward call, shared by its three autograd nodes (see `_EDMForwardFn`)."""
+
+    def __init__(self, net, taps, aug, drop, early, names):
+        self.net, self.taps, self.aug, self.drop, self.early = net, taps, aug, drop, early
+        self.training = net.training  # the backward differentiates the forward that ran, whatever mode the module is in by then
+        # parameters by the part of the backward pass that finishes their gradients (fg_edm_backward_part)
+        self.names = {
+            _lib.FG_BWD_DECODER: tuple(n for n in names if n.startswith("model.dec.")),
+            _lib.FG_BWD_ENCODER: tuple(n for n in names if n.startswith("model.enc.")),
+            _lib.FG_BWD_EMBED: tuple(n for n in names if not n.startswith(("model.dec.", "model.enc."))),
+        }
+        self.dt = self.token = self.ws_ptr = self.ws_ptr_bwd = self.ntap = None
+        self.saved = None          # (x32, t64, r64 | None, labels | None)
+        self.want_dx = False
+        # set by the first backward stage, read by the later ones
+        self.d32 = self.dptrs = self.dx = self.scratch_out = None
+        self.keep = []
+        self.any_feat = False
+        self.have_forward = 0
+
+    def run_part(self, part: int, needs):
+        """One third of the backward pass; returns the gradients of this part's parameters (None where not needed)."""
+        net = self.net
+        x32, t64, r64, labels = self.saved
+        dev, B = x32.device, x32.shape[0]
+        L = _lib.lib()
+        with torch.no_grad():
+            dt, h = net._engine(dev, self.dt)
+        _lib.check(L.fg_edm_set_training(h, int(self.training)))
+        named = net._named_weights(self.names[part])
+        need_w = [p.requires_grad and nd for (_, p), nd in zip(named, needs)]
+        # one zero-filled fp32 buffer, one view per trainable parameter (a fill per parameter costs 400+ launches)
+        flat = torch.zeros(sum(p.numel() for (_, p), nw in zip(named, need_w) if nw), dtype=torch.float32, device=dev)
+        grads, off = [], 0
+        for (_, p), nw in zip(named, need_w):
+            if nw:
+                grads.append(flat[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+            else:
+                grads.append(None)
+        ws = net._train_workspace(h, B, dev)
+        if part == _lib.FG_BWD_DECODER:
+            self.have_forward = int(getattr(net, "_train_token", None) is self.token and ws.data_ptr() == self.ws_ptr)
+        elif ws.data_ptr() != self.ws_ptr_bwd:
+            raise RuntimeError("the training workspace was replaced between two parts of one backward pass")
+        self.ws_ptr_bwd = ws.data_ptr()
+        if self.drop is not None:
+            _lib.check(L.fg_edm_set_dropout(h, self.drop[0], self.drop[1]))
+        p_ = lambda a: ctypes.c_void_p(a.data_ptr() if a is not None else None)  # noqa: E731
+        try:
+            for (n, _), g in zip(named, grads):
+                if g is not None:
+                    _lib.check(L.fg_edm_bind_grad(h, n.encode(), ctypes.c_void_p(g.data_ptr()), g.numel()))
+            if self.aug is not None:
+                _lib.check(L.fg_edm_set_augment(h, ctypes.c_void_p(self.aug.data_ptr())))
+            _lib.check(L.fg_edm_backward_part(
+                h, p_(x32), p_(t64), p_(r64), p_(labels), p_(self.d32), self.dptrs if (self.any_feat or self.early) else None,
+                p_(self.scratch_out), p_(self.dx), self.have_forward, part, B, ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                net._stream(dev)))
+        finally:
+            if self.drop is not None:
+                _lib.check(L.fg_edm_set_dropout(h, 0.0, 0))
+            if self.aug is not None:
+                _lib.check(L.fg_edm_set_augment(h, None))
+            for (n, _), g in zip(named, grads):
+                if g is not None:
+                    _lib.check(L.fg_edm_bind_grad(h, n.encode(), None, 0))
+        return [g.to(p.dtype) if g is not None else None for (_, p), g in zip(named, grads)]
+
+
 class _EDMForwardFn(torch.autograd.Function):
-    """EDMPrecond.forward under autograd.  forward = fg_edm_forward_train (which leaves every block's inputs and intermediates
-    in the module's training workspace), backward = fg_edm_backward_ex.  Differentiable outputs: the prediction (unless the
-    feature taps are returned early) and the requested feature taps; differentiable inputs: the parameters (passed as inputs so
-    that autograd accumulates into their .grad and DDP hooks fire, as for the reference module) and x_t."""
+    """EDMPrecond.forward under autograd, as a chain of THREE nodes so that a data-parallel wrapper can overlap its gradient
+    reduction with the rest of the backward pass (torch DDP reduces a bucket as soon as the hooks of all its parameters have
+    fired, fastgen/utils/distributed/ddp.py:44-72; with one node all 418 hooks would fire together at the end):
+
+        _EDMForwardFn (x_t, embedding-MLP parameters)  -> raw outputs, token      forward: fg_edm_forward_train (everything)
+        _EDMEncoderFn (token, encoder parameters)      -> token                   forward: nothing
+        _EDMDecoderFn (token, raw outputs, decoder parameters) -> outputs         forward: nothing
+
+    Autograd runs them in reverse: _EDMDecoderFn.backward receives the output gradients and runs FG_BWD_DECODER (head + decoder:
+    its parameters' hooks fire, their buckets start reducing), _EDMEncoderFn.backward runs FG_BWD_ENCODER, this node's backward
+    FG_BWD_EMBED and hands back dL/dx_t.  The tokens carry no data (the state between the parts lives in the engine's workspace).
+    Differentiable outputs: the prediction (unless the feature taps are returned early) and the requested taps; differentiable
+    inputs: the parameters the call reads (so autograd accumulates into their .grad, as for the reference module) and x_t."""
 
     @staticmethod
-    def forward(ctx, net, x32, t64, r64, labels, taps_aug, early, *weights):
-        taps, aug, drop, ctx.names = taps_aug
-        ctx.aug, ctx.drop = aug, drop
-        ctx.training = net.training  # the backward differentiates the forward that ran, whatever mode the module is in by then
+    def forward(ctx, call, x32, t64, r64, labels, *weights):
+        ctx.call = call
         # outputs nothing depends on (DMD2 detaches the teacher's prediction and keeps its taps) arrive in backward as None, not as
         # zero tensors: the backward then leaves the decoder alone
         ctx.set_materialize_grads(False)
+        net, taps, drop, early = call.net, call.taps, call.drop, call.early
         dev, B = x32.device, x32.shape[0]
         L = _lib.lib()
         dt, h = net._engine(dev)
-        ctx.dt = dt  # the backward differentiates in the mode the forward ran in, whatever autocast state it is called under
+        call.dt = dt  # the backward differentiates in the mode the forward ran in, whatever autocast state it is called under
         if drop is not None:  # before the workspace is sized: one more tensor per block
             _lib.check(L.fg_edm_set_dropout(h, drop[0], drop[1]))
         ws = net._train_workspace(h, B, dev)
@@ -114,7 +193,7 @@ class _EDMForwardFn(torch.autograd.Function):
             f = torch.empty(B, ch.value, res.value, res.value, dtype=torch.float32, device=dev)
             ptrs[i] = f.data_ptr()
             feats.append(f)
-        with net._AugmentScope(h, aug):
+        with net._AugmentScope(h, call.aug):
             _lib.check(L.fg_edm_forward_train(
                 h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
                 ctypes.c_void_p(r64.data_ptr() if r64 is not None else None),
@@ -125,83 +204,70 @@ class _EDMForwardFn(torch.autograd.Function):
             _lib.check(L.fg_edm_set_dropout(h, 0.0, 0))
         # the training workspace now holds this call's state; any later training forward of the module replaces the token, and
         # the backward of this call then recomputes its forward
-        ctx.token = net._train_token = object()
-        ctx.ws_ptr = ws.data_ptr()
-        ctx.net, ctx.taps, ctx.early, ctx.ntap = net, taps, early, ntap
-        ctx.save_for_backward(x32, t64, r64 if r64 is not None else torch.empty(0), labels if labels is not None else torch.empty(0))
-        ctx.has_r, ctx.has_labels = r64 is not None, labels is not None
-        return tuple(([] if early else [out]) + feats)
+        call.token = net._train_token = object()
+        call.ws_ptr, call.ntap = ws.data_ptr(), ntap
+        call.saved = (x32, t64, r64, labels)  # plain inputs (no graph): held by the call object
+        call.want_dx = bool(x32.requires_grad)
+        token = torch.zeros(1, dtype=torch.float32, device=dev)
+        return tuple(([] if early else [out]) + feats + [token])
 
     @staticmethod
     def backward(ctx, *douts):
-        net = ctx.net
-        x32, t64, r64, labels = ctx.saved_tensors
-        dev, B = x32.device, x32.shape[0]
-        L = _lib.lib()
+        call = ctx.call
+        grads = call.run_part(_lib.FG_BWD_EMBED, ctx.needs_input_grad[5:])
+        return (None, call.dx if ctx.needs_input_grad[1] else None, None, None, None, *grads)
+
+
+class _EDMEncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, call, token, *weights):
+        ctx.call = call
+        ctx.set_materialize_grads(False)
+        return token.view_as(token)
+
+    @staticmethod
+    def backward(ctx, dtoken):
+        grads = ctx.call.run_part(_lib.FG_BWD_ENCODER, ctx.needs_input_grad[2:])
+        return (None, dtoken, *grads)
+
+
+class _EDMDecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, call, nraw, token, *rest):
+        ctx.call, ctx.nraw = call, nraw
+        ctx.set_materialize_grads(False)
+        return tuple(r.view_as(r) for r in rest[:nraw])
+
+    @staticmethod
+    def backward(ctx, *douts):
+        call = ctx.call
+        net = call.net
+        x32 = call.saved[0]
         # under FSDP2 the root group was all-gathered by its pre-backward hook; the blocks' groups are gathered here and stay
         # unsharded until the root's post-backward callback reduce-scatters their gradients and reshards them
         net._unshard_all()
-        with torch.no_grad():
-            dt, h = net._engine(dev, ctx.dt)
-        _lib.check(L.fg_edm_set_training(h, int(ctx.training)))
-        named = net._named_weights(ctx.names)
-        # one zero-filled fp32 buffer, one view per trainable parameter (a fill per parameter costs 400+ launches)
-        need_w = [p.requires_grad and ctx.needs_input_grad[7 + i] for i, (_, p) in enumerate(named)]
-        flat = torch.zeros(sum(p.numel() for (_, p), nw in zip(named, need_w) if nw), dtype=torch.float32, device=dev)
-        grads, off = [], 0
-        for (_, p), nw in zip(named, need_w):
-            if nw:
-                grads.append(flat[off:off + p.numel()].view(p.shape))
-                off += p.numel()
-            else:
-                grads.append(None)
-        if ctx.drop is not None:
-            _lib.check(L.fg_edm_set_dropout(h, ctx.drop[0], ctx.drop[1]))
-        ws = net._train_workspace(h, B, dev)
-        have_forward = int(getattr(net, "_train_token", None) is ctx.token and ws.data_ptr() == ctx.ws_ptr)
         douts = list(douts)
-        d_out = None if ctx.early else douts.pop(0)
-        keep = []  # contiguous fp32 copies must outlive the call
-        d32 = None
+        d_out = None if call.early else douts.pop(0)
+        call.keep = []  # contiguous fp32 copies must outlive the three engine calls
+        call.d32 = None
         if d_out is not None:
-            d32 = d_out.detach().to(torch.float32).contiguous()
-        dptrs = (ctypes.c_void_p * max(ctx.ntap, 1))()
-        any_feat = False
-        for i, g in zip(ctx.taps, douts):
+            call.d32 = d_out.detach().to(torch.float32).contiguous()
+        call.dptrs = (ctypes.c_void_p * max(call.ntap, 1))()
+        call.any_feat = False
+        for i, g in zip(call.taps, douts):
             if g is not None:
                 g32 = g.detach().to(torch.float32).contiguous()
-                keep.append(g32)
-                dptrs[i] = g32.data_ptr()
-                any_feat = True
-        if d32 is None and not ctx.early and not any_feat:
-            d32 = torch.zeros_like(x32)  # nothing carries gradient (autograd does not normally call us then)
-        # d32 None here: only the feature taps carry gradient (DMD2's GAN branch detaches the teacher's output, dmd2.py:137-146) —
+                call.keep.append(g32)
+                call.dptrs[i] = g32.data_ptr()
+                call.any_feat = True
+        if call.d32 is None and not call.early and not call.any_feat:
+            call.d32 = torch.zeros_like(x32)  # nothing carries gradient (autograd does not normally call us then)
+        # d32 None here: only the feature taps carry gradient (DMD2's GAN branch detaches the teacher's output, dmd2.py:137-146) -
         # the engine then differentiates the encoder alone, as after an early return
-        dx = torch.empty_like(x32) if ctx.needs_input_grad[1] else None
-        scratch_out = None if d32 is None else torch.empty_like(x32)
-        try:
-            for (n, _), g in zip(named, grads):
-                if g is not None:
-                    _lib.check(L.fg_edm_bind_grad(h, n.encode(), ctypes.c_void_p(g.data_ptr()), g.numel()))
-            if ctx.aug is not None:
-                _lib.check(L.fg_edm_set_augment(h, ctypes.c_void_p(ctx.aug.data_ptr())))
-            _lib.check(L.fg_edm_backward_ex(
-                h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t64.data_ptr()),
-                ctypes.c_void_p(r64.data_ptr() if ctx.has_r else None), ctypes.c_void_p(labels.data_ptr() if ctx.has_labels else None),
-                ctypes.c_void_p(d32.data_ptr() if d32 is not None else None), dptrs if (any_feat or ctx.early) else None,
-                ctypes.c_void_p(scratch_out.data_ptr() if scratch_out is not None else None),
-                ctypes.c_void_p(dx.data_ptr() if dx is not None else None), have_forward, B,
-                ctypes.c_void_p(ws.data_ptr()), ws.numel(), net._stream(dev)))
-        finally:
-            if ctx.drop is not None:
-                _lib.check(L.fg_edm_set_dropout(h, 0.0, 0))
-            if ctx.aug is not None:
-                _lib.check(L.fg_edm_set_augment(h, None))
-            for (n, _), g in zip(named, grads):
-                if g is not None:
-                    _lib.check(L.fg_edm_bind_grad(h, n.encode(), None, 0))
-        grads = [g.to(p.dtype) if g is not None else None for (_, p), g in zip(named, grads)]
-        return (None, dx, None, None, None, None, None, *grads)
+        call.dx = torch.empty_like(x32) if call.want_dx else None
+        call.scratch_out = None if call.d32 is None else torch.empty_like(x32)
+        grads = call.run_part(_lib.FG_BWD_DECODER, ctx.needs_input_grad[3 + ctx.nraw:])
+        return (None, None, torch.zeros(1, dtype=torch.float32, device=x32.device), *([None] * ctx.nraw), *grads)
 
 
 class EDMPrecond(FastGenNetwork):
@@ -599,9 +665,11 @@ class EDMPrecond(FastGenNetwork):
                 taps = tuple(i for i in range(ntap) if i in feature_indices)
                 if return_features_early:
                     assert len(taps) == len(feature_indices), f"{len(taps)} != {len(feature_indices)}"
-                names = self._diff_names(aug is not None)
-                res = _EDMForwardFn.apply(self, x32, t64, r64, labels, (taps, aug, drop, names), bool(return_features_early),
-                                          *[p_ for _, p_ in self._named_weights(names)])
+                call = _TrainCall(self, taps, aug, drop, bool(return_features_early), self._diff_names(aug is not None))
+                W = {k: [p_ for _, p_ in self._named_weights(v)] for k, v in call.names.items()}
+                raw = _EDMForwardFn.apply(call, x32, t64, r64, labels, *W[_lib.FG_BWD_EMBED])
+                token = _EDMEncoderFn.apply(call, raw[-1], *W[_lib.FG_BWD_ENCODER])
+                res = _EDMDecoderFn.apply(call, len(raw) - 1, token, *raw[:-1], *W[_lib.FG_BWD_DECODER])
                 res = list(res)
                 out = None if return_features_early else res.pop(0)
                 features = [f.to(x_t.dtype) for f in res]

@@ -226,6 +226,19 @@ FG_API int fg_edm_backward_ex(fg_edm* h, const float* x_t, const double* t, cons
                        const float* const* dfeatures, float* out, float* dx_t, int have_forward, int batch, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* fg_edm_backward_ex in up to three calls, in this order, on the same arguments and workspace (the state in between lives in the
+ * workspace; nothing else may write to it): FG_BWD_DECODER = [kept forward if have_forward == 0] + output head + decoder blocks,
+ * FG_BWD_ENCODER = feature-tap gradients + encoder blocks + stem (+ dx_t), FG_BWD_EMBED = embedding MLP.  When a call returns, every
+ * parameter gradient of its part is enqueued complete - a data-parallel wrapper can start reducing the decoder's gradients while
+ * the encoder is still being differentiated (the module's autograd nodes are split this way, fastgen/utils/distributed/ddp.py:44-72).
+ * parts is a mask: FG_BWD_DECODER | FG_BWD_ENCODER | FG_BWD_EMBED in one call is fg_edm_backward_ex. */
+#define FG_BWD_DECODER 1
+#define FG_BWD_ENCODER 2
+#define FG_BWD_EMBED 4
+FG_API int fg_edm_backward_part(fg_edm* h, const float* x_t, const double* t, const double* r, const float* labels, const float* dout,
+                                const float* const* dfeatures, float* out, float* dx_t, int have_forward, int parts, int batch,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
 /* One head of Discriminator_EDM (networks/discriminators.py:62-137) on a [B,256,res,res] NCHW fp32 feature tap, res in {8,16,32}:
  * strided 4x4 convs + GroupNorm + SiLU down to 1x1, then a 1x1 conv to one logit per image.  params: fg_disc_edm_num_params(res)
  * device pointers in the reference's module order ({conv.weight, conv.bias, gn.weight, gn.bias} per strided conv, then the 1x1

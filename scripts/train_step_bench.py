@@ -11,7 +11,9 @@ from fastgen_amd.networks.EDM.network import EDMPrecond
 KW = dict(img_resolution=32, img_channels=3, label_dim=10, model_type="SongUNet", augment_dim=9, model_channels=128,
           channel_mult=[2, 2, 2], num_blocks=4, attn_resolutions=[16], embedding_type="positional", encoder_type="standard",
           decoder_type="standard", resample_filter=[1, 1], dropout=0.0)
-net = EDMPrecond(compute_dtype="bf16", **KW).randomize_parameters_(seed=1).cuda().eval()
+MODE = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--mode=")), "bf16")  # bf16 | bf16x3 (the fp32-grade mode)
+net = EDMPrecond(compute_dtype=MODE, **KW).randomize_parameters_(seed=1).cuda().eval()
+print("compute mode:", MODE)
 ONLY = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]  # e.g. --only=backward: time (profile) that leg alone
 for B in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [64, 128]:
     x = torch.randn(B, 3, 32, 32, device="cuda") * 3

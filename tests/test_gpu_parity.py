@@ -842,6 +842,36 @@ def test_module_autograd_through_the_hip_backward(nets, golden_dir):
         net.zero_grad(set_to_none=True)
 
 
+def test_backward_releases_gradients_in_three_stages(nets, golden_dir):
+    """The module's backward is three autograd nodes (decoder + head, encoder + stem, embedding MLP: fg_edm_backward_part), so a
+    data-parallel wrapper sees the decoder's gradients while the encoder is still being differentiated (torch DDP reduces a
+    bucket once the hooks of all its parameters have fired, fastgen/utils/distributed/ddp.py:44-72).  Checked here: the order in
+    which the parameters' post-accumulate hooks fire, and that the staged pass produces the gradients of the single call."""
+    fx = load(golden_dir, "full_backward_b2.pt")
+    net = nets["bf16"]
+    t, cond = fx["t"].to(dev()), fx["cond"].to(dev())
+    x = (seeded((2, 3, 32, 32), 21) * fx["t"].reshape(2, 1, 1, 1).float()).to(dev())
+    dout = seeded((2, 3, 32, 32), 401).to(dev())
+    order, handles = [], []
+    for n, p in net.named_parameters():
+        handles.append(p.register_post_accumulate_grad_hook(lambda p_, n=n: order.append(n)))
+    try:
+        net.zero_grad(set_to_none=True)
+        (net(x, t, condition=cond, fwd_pred_type="x0") * dout).sum().backward()
+    finally:
+        for hd in handles:
+            hd.remove()
+    stage = [0 if n.startswith("model.dec.") else (1 if n.startswith("model.enc.") else 2) for n in order]
+    assert stage == sorted(stage) and set(stage) == {0, 1, 2}, "decoder, then encoder, then embedding parameters"
+    assert len(order) == 418 == len(set(order))  # every parameter the call reads (421 minus map_augment and logvar_linear), once
+    # same numbers as the one-call backward of the C ABI (fg_edm_backward = all three parts at once)
+    _, want = _net_backward(net, {k: v for k, v in net.state_dict().items()}, x.cpu(), fx["t"], fx["cond"], dout.cpu())
+    for n in ("model.dec.32x32_block2.conv1.weight", "model.enc.16x16_block1.affine.weight", "model.enc.32x32_conv.weight",
+              "model.map_layer0.weight", "model.dec.8x8_in0.qkv.bias", "model.enc.16x16_down.conv0.bias"):
+        assert torch.equal(dict(net.named_parameters())[n].grad.cpu(), want[n]), n
+    net.zero_grad(set_to_none=True)
+
+
 def test_module_autograd_at_the_reference_training_precision(sd, golden_dir):
     """What a `_target_`-swapped fp32 training config does (configs/config.py:167-169: precision float32, no AMP): the module
     as constructed by the config (no compute_dtype, no autocast) under loss.backward().  The call runs in the bf16x3 mode; every
