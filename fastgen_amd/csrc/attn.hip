@@ -34,6 +34,33 @@ struct PFrag<float> {
     }
 };
 
+// bf16x3 (common.h): q, k, v^T and the output are fp32 in memory; operands are split into hi / lo bf16 in registers on their
+// way to the matrix cores (three bf16 MFMAs per product instead of the eight exact-fp32 ones of the float instantiation)
+template <>
+struct PFrag<bf16x3> {
+    static __device__ __forceinline__ Frag8<bf16x3> make(const f32x16& p, int s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[8 * s + j];
+        Frag8<bf16x3> f;
+        split8(v, f.hi, f.lo);
+        return f;
+    }
+};
+// 8 consecutive operand elements of the storage type as a fragment of compute type T
+template <typename T>
+__device__ __forceinline__ Frag8<T> load_op(const typename DT<T>::ST* p) {
+    return load_frag(p);
+}
+template <>
+__device__ __forceinline__ Frag8<bf16x3> load_op<bf16x3>(const float* p) {
+    float v[8];
+    widen8(load_frag(p), v);
+    Frag8<bf16x3> f;
+    split8(v, f.hi, f.lo);
+    return f;
+}
+
 // V fragment for k-step s of key tile kt: element j <-> key kt*32 + 16s + 8(j>>2) + 4h + (j&3)
 __device__ __forceinline__ Frag8<__bf16> load_v(const __bf16* row, int key0) {
     Frag8<__bf16> f;
@@ -49,9 +76,23 @@ __device__ __forceinline__ Frag8<float> load_v(const float* row, int key0) {
     return f;
 }
 
-template <typename T, int NT>  // NT = T/32 key tiles
-__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q, const T* __restrict__ k,
-                                                        const T* __restrict__ vt, T* __restrict__ out, int B) {
+template <typename T>
+__device__ __forceinline__ Frag8<T> load_vop(const typename DT<T>::ST* row, int key0) {
+    return load_v(row, key0);
+}
+template <>
+__device__ __forceinline__ Frag8<bf16x3> load_vop<bf16x3>(const float* row, int key0) {
+    float v[8];
+    widen8(load_v(row, key0), v);
+    Frag8<bf16x3> f;
+    split8(v, f.hi, f.lo);
+    return f;
+}
+
+template <typename T, int NT>  // NT = T/32 key tiles; T = compute type (common.h), tensors in its storage type
+__global__ __launch_bounds__(256) void attention_kernel(const typename DT<T>::ST* __restrict__ q, const typename DT<T>::ST* __restrict__ k,
+                                                        const typename DT<T>::ST* __restrict__ vt, typename DT<T>::ST* __restrict__ out, int B) {
+    typedef typename DT<T>::ST ST;
     constexpr int Tn = NT * 32;
     constexpr int D = 256;
     constexpr bool FAST = DT<T>::FAST;
@@ -61,8 +102,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
     const int n = gw / NT, q0 = (gw % NT) * 32;
     if (n >= B) return;  // wave-uniform
 
-    const T* qrow = q + ((size_t)n * Tn + q0 + r) * D + 8 * h;
-    const T* kbase = k + ((size_t)n * Tn + r) * D + 8 * h;
+    const ST* qrow = q + ((size_t)n * Tn + q0 + r) * D + 8 * h;
+    const ST* kbase = k + ((size_t)n * Tn + r) * D + 8 * h;
 
     // ---- S^T[key][query] = sum_d K[key][d] Q[query][d] --------------------------------------------------
     f32x16 st[NT];
@@ -72,10 +113,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
         for (int i = 0; i < 16; ++i) st[kt][i] = 0.f;
 #pragma unroll 2
     for (int kk = 0; kk < D / 16; ++kk) {
-        const Frag8<T> qf = load_frag(qrow + kk * 16);
+        const Frag8<T> qf = load_op<T>(qrow + kk * 16);
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
-            const Frag8<T> kf = load_frag(kbase + (size_t)kt * 32 * D + kk * 16);
+            const Frag8<T> kf = load_op<T>(kbase + (size_t)kt * 32 * D + kk * 16);
             mma16(st[kt], kf, qf);
         }
     }
@@ -106,8 +147,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
         for (int i = 0; i < 16; ++i) st[kt][i] = FAST ? st[kt][i] * inv : st[kt][i] / sum;
 
     // ---- O[query][dim] = sum_key P[query][key] V[key][dim], four 32-wide dim tiles at a time ---------------
-    const T* vbase = vt + ((size_t)n * D + r) * Tn + 4 * h;
-    T* obase = out + ((size_t)n * Tn + q0) * D + r;
+    const ST* vbase = vt + ((size_t)n * D + r) * Tn + 4 * h;
+    ST* obase = out + ((size_t)n * Tn + q0) * D + r;
 #pragma unroll 1
     for (int dg = 0; dg < D / 128; ++dg) {
         f32x16 o[4];
@@ -122,7 +163,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
                 const Frag8<T> pf = PFrag<T>::make(st[kt], s);
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    const Frag8<T> vf = load_v(vbase + (size_t)(dg * 128 + d * 32) * Tn, kt * 32 + 16 * s);
+                    const Frag8<T> vf = load_vop<T>(vbase + (size_t)(dg * 128 + d * 32) * Tn, kt * 32 + 16 * s);
                     mma16(o[d], pf, vf);
                 }
             }
@@ -130,7 +171,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) obase[(size_t)acc_row(i, h) * D + dg * 128 + d * 32] = (T)o[d][i];
+            for (int i = 0; i < 16; ++i) obase[(size_t)acc_row(i, h) * D + dg * 128 + d * 32] = (ST)o[d][i];
     }
 }
 
@@ -283,7 +324,7 @@ int launch_attention(int dtype, const void* q, const void* k, const void* vt, vo
     const int nt = T / 32;
     const int waves = B * nt;
     dim3 grid((waves + 3) / 4), block(256);
-    if (dtype && nt == 8) {
+    if (dtype == 1 && nt == 8) {
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_BUF);
@@ -295,7 +336,12 @@ int launch_attention(int dtype, const void* q, const void* k, const void* vt, vo
         return (int)hipGetLastError();
     }
     if (!q) return 0;  // prepare-only call: nothing to set for the direct-from-global kernels
-    if (dtype) {
+    if (dtype == 2) {  // split-bf16 products on fp32 tensors
+        if (nt == 8)
+            hipLaunchKernelGGL((attention_kernel<bf16x3, 8>), grid, block, 0, s, (const float*)q, (const float*)k, (const float*)vt, (float*)out, B);
+        else
+            hipLaunchKernelGGL((attention_kernel<bf16x3, 2>), grid, block, 0, s, (const float*)q, (const float*)k, (const float*)vt, (float*)out, B);
+    } else if (dtype) {
         if (nt == 8)
             hipLaunchKernelGGL((attention_kernel<__bf16, 8>), grid, block, 0, s, (const __bf16*)q, (const __bf16*)k, (const __bf16*)vt, (__bf16*)out, B);
         else

@@ -13,12 +13,16 @@ namespace {
 constexpr int APITCH = 144;
 constexpr int HWID = 34, HROWS = 6;  // halo of a 4 x 32 pixel tile
 
+// T: compute type of common.h (float / __bf16 / bf16x3); x is in its storage type, the weights in its packed type
 template <typename T>
-__global__ __launch_bounds__(256) void aux_head_kernel(const T* __restrict__ x, const float2* __restrict__ ab,
-                                                       const T* __restrict__ wpack, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) void aux_head_kernel(const typename DT<T>::ST* __restrict__ x, const float2* __restrict__ ab,
+                                                       const typename DT<T>::WT* __restrict__ wpack, const float* __restrict__ bias,
                                                        const float* __restrict__ x_t, const float* __restrict__ coef,
                                                        float* __restrict__ out, float* __restrict__ raw, int B, int C, int cout) {
+    typedef typename DT<T>::ST ST;
+    typedef typename DT<T>::WT WT;
     constexpr int KC = DT<T>::KC, KK = KC / 16, OPP = KC / 8;
+    constexpr int FB = DT<T>::FRAG_BYTES, WP = DT<T>::WPARTS;
     constexpr bool FAST = DT<T>::FAST;
     constexpr int LOG_OPP = (OPP == 8) ? 3 : 2;
     constexpr int PSTRIDE = 256 / OPP;
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(256) void aux_head_kernel(const T* __restrict__ x, 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = 0.f;
                 if (y >= 0 && y < 32 && xx >= 0 && xx < 32) {
-                    const T* p = x + (((size_t)n * 32 + y) * 32 + xx) * C + chunk * KC + oct * 8;
+                    const ST* p = x + (((size_t)n * 32 + y) * 32 + xx) * C + chunk * KC + oct * 8;
                     const f32x4 lo = load4(p), hi = load4(p + 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -66,19 +70,19 @@ __global__ __launch_bounds__(256) void aux_head_kernel(const T* __restrict__ x, 
                         o[j + 4] = silu_f<FAST>(fmaf(hi[j], abr[j + 4].x, abr[j + 4].y));
                     }
                 }
-                store_frag(reinterpret_cast<T*>(smem + hq * APITCH) + oct * 8, o);
+                lds_store_a<T>(smem + hq * APITCH + oct * FB, o);
             }
         }
         __syncthreads();
         // ---- multiply: wave w = image row row0 + w of the tile, 9 taps x KK k-steps, N padded to 32 ----------------
-        const T* wp = wpack + (size_t)chunk * 9 * KK * 512 + lane * 8;
+        const WT* wp = wpack + (size_t)chunk * 9 * KK * 512 * WP + lane * 8;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const char* abase = smem + ((wave + tap / 3) * HWID + r + tap % 3) * APITCH + h * (8 * (int)sizeof(T));
+            const char* abase = smem + ((wave + tap / 3) * HWID + r + tap % 3) * APITCH + h * FB;
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
-                const Frag8<T> af = load_frag(reinterpret_cast<const T*>(abase) + kk * 16);
-                const Frag8<T> bf = load_frag(wp + (tap * KK + kk) * 512);
+                const Frag8<T> af = lds_read_a<T>(abase, kk);
+                const Frag8<T> bf = load_wfrag<T>(wp + (tap * KK + kk) * 512 * WP);
                 mma16(acc, af, bf);
             }
         }
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void aux_head_kernel(const T* __restrict__ x, 
 
 // packed[chunk][tap][kk][lane][j] = W[co = lane & 31][ci = chunk*KC + kk*16 + 8*(lane>>5) + j][tap], zero for co >= cout
 template <typename T>
-__global__ void pack_aux_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int C, int cout) {
+__global__ void pack_aux_weights_kernel(const float* __restrict__ w, typename DT<T>::WT* __restrict__ out, int C, int cout) {
     constexpr int KC = DT<T>::KC, KK = KC / 16;
     const int total = C * 9 * 32;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -112,7 +116,15 @@ __global__ void pack_aux_weights_kernel(const float* __restrict__ w, T* __restri
         const int chunk = t;
         const int co = lane & 31;
         const int ci = chunk * KC + kk * 16 + 8 * (lane >> 5) + j;
-        out[idx] = (co < cout) ? (T)w[((size_t)co * C + ci) * 9 + tap] : (T)0.f;
+        const float v = (co < cout) ? w[((size_t)co * C + ci) * 9 + tap] : 0.f;
+        if constexpr (DT<T>::WPARTS == 1) {
+            out[idx] = (typename DT<T>::WT)v;
+        } else {  // bf16x3: the lo plane of a fragment follows its hi plane
+            const size_t o = ((size_t)idx / 512) * 1024 + (idx % 512);
+            const __bf16 hi = (__bf16)v;
+            out[o] = hi;
+            out[o + 512] = (__bf16)(v - (float)hi);
+        }
     }
 }
 
@@ -199,7 +211,9 @@ size_t aux_pack_elems(int C) { return (size_t)C * 9 * 32; }
 
 int launch_pack_aux_weights(int dtype, const float* w, void* out, int C, int cout, hipStream_t s) {
     const int grid = (int)((aux_pack_elems(C) + 255) / 256);
-    if (dtype)
+    if (dtype == 2)
+        hipLaunchKernelGGL(pack_aux_weights_kernel<bf16x3>, dim3(grid), dim3(256), 0, s, w, (__bf16*)out, C, cout);
+    else if (dtype)
         hipLaunchKernelGGL(pack_aux_weights_kernel<__bf16>, dim3(grid), dim3(256), 0, s, w, (__bf16*)out, C, cout);
     else
         hipLaunchKernelGGL(pack_aux_weights_kernel<float>, dim3(grid), dim3(256), 0, s, w, (float*)out, C, cout);
@@ -207,11 +221,13 @@ int launch_pack_aux_weights(int dtype, const float* w, void* out, int C, int cou
 }
 
 // supported: res == 32, C a multiple of the chunk size, cout <= 32
-int aux_head_supported(int dtype, int res, int C, int cout) { return res == 32 && C % (dtype ? 64 : 32) == 0 && cout <= 32; }
+int aux_head_supported(int dtype, int res, int C, int cout) { return res == 32 && C % (dtype == 1 ? 64 : 32) == 0 && cout <= 32; }
 
 int launch_aux_head(int dtype, const void* x, const float2* ab, const void* wpack, const float* bias, const float* x_t,
                     const float* coef, float* out, int B, int C, int cout, hipStream_t s, float* raw) {
-    if (dtype)
+    if (dtype == 2)
+        hipLaunchKernelGGL(aux_head_kernel<bf16x3>, dim3(B * 8), dim3(256), 0, s, (const float*)x, ab, (const __bf16*)wpack, bias, x_t, coef, out, raw, B, C, cout);
+    else if (dtype)
         hipLaunchKernelGGL(aux_head_kernel<__bf16>, dim3(B * 8), dim3(256), 0, s, (const __bf16*)x, ab, (const __bf16*)wpack, bias, x_t, coef, out, raw, B, C, cout);
     else
         hipLaunchKernelGGL(aux_head_kernel<float>, dim3(B * 8), dim3(256), 0, s, (const float*)x, ab, (const float*)wpack, bias, x_t, coef, out, raw, B, C, cout);

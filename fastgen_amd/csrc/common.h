@@ -133,6 +133,18 @@ __device__ __forceinline__ void load_frag_rsrc(Frag8<bf16x3>& f, __amdgpu_buffer
     f.hi = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, lane_elems * 2, elem_off * 2, 0));
     f.lo = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, lane_elems * 2, elem_off * 2 + 1024, 0));
 }
+// a packed weight fragment straight from memory (p: the fragment's first element for this lane)
+template <typename T>
+__device__ __forceinline__ Frag8<T> load_wfrag(const typename DT<T>::WT* p) {
+    return load_frag(p);
+}
+template <>
+__device__ __forceinline__ Frag8<bf16x3> load_wfrag<bf16x3>(const __bf16* p) {
+    Frag8<bf16x3> f;
+    f.hi = *reinterpret_cast<const bf16x8*>(p);
+    f.lo = *reinterpret_cast<const bf16x8*>(p + 512);
+    return f;
+}
 // A fragment of 16-deep MFMA step kk out of a pixel's K-chunk in LDS (p: the lane's pixel + lane-half offset)
 template <typename T>
 __device__ __forceinline__ Frag8<T> lds_read_a(const char* p, int kk);

@@ -534,7 +534,7 @@ int run_block(fg_edm* h, const Block& b, const Act& x1, int c1, const Act& x2, i
         q.ab = w.ab2; q.wpack = b.p_qkv; q.bias = b.qkv_bias; q.scale = 1.0f; q.Cout = 3 * b.cout;
         q.q_out = w.q; q.k_out = w.k; q.vt_out = w.vt;
         HIP_TRY(conv_launch(h, 1, PRO_GN, RES_NONE, OUT_QKV, q, s));
-        HIP_TRY(launch_attention(h->dtype, w.q, w.k, w.vt, w.aout, B, hw, s));
+        HIP_TRY(launch_attention(h->cmode, w.q, w.k, w.vt, w.aout, B, hw, s));
         ConvArgs p{};
         p.src1 = w.aout; p.C1 = b.cout; p.Hs = p.Ws = p.H = p.W = b.res_out; p.B = B;
         p.wpack = b.p_proj; p.bias = h->P(b.proj_b); p.resid = x_mid.p; p.scale = kSkipScale; p.out = out.p; p.Cout = b.cout;
@@ -618,7 +618,7 @@ int run_forward(fg_edm* h, const float* x_t, const double* t, int t_stride, cons
             aux_ab = w.ab0;
         } else if (b.kind == K_AUX_CONV) {
             if (b.p_aux)
-                HIP_TRY(launch_aux_head(h->dtype, x->p, aux_ab, b.p_aux, h->P(b.b), x_t, w.coef, out, B, b.cin, b.cout, s, ts ? ts->raw_out : nullptr));
+                HIP_TRY(launch_aux_head(h->cmode, x->p, aux_ab, b.p_aux, h->P(b.b), x_t, w.coef, out, B, b.cin, b.cout, s, ts ? ts->raw_out : nullptr));
             else
                 HIP_TRY(launch_aux_out(h->dtype, x->p, aux_ab, h->P(b.w), h->P(b.b), x_t, w.coef, out, B, b.res_out, b.cin, b.cout, s, ts ? ts->raw_out : nullptr));
         }
@@ -724,7 +724,7 @@ int ensure_device_state(fg_edm* h) {
         if (b.kind == K_STEM && stem_supported(b.res_out, b.cin, b.cout))
             if ((rc = dev_alloc(h, &b.p_stem, stem_pack_elems() * tsz))) return rc;
     for (Block& b : h->dec)
-        if (b.kind == K_AUX_CONV && aux_head_supported(h->dtype, b.res_out, b.cin, b.cout))
+        if (b.kind == K_AUX_CONV && aux_head_supported(h->cmode, b.res_out, b.cin, b.cout))
             if ((rc = dev_alloc(h, &b.p_aux, aux_pack_elems(b.cin) * tsz))) return rc;
     if ((rc = dev_alloc(h, (void**)&h->aff_w, sizeof(float) * (size_t)h->temb_total * h->emb_ch))) return rc;
     if ((rc = dev_alloc(h, (void**)&h->aff_b, sizeof(float) * (size_t)h->temb_total))) return rc;
@@ -735,7 +735,7 @@ int ensure_device_state(fg_edm* h) {
     if ((rc = dev_alloc(h, (void**)&h->freqs, sizeof(float) * half))) return rc;
     HIP_TRY(hipMemcpy(h->freqs, fr.data(), sizeof(float) * half, hipMemcpyHostToDevice));
     if (conv_prepare_all(h->cmode) != 0) return fail(FG_EHIP, "hipFuncSetAttribute(dynamic LDS) failed");
-    if (launch_attention(h->dtype, nullptr, nullptr, nullptr, nullptr, 1, 256, nullptr) != 0) return fail(FG_EHIP, "attention prepare failed");
+    if (launch_attention(h->cmode, nullptr, nullptr, nullptr, nullptr, 1, 256, nullptr) != 0) return fail(FG_EHIP, "attention prepare failed");
     HIP_TRY(hipHostMalloc((void**)&h->slots, sizeof(fg_edm::Slot) * fg_edm::kSlots));
     for (int i = 0; i < fg_edm::kSlots; ++i) HIP_TRY(hipEventCreateWithFlags(&h->slot_ev[i], hipEventDisableTiming));
     h->device_ready = true;
@@ -850,7 +850,7 @@ int fg_edm_pack_weights(fg_edm* h, void* stream) {
     for (Block& b : h->enc)
         if (b.kind == K_STEM && b.p_stem) HIP_TRY(launch_pack_stem_weights(h->dtype, h->P(b.w), b.p_stem, b.cin, s));
     for (Block& b : h->dec)
-        if (b.kind == K_AUX_CONV && b.p_aux) HIP_TRY(launch_pack_aux_weights(h->dtype, h->P(b.w), b.p_aux, b.cin, b.cout, s));
+        if (b.kind == K_AUX_CONV && b.p_aux) HIP_TRY(launch_pack_aux_weights(h->cmode, h->P(b.w), b.p_aux, b.cin, b.cout, s));
     drop_graph(h);
     h->packed = true;
     return FG_OK;

@@ -99,7 +99,8 @@ int launch_act_to_nchw(int dtype, const void* in, float* out, int B, int C, int 
 int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, hipStream_t s);
 
 // Single-head self-attention over T tokens, head dim 256 (AttentionOp + value product, EDM/network.py:160-168, 295-296).
-// q,k: [B][T][256], vt: [B][256][T], out [B][T][256], all in the compute dtype (dtype 0 fp32 / 1 bf16).
+// q,k: [B][T][256], vt: [B][256][T], out [B][T][256]; dtype 0: fp32 tensors, exact fp32 products / 1: bf16 / 2: fp32 tensors,
+// split-bf16 products (FG_DTYPE_BF16X3).
 int launch_attention(int dtype, const void* q, const void* k, const void* vt, void* out, int B, int T, hipStream_t s);
 
 // MFMA output head (aux.hip): aux_conv(silu(aux_norm(x))) + EDM output preconditioning, res == 32.

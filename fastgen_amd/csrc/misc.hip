@@ -70,31 +70,46 @@ __global__ __launch_bounds__(512) void gn_coeffs_kernel(const AT* __restrict__ x
 // tensor.  st[b][slot][quad] = {sum, sum of squares} over a pixel tile of channels 4*quad..4*quad+3; the normalised
 // tensor is the virtual concat of up to two producers.  One workgroup per image, one thread per channel; combined in
 // fp64 in a fixed order (deterministic).
-__global__ void gn_finalize_kernel(const float2* __restrict__ st1, int C1, int S1, const float2* __restrict__ st2, int C2,
-                                   int S2, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                   float2* __restrict__ ab, int hw, float2* __restrict__ mr) {
-    const int C = C1 + C2;
+__global__ __launch_bounds__(512) void gn_finalize_kernel(const float2* __restrict__ st1, int C1, int S1, const float2* __restrict__ st2, int C2,
+                                                         int S2, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                         float2* __restrict__ ab, int hw, float2* __restrict__ mr) {
+    // Two levels, fixed order (deterministic), fp64: (1) thread (slot lane sg, channel quad q) adds the slots sg, sg + SG, ... of
+    // its quad - the loads of a quad's up to 32 slots (conv_ws3.hip writes one per tile and producer wave) are spread over SG
+    // threads instead of one thread walking them all; (2) one thread per channel adds its group's quads x lanes.
+    const int C = C1 + C2, Qt = C >> 2;
     const int groups = min(32, C / 4);
     const int cpg = C / groups;
     const int n = blockIdx.x;
+    const int SG = (int)blockDim.x / Qt;  // >= 4 for C <= 512 (checked by the launcher)
+    __shared__ double ps[512], pq[512];
+    const int q = threadIdx.x % Qt, sg = threadIdx.x / Qt;
+    if (sg < SG) {
+        const bool first = q * 4 < C1;
+        const float2* st = first ? st1 : st2;
+        const int S = first ? S1 : S2;
+        const int Q = (first ? C1 : C2) >> 2;
+        const int ql = first ? q : q - (C1 >> 2);
+        double s = 0.0, v2 = 0.0;
+        for (int sl = sg; sl < S; sl += SG) {
+            const float2 v = st[((size_t)n * S + sl) * Q + ql];
+            s += v.x;
+            v2 += v.y;
+        }
+        ps[sg * Qt + q] = s;
+        pq[sg * Qt + q] = v2;
+    }
+    __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const int g = c / cpg;
-        double s = 0.0, q = 0.0;
-        for (int quad = g * cpg / 4; quad < (g + 1) * cpg / 4; ++quad) {
-            const bool first = quad * 4 < C1;
-            const float2* st = first ? st1 : st2;
-            const int S = first ? S1 : S2;
-            const int Q = (first ? C1 : C2) >> 2;
-            const int ql = first ? quad : quad - (C1 >> 2);
-            for (int sl = 0; sl < S; ++sl) {
-                const float2 v = st[((size_t)n * S + sl) * Q + ql];
-                s += v.x;
-                q += v.y;
+        double s = 0.0, v2 = 0.0;
+        for (int quad = g * cpg / 4; quad < (g + 1) * cpg / 4; ++quad)
+            for (int l = 0; l < SG; ++l) {
+                s += ps[l * Qt + quad];
+                v2 += pq[l * Qt + quad];
             }
-        }
         const double cnt = (double)cpg * hw;
         const double mean = s / cnt;
-        double var = q / cnt - mean * mean;
+        double var = v2 / cnt - mean * mean;
         if (var < 0.0) var = 0.0;
         const float m = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
         const float a = rstd * gamma[c];
@@ -539,8 +554,8 @@ int launch_gn_finalize(const float2* st1, int c1, int s1, const float2* st2, int
     if (C % 4 || (c1 % 4) || C < 16) return (int)hipErrorInvalidValue;
     const int groups = C / 4 < 32 ? C / 4 : 32;
     if (C % groups || (C / groups) % 4) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(C < 512 ? C : 512), 0, s, st1, c1, s1, st2, c2, s2, gamma, beta,
-                       eps, ab, hw, mr);
+    if (C > 512 || (C % 4) || (c1 % 4)) return (int)hipErrorInvalidValue;  // the kernel's LDS partials: 512 / (C / 4) >= 4 slot lanes
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(512), 0, s, st1, c1, s1, st2, c2, s2, gamma, beta, eps, ab, hw, mr);
     RET_LAST();
 }
 
