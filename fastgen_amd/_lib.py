@@ -28,6 +28,11 @@ class fg_edm_config(ctypes.Structure):
     ]
 
 
+class fg_dit_config(ctypes.Structure):
+    _fields_ = [("input_size", c_int), ("patch_size", c_int), ("in_channels", c_int), ("hidden_size", c_int), ("depth", c_int),
+                ("num_heads", c_int), ("mlp_hidden", c_int), ("embedding_rows", c_int), ("r_timestep", c_int), ("compute_dtype", c_int)]
+
+
 # name -> (restype, argtypes); every symbol include/fastgen_amd.h declares
 SIGNATURES = {
     "fg_last_error": (c_char_p, []),
@@ -76,6 +81,14 @@ SIGNATURES = {
                                    c_int, c_void_p, c_size_t, c_void_p]),
     "fg_edm_backward_part": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "fg_dit_create": (c_int, [POINTER(fg_dit_config), POINTER(c_void_p)]),
+    "fg_dit_destroy": (None, [c_void_p]),
+    "fg_dit_num_params": (c_int, [c_void_p]),
+    "fg_dit_param_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int), POINTER(c_int64)]),
+    "fg_dit_bind_param": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
+    "fg_dit_pack_weights": (c_int, [c_void_p, c_void_p]),
+    "fg_dit_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "fg_dit_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "fg_disc_edm_num_params": (c_int, [c_int]),
     "fg_disc_edm_workspace_bytes": (c_size_t, [c_int, c_int]),
     "fg_disc_edm_run": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),

@@ -30,11 +30,17 @@ struct ConvArgs {
     void* q_out;
     void* k_out;
     void* vt_out;
+    // Transformer GEMMs (OUT_TOK / OUT_HEADS: the DiT blocks, dit.hip): the same kernel with 128-column output tiles.
+    // epilogue: v = acc + bias; act 1: v = gelu_tanh(v); gate: v *= gate[n][co]; + resid; * scale
+    const float* gate = nullptr;  // [B][gate_stride] per-image, per-channel multiplier (the adaLN gates), or nullptr
+    int gate_stride = 0;
+    int act = 0;                  // 0 none, 1 GELU(tanh)
+    int heads = 0, head_dim = 0;  // OUT_HEADS: Cout = 3 * heads * head_dim; q_out, k_out [B][heads][T][head_dim], vt_out [B][heads][head_dim][T]
 };
 
 enum { PRO_NONE = 0, PRO_GN = 1, PRO_GN_SILU = 2 };
 enum { RES_NONE = 0, RES_DOWN = 1, RES_UP = 2 };
-enum { OUT_NHWC = 0, OUT_QKV = 1 };
+enum { OUT_NHWC = 0, OUT_QKV = 1, OUT_TOK = 2, OUT_HEADS = 3 };
 
 // dtype: 0 fp32, 1 bf16 — also the storage type of every activation tensor (src1/src2/resid/out); 2 = split-bf16 arithmetic
 // (common.h bf16x3) on fp32 tensors.

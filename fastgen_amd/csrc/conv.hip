@@ -59,7 +59,17 @@ struct Geom {
 
 // Output-channel tiles per wave.  The 8x8 layers have only B/2 pixel tiles: splitting N over two workgroups (128
 // channels each) doubles the grid so that two workgroups are resident per CU there as well.
-__host__ __device__ constexpr int conv_nt(int ks, int logw, int outmode) { return (logw == 3 && ks == 3 && outmode == OUT_NHWC) ? 1 : 2; }
+__host__ __device__ constexpr int conv_nt(int ks, int logw, int outmode) {
+    return ((logw == 3 && ks == 3 && outmode == OUT_NHWC) || outmode == OUT_TOK || outmode == OUT_HEADS) ? 1 : 2;
+}
+
+// GELU with the tanh approximation (torch.nn.GELU(approximate="tanh"), the DiT feed-forward: DiT/network.py:176)
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    const float u = 0.7978845608028654f * fmaf(0.044715f * x, x * x, x);
+    // tanh(u) = 1 - 2 / (1 + e^{2u}); accurate expf keeps the exact-fp32 mode exact, the MFMA-bound GEMM hides its cost
+    const float t = 1.0f - 2.0f / (1.0f + expf(2.0f * u));
+    return 0.5f * x * (1.0f + t);
+}
 
 template <int PRO, bool FAST>
 __device__ __forceinline__ float pro_apply(float x, float2 ab) {
@@ -375,7 +385,10 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         if (t == 1234.5678f) reinterpret_cast<float*>(a.out)[0] = t;
         return;
     }
-    if (OUTMODE == OUT_NHWC || nblk < 2) {  // NHWC tensor, or the q / k plane of the qkv projection ([B][HW][256])
+    // which plane of a head-split qkv projection this 128-column tile lies in (planes are multiples of 128 wide)
+    const int hplane = (OUTMODE == OUT_HEADS) ? (nblk * 128) / (a.heads * a.head_dim) : 0;
+    if (OUTMODE == OUT_NHWC || OUTMODE == OUT_TOK || (OUTMODE == OUT_QKV && nblk < 2) || (OUTMODE == OUT_HEADS && hplane < 2)) {
+        // NHWC tensor, or the q / k plane of a qkv projection ([B][HW][256]; OUT_HEADS: [B][heads][T][head_dim])
         // Transpose each 32-pixel x 64-channel accumulator slab through this wave's private LDS scratch (the A buffers
         // are dead after the last barrier) so that global traffic is row-contiguous: a lane owns one channel QUAD of one
         // pixel (16 B fp32 / 8 B bf16 per access), 16 lanes cover a pixel's 64 channels, 4 pixels per wave instruction.
@@ -389,10 +402,14 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         const int c4 = lane % QPW, prow = lane / QPW;
         const int co0 = nblk * (128 * NT) + wave * (32 * NT) + c4 * 4;
         const bool qk = (OUTMODE == OUT_QKV);
-        ST* out = reinterpret_cast<ST*>(qk ? (nblk == 0 ? a.q_out : a.k_out) : a.out);
-        const ST* resid = qk ? nullptr : reinterpret_cast<const ST*>(a.resid);
-        const int ostride = qk ? 256 : a.Cout;          // channels per pixel of the tensor written
-        const int co_out = qk ? co0 - nblk * 256 : co0;  // channel within that tensor (co0 indexes bias / temb / stats)
+        const bool hd = (OUTMODE == OUT_HEADS);
+        ST* out = reinterpret_cast<ST*>(qk ? (nblk == 0 ? a.q_out : a.k_out) : (hd ? (hplane == 0 ? a.q_out : a.k_out) : a.out));
+        const ST* resid = (qk || hd) ? nullptr : reinterpret_cast<const ST*>(a.resid);
+        const int ostride = qk ? 256 : (hd ? a.head_dim : a.Cout);  // channels per pixel of the tensor written
+        // channel within that tensor (co0 indexes bias / temb / stats); OUT_HEADS: this lane's quad lies in ONE head (head_dim % 4 == 0)
+        const int hcol = hd ? co0 - hplane * a.heads * a.head_dim : 0;
+        const int hhead = hd ? hcol / a.head_dim : 0;
+        const int co_out = qk ? co0 - nblk * 256 : (hd ? hcol - hhead * a.head_dim : co0);
         f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
         if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + co0);
         float ssum[G::IMGS], ssq[G::IMGS];
@@ -405,6 +422,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
             const int y = row0 + ((p >> G::LOGTW) & (G::TH - 1));
             const int n = n_base + mt / MT_PER_IMG;
             ok = n < a.B;
+            if (hd) return (((size_t)n * a.heads + hhead) * HWo + (size_t)y * G::W + x) * ostride + co_out;
             return (((size_t)n * H + y) * G::W + x) * ostride + co_out;
         };
         typedef typename Raw4<ST>::type R4;
@@ -431,6 +449,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
                     *reinterpret_cast<float*>(ep + acc_row(i, h) * EP_PITCH + (nt * 32 + r) * 4) = acc[mt][nt][i];
             f32x4 add = bias4;
             if (!qk && a.temb && n < a.B) add += *reinterpret_cast<const f32x4*>(a.temb + (size_t)n * a.temb_stride + co0);
+            f32x4 gate4 = {1.f, 1.f, 1.f, 1.f};
+            if (OUTMODE == OUT_TOK && a.gate && n < a.B) gate4 = *reinterpret_cast<const f32x4*>(a.gate + (size_t)n * a.gate_stride + co0);
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 const int pl = j * RP + prow;
@@ -439,6 +459,13 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
                 const size_t go = goff(mt, j, ok);
                 if (ok) {
                     v += add;
+                    if (OUTMODE == OUT_TOK) {
+                        if (a.act == 1) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+                        }
+                        v *= gate4;
+                    }
                     if (resid) v += widen4(rcur[j]);
                     v *= a.scale;
                     const f32x4 vr = store4(out + go, v);  // the values as the consumer will read them
@@ -468,8 +495,10 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         ST* vt = reinterpret_cast<ST*>(a.vt_out);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int cl = wave * 64 + nt * 32 + r;
-            const float bias = a.bias ? a.bias[nblk * 256 + cl] : 0.f;
+            // channel of this lane: row of the [256][HW] plane (OUT_QKV), or of head h's [head_dim][T] plane (OUT_HEADS)
+            const int cg = nblk * (128 * NT) + wave * (32 * NT) + nt * 32 + r;  // global output channel
+            const int cl = (OUTMODE == OUT_HEADS) ? cg - 2 * a.heads * a.head_dim : wave * 64 + nt * 32 + r;
+            const float bias = a.bias ? a.bias[OUTMODE == OUT_HEADS ? cg : nblk * 256 + cl] : 0.f;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
@@ -479,7 +508,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
                     const int y = row0 + ((p >> G::LOGTW) & (G::TH - 1));
                     const int n = n_base + (p >> (G::LOGTW + G::LOGTH));
                     if (n < a.B)
-                        store4(vt + ((size_t)n * 256 + cl) * HWo + y * G::W + x,
+                        store4(vt + ((size_t)n * (OUTMODE == OUT_HEADS ? a.heads * a.head_dim : 256) + cl) * HWo + y * G::W + x,
                                f32x4{acc[mt][nt][i4] + bias, acc[mt][nt][i4 + 1] + bias, acc[mt][nt][i4 + 2] + bias,
                                      acc[mt][nt][i4 + 3] + bias});
                 }
@@ -562,6 +591,10 @@ int launch_t(int ks, int pro, int res, int outmode, const ConvArgs& a, hipStream
         if (ks == 1 && pro == PRO_GN && res == RES_NONE) return launch_w<T, 1, PRO_GN, RES_NONE, OUT_QKV>(a, s);
         return (int)hipErrorInvalidValue;
     }
+    if (outmode == OUT_TOK || outmode == OUT_HEADS) {  // transformer GEMMs: 256 tokens per image as a 16x16 "image", 1x1 "conv"
+        if (ks != 1 || pro != PRO_NONE || res != RES_NONE || a.W != 16) return (int)hipErrorInvalidValue;
+        return outmode == OUT_TOK ? launch_one<T, 1, PRO_NONE, RES_NONE, 4, OUT_TOK>(a, s) : launch_one<T, 1, PRO_NONE, RES_NONE, 4, OUT_HEADS>(a, s);
+    }
     if (ks == 3 && pro == PRO_GN_SILU) {
         if (res == RES_NONE) return launch_w<T, 3, PRO_GN_SILU, RES_NONE, OUT_NHWC>(a, s);
         if (res == RES_UP) return launch_w<T, 3, PRO_GN_SILU, RES_UP, OUT_NHWC>(a, s);
@@ -607,7 +640,11 @@ int launch_conv_debug(int dtype, const ConvArgs& a, hipStream_t stream) {
 int launch_conv_fused(int dtype, int ks, int pro, int res, int outmode, const ConvArgs& a, hipStream_t stream) {
     const int kc = dtype == 1 ? DT<__bf16>::KC : DT<float>::KC;  // 32 for fp32 and bf16x3
     if (a.H != a.W || (a.W != 8 && a.W != 16 && a.W != 32)) return (int)hipErrorInvalidValue;
-    if ((a.C1 % kc) || (a.C2 % kc) || (a.Cout % 256) || a.B <= 0) return (int)hipErrorInvalidValue;
+    const bool tok = outmode == OUT_TOK || outmode == OUT_HEADS;
+    if ((a.C1 % kc) || (a.C2 % kc) || (a.Cout % (tok ? 128 : 256)) || a.B <= 0) return (int)hipErrorInvalidValue;
+    if (outmode == OUT_HEADS && (a.heads <= 0 || (a.head_dim % 4) || a.Cout != 3 * a.heads * a.head_dim || ((a.heads * a.head_dim) % 128) ||
+                                 !a.q_out || !a.k_out || !a.vt_out))
+        return (int)hipErrorInvalidValue;
     if (res == RES_NONE && (a.Hs != a.H || a.Ws != a.W)) return (int)hipErrorInvalidValue;
     if (res == RES_DOWN && (a.Hs != 2 * a.H || a.Ws != 2 * a.W)) return (int)hipErrorInvalidValue;
     if (res == RES_UP && (2 * a.Hs != a.H || 2 * a.Ws != a.W)) return (int)hipErrorInvalidValue;
@@ -650,6 +687,8 @@ int conv_prepare_all(int dtype) {
         }
         if (!rc) rc = dispatch_t(dtype, 3, PRO_NONE, RES_NONE, OUT_NHWC, a, nullptr);
         if (!rc && a.W <= 16) rc = dispatch_t(dtype, 1, PRO_GN, RES_NONE, OUT_QKV, a, nullptr);
+        if (!rc && a.W == 16) rc = dispatch_t(dtype, 1, PRO_NONE, RES_NONE, OUT_TOK, a, nullptr);
+        if (!rc && a.W == 16) rc = dispatch_t(dtype, 1, PRO_NONE, RES_NONE, OUT_HEADS, a, nullptr);
     }
     g_prepare_only = false;
     if (!rc && dtype == 2) {

@@ -116,3 +116,15 @@ size_t stem_pack_elems();
 int launch_pack_stem_weights(int dtype, const float* w, void* out, int cin, hipStream_t s);
 int launch_stem(int dtype, const float* x, const float* c_in, const void* wpack, const float* bias, void* out, float2* stats,
                 int B, int res, int cin, hipStream_t s);
+
+// dit.hip: the non-GEMM pieces of a DiT forward (reference fastgen/networks/DiT/network.py); dtype = token-tensor storage (1 bf16, 0 fp32)
+int launch_dit_ln_modulate(int dtype, int D, const void* x, const float* mod, int mod_stride, int shift_off, int scale_off, void* y,
+                           int ntok, int tokens_per_image, hipStream_t s);
+int launch_dit_final(int dtype, int D, const void* x, const float* mod, const float* w, const float* bias, float* out, int ntok, int grid,
+                     int p, int C, hipStream_t s);
+int launch_dit_patch_embed(int dtype, const float* x, const float* w, const float* bias, const float* pos, void* out, int B, int C, int grid,
+                           int p, int D, hipStream_t s);
+int launch_dit_fourier(const float* t, float* f, int B, int dim, hipStream_t s);
+int launch_dit_cond(const float* t_emb, const float* r_emb, const float* table, const int64_t* cls, float* c, float* sc, int B, int D,
+                    hipStream_t s);
+int launch_dit_attention(int mode, const void* q, const void* k, const void* vt, void* out, int B, int heads, int head_dim, hipStream_t s);

@@ -275,6 +275,41 @@ FG_API int fg_edm_set_augment(fg_edm* h, const float* augment_labels);
 FG_API int fg_edm_set_dropout(fg_edm* h, float p, uint64_t seed);
 FG_API int fg_op_dropout_mask(float* out, int64_t total, float p, uint32_t block_index, uint64_t seed, void* stream);
 
+/* ---- DiT: the class-conditional diffusion transformer of fastgen/networks/DiT/network.py -------------------------
+ * kwargs of DiT(input_size, patch_size, in_channels, hidden_size, depth, num_heads, mlp_ratio, num_classes, class_dropout_prob,
+ * r_timestep, ...) (:233-253; configs/net.py:98-127).  Supported: 256 tokens (input_size / patch_size == 16), hidden_size in
+ * {384, 768, 1024, 1152} with head dim 64 or 72 (DiT-S/2, B/2, L/2, XL/2), mlp_hidden % 128 == 0. */
+typedef struct fg_dit_config {
+    int input_size;      /* 32 (latent resolution) */
+    int patch_size;      /* 2 */
+    int in_channels;     /* 4 */
+    int hidden_size;     /* 1152 */
+    int depth;           /* 28 */
+    int num_heads;       /* 16 */
+    int mlp_hidden;      /* int(hidden_size * mlp_ratio) = 4608 */
+    int embedding_rows;  /* num_classes + (class_dropout_prob > 0): rows of y_embedder.class_embeddings (:116-118) */
+    int r_timestep;      /* 1: second time embedding r_embedder (:276-279) */
+    int compute_dtype;   /* FG_DTYPE_* */
+} fg_dit_config;
+typedef struct fg_dit fg_dit; /* opaque */
+
+FG_API int fg_dit_create(const fg_dit_config* cfg, fg_dit** out);
+FG_API void fg_dit_destroy(fg_dit* h);
+/* State-dict view: the reference's names and shapes (restated timm attribute names for the patch embedding / attention / MLP
+ * layers), `pos_embed` (a persistent buffer there) included; bind / pack as for fg_edm. */
+FG_API int fg_dit_num_params(const fg_dit* h);
+FG_API int fg_dit_param_info(const fg_dit* h, int index, const char** name, int* ndim, int64_t shape[4]);
+FG_API int fg_dit_bind_param(fg_dit* h, const char* name, const float* device_ptr, int64_t numel);
+FG_API int fg_dit_pack_weights(fg_dit* h, void* stream);
+FG_API size_t fg_dit_workspace_bytes(const fg_dit* h, int batch);
+/* The network part of DiT.forward (:511-547): patch embedding + positional table, conditioning vector, the transformer blocks,
+ * output projection, unpatchify.  x_t, out: [B,C,H,W] fp32; t, r: [B] fp32 AS THE EMBEDDERS SEE THEM (after prepare_t's rescaling,
+ * :457-462, the SiT flip :503-504 and, for time_cond_type 'diff', the t - r difference :520-521: scalar host-side plumbing);
+ * r NULL = no r embedding; class_ids: [B] int64 row of the class table (num_classes = the unconditional row, :493-498);
+ * cond_out (nullable): [B, hidden_size] conditioning vector c.  Prediction-type conversion and the SiT sign stay with the caller. */
+FG_API int fg_dit_forward(fg_dit* h, const float* x_t, const float* t, const float* r, const int64_t* class_ids, float* out,
+                          float* cond_out, int batch, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Samples to image bytes, the step after generator_fn in the reference's sample writer
  * (scripts/fid/compute_fid_from_ckpts.py:199): out[n,y,x,c] = uint8(clip(images[n,c,y,x] * 127.5 + 128, 0, 255)),
  * fp32 multiply then add, truncation; NaN -> 0.  images NCHW fp32, out NHWC bytes. */

@@ -12,6 +12,7 @@ Usage:  python oracle/gen_golden.py            (writes tests/golden/*.pt)
         python oracle/gen_golden.py meanflow   (only the MeanFlow / rectified-flow fixtures)
         python oracle/gen_golden.py sample     (only the teacher Euler-sampler fixture)
         python oracle/gen_golden.py train_schedule   (only the training-side schedule helpers)
+        python oracle/gen_golden.py dit        (only the DiT fixtures: reference DiT class on restated timm stand-ins)
         python oracle/gen_golden.py sigma_shift   (only the eval- vs train-mode sigma_shift fixture)
         python oracle/gen_golden.py backward   (only the training-step fixtures: conv weight gradients)
 """
@@ -506,6 +507,64 @@ def augment_fixture(edm_net):
     torch.save(fx, os.path.join(OUT, "augment_b2.pt"))
 
 
+def dit_fixture():
+    """DiT: the reference's own `DiT` class (fastgen/networks/DiT/network.py) built on restated stand-ins of the
+    three timm classes it imports (oracle/_timm_restated.py: timm is un-vendored and absent here - parity 'restated' for those
+    three, reference code for the rest), seeded re-randomised weights (oracle/dit_ref.random_state_dict).  Recorded: state-dict
+    names / shapes, and for DiT-XL/2 (configs/net.py:124-127: hidden 1152, depth 28, 16 heads of 72) and DiT-S/2 (384, 12, 6 x 64)
+    a forward at B = 2 - output, conditioning vector, strided samples of every block output; XL also with the r embedding."""
+    import _timm_restated
+    import dit_ref
+
+    _ref_import.install_stubs()
+    _timm_restated.install()
+    if _ref_import.REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, _ref_import.REFERENCE_ROOT)
+    import fastgen.networks.DiT.network as dit_net
+
+    fx = {}
+    for tag, cfg in (("xl", dit_ref.XL_2), ("s", dit_ref.S_2), ("xl_r", dit_ref.DiTConfig(r_timestep=True))):
+        sd = dit_ref.random_state_dict(cfg, seed=77)
+        net = dit_net.DiT(input_size=cfg.input_size, patch_size=cfg.patch_size, in_channels=cfg.in_channels, hidden_size=cfg.hidden_size,
+                          depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio, class_dropout_prob=cfg.class_dropout_prob,
+                          enable_class_dropout=False, num_classes=cfg.num_classes, learn_sigma=False, r_timestep=cfg.r_timestep,
+                          scale_t=cfg.scale_t)
+        ref_sd = net.state_dict()
+        assert list(ref_sd.keys()) == list(sd.keys()), (set(ref_sd) ^ set(sd))
+        assert torch.allclose(ref_sd["pos_embed"], sd["pos_embed"], atol=1e-6)  # the restated 2-D sinusoidal table
+        if tag != "xl_r":
+            with open(os.path.join(OUT, f"dit_{tag}_state_dict_keys.txt"), "w") as f:
+                for k, v in ref_sd.items():
+                    f.write(f"{k} {' '.join(str(d) for d in v.shape)}\n")
+        net.load_state_dict(sd, strict=True)
+        net.eval()
+        B = 2
+        x = seeded((B, 4, 32, 32), 501)
+        t = torch.tensor([0.731, 0.094], dtype=torch.float64)
+        r = torch.tensor([0.352, 0.0], dtype=torch.float64) if cfg.r_timestep else None
+        cond = torch.zeros(B, cfg.num_classes)
+        cond[0, 417] = 1.0  # row 1 stays all-zero: the unconditional class (DiT/network.py:493-498)
+        trace, hooks = {}, []
+        for i, blk in enumerate(net.blocks):
+            hooks.append(blk.register_forward_hook(lambda m, a, o, i=i: trace.__setitem__(i, o.detach().clone())))
+        with torch.inference_mode():
+            out = net(x, t, condition=cond, r=r)
+        for h in hooks:
+            h.remove()
+        tr = {}
+        oo = dit_ref.dit_forward(sd, cfg, x, t, cond, r=r, trace=tr)
+        assert torch.allclose(oo, out, rtol=1e-4, atol=2e-5), float((oo - out).abs().max())
+        fx.update({f"{tag}/out": out.clone(), f"{tag}/t": t, f"{tag}/cond_class": torch.tensor([417, -1]), f"{tag}/c": tr["c"].clone(),
+                   f"{tag}/sd_checksum": sd_checksum(sd), f"{tag}/x_checksum": checksum(x)})
+        if r is not None:
+            fx[f"{tag}/r"] = r
+        for i in range(cfg.depth):
+            v = trace[i].reshape(-1)
+            fx[f"{tag}/block{i}/sample"] = v[:: max(1, v.numel() // 1024)][:1024].clone()
+            fx[f"{tag}/block{i}/norm"] = v.double().norm().float()
+    torch.save(fx, os.path.join(OUT, "dit_forward_b2.pt"))
+
+
 def sigma_shift_fixture(edm_net):
     """sigma_shift is applied in eval mode only (EDM/network.py:956: `None if self.training else self.sigma_shift`): the
     reference with sigma_shift = 0.003 (the value suggested in its consistency-model configs) in eval() and in train() mode
@@ -592,6 +651,10 @@ def dropout_fixture(edm_net):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["dit"]:
+        dit_fixture()
+        print("DiT fixtures written to", OUT)
+        return
     edm_net, ns, model = _ref_import.import_reference()
     torch.manual_seed(0)
     if sys.argv[1:] == ["augment"]:

@@ -1,0 +1,125 @@
+"""DiT.  CPU: the oracle restatement (oracle/dit_ref.py) against vectors recorded from the reference's own DiT class
+(built on restated timm stand-ins: oracle/_timm_restated.py, `python oracle/gen_golden.py dit`), and the drop-in module's state dict.
+GPU (-m gpu): the HIP path through the C ABI (fg_dit_forward) against those vectors and the oracle.
+
+Tolerances on the O(1) output: bf16x3 (default, fp32 tensors) and exact fp32: max |err| <= 2e-4, relative L2 <= 5e-5 (28 blocks of
+width 1152: three times the contraction length and twice the depth of the EDM U-Net); bf16: relative L2 <= 2e-2."""
+import os
+
+import pytest
+import torch
+
+from oracle import dit_ref as R
+
+CFGS = {"xl": R.XL_2, "s": R.S_2, "xl_r": R.DiTConfig(r_timestep=True)}
+KW = {"xl": dict(hidden_size=1152, depth=28, num_heads=16), "s": dict(hidden_size=384, depth=12, num_heads=6),
+      "xl_r": dict(hidden_size=1152, depth=28, num_heads=16, r_timestep=True)}
+
+
+def _inputs(fx, tag):
+    B = 2
+    x = torch.randn((B, 4, 32, 32), generator=torch.Generator().manual_seed(501))
+    cond = torch.zeros(B, 1000)
+    cond[0, 417] = 1.0  # row 1 all-zero: the unconditional class
+    r = fx.get(f"{tag}/r")
+    return x, fx[f"{tag}/t"], cond, r
+
+
+@pytest.mark.parametrize("tag", ["s", "xl", "xl_r"])
+def test_oracle_against_reference_golden(golden_dir, tag):
+    fx = torch.load(os.path.join(golden_dir, "dit_forward_b2.pt"), weights_only=True)
+    cfg = CFGS[tag]
+    sd = R.random_state_dict(cfg, seed=77)
+    x, t, cond, r = _inputs(fx, tag)
+    tr = {}
+    out = R.dit_forward(sd, cfg, x, t, cond, r=r, trace=tr)
+    assert (out - fx[f"{tag}/out"]).abs().max() < 5e-5
+    assert (tr["c"] - fx[f"{tag}/c"]).abs().max() < 1e-5
+    for i in (0, cfg.depth // 2, cfg.depth - 1):
+        v = tr[f"block{i}"].reshape(-1)
+        smp = v[:: max(1, v.numel() // 1024)][:1024]
+        assert float((smp - fx[f"{tag}/block{i}/sample"]).norm() / fx[f"{tag}/block{i}/sample"].norm()) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["s", "xl"])
+def test_module_state_dict_is_the_references(golden_dir, tag):
+    from fastgen_amd.networks.DiT.network import DiT
+
+    net = DiT(**KW[tag])
+    want = {}
+    for line in open(os.path.join(golden_dir, f"dit_{tag}_state_dict_keys.txt")):
+        p = line.split()
+        want[p[0]] = tuple(int(v) for v in p[1:])
+    got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert got == want and list(got) == list(want)
+    sd = R.random_state_dict(CFGS[tag], seed=77)
+    res = net.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    # the positional table is the reference's (recorded there as a persistent buffer)
+    assert torch.allclose(net.pos_embed, R.pos_embed_2d(KW[tag]["hidden_size"], 16).unsqueeze(0), atol=1e-6)
+    with pytest.raises(RuntimeError, match="HIP GPU only"):
+        with torch.no_grad():
+            net(torch.zeros(1, 4, 32, 32), torch.full((1,), 0.5, dtype=torch.float64), condition=torch.zeros(1, 1000))
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros(1, 4, 32, 32), torch.full((1,), 0.5, dtype=torch.float64), condition=torch.zeros(1, 1000))  # autograd
+
+
+TOL = {"fp32": (2e-4, 5e-5), "bf16x3": (2e-4, 5e-5), "bf16": (1e-1, 2e-2)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,mode", [("s", "fp32"), ("s", "bf16x3"), ("s", "bf16"), ("xl", "bf16x3"), ("xl", "bf16"), ("xl_r", "bf16x3")])
+def test_forward_against_reference_golden(golden_dir, tag, mode):
+    from fastgen_amd.networks.DiT.network import DiT
+
+    fx = torch.load(os.path.join(golden_dir, "dit_forward_b2.pt"), weights_only=True)
+    dev = torch.device("cuda:0")
+    net = DiT(compute_dtype=mode, **KW[tag])
+    net.load_state_dict(R.random_state_dict(CFGS[tag], seed=77), strict=True)
+    net = net.to(dev).eval()
+    x, t, cond, r = _inputs(fx, tag)
+    with torch.inference_mode():
+        out = net(x.to(dev), t.to(dev), condition=cond.to(dev), r=None if r is None else r.to(dev)).cpu()
+    want = fx[f"{tag}/out"]
+    err, rel = float((out - want).abs().max()), float((out - want).norm() / want.norm())
+    assert torch.isfinite(out).all() and err <= TOL[mode][0] and rel <= TOL[mode][1], (tag, mode, err, rel)
+    if tag == "s" and mode == "bf16x3":
+        with torch.inference_mode():
+            # class indices instead of one-hot rows, x0 conversion of the flow prediction, ragged batch, determinism
+            ids = torch.tensor([417, 1000], device=dev)
+            assert torch.equal(net(x.to(dev), t.to(dev), condition=ids).cpu(), out)
+            x0 = net(x.to(dev), t.to(dev), condition=ids, fwd_pred_type="x0").cpu()
+            assert torch.allclose(x0, x - t.reshape(2, 1, 1, 1).float() * out, atol=1e-5)
+            x5 = torch.randn((5, 4, 32, 32), generator=torch.Generator().manual_seed(9))
+            t5 = torch.tensor([0.9, 0.7, 0.5, 0.3, 0.1], dtype=torch.float64)
+            c5 = torch.nn.functional.one_hot(torch.tensor([1, 2, 3, 4, 5]), 1000).float()
+            got5 = net(x5.to(dev), t5.to(dev), condition=c5.to(dev)).cpu()
+            want5 = R.dit_forward(R.random_state_dict(CFGS[tag], seed=77), CFGS[tag], x5, t5, c5)
+            assert float((got5 - want5).abs().max()) <= TOL[mode][0]
+            assert torch.equal(got5[1:3], net(x5[1:3].to(dev), t5[1:3].to(dev), condition=c5[1:3].to(dev)).cpu())  # batch independence
+
+
+@pytest.mark.gpu
+def test_flow_sampler_against_oracle():
+    """RF Euler sampler of the reference (`DiT._sample_flow`, :605-651) with classifier-free guidance, 4 steps, DiT-S/2: the module's
+    `sample()` on the HIP network against the same loop run on the oracle network."""
+    from fastgen_amd.networks.DiT.network import DiT
+
+    dev = torch.device("cuda:0")
+    cfg = R.S_2
+    sd = R.random_state_dict(cfg, seed=77)
+    net = DiT(**KW["s"])
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    noise = torch.randn((2, 4, 32, 32), generator=torch.Generator().manual_seed(3))
+    cond = torch.nn.functional.one_hot(torch.tensor([7, 99]), 1000).float()
+    neg = torch.zeros(2, 1000)
+    got = net.sample(noise.to(dev), condition=cond.to(dev), neg_condition=neg.to(dev), guidance_scale=2.0, num_steps=4).cpu()
+    tl = net.noise_scheduler.get_t_list(4)
+    x = net.noise_scheduler.latents(noise=noise, t_init=tl[0])
+    for t, tn in zip(tl[:-1], tl[1:]):
+        tb = t.expand(2)
+        v = R.dit_forward(sd, cfg, torch.cat([x, x]), torch.cat([tb, tb]), torch.cat([neg, cond]))
+        vu, vc = v.chunk(2)
+        x = x + (tn - t).to(x.dtype) * (vu + 2.0 * (vc - vu))
+    assert float((got - x).abs().max()) <= 5e-4 and float((got - x).norm() / x.norm()) <= 1e-4
