@@ -325,7 +325,10 @@ int launch_attention(int dtype, const void* q, const void* k, const void* vt, vo
     const int waves = B * nt;
     dim3 grid((waves + 3) / 4), block(256);
     if (dtype == 1 && nt == 8) {
-        static bool attr_done = false;
+        static bool attr_done_dev[16] = {};
+        const int dev = fg_device_slot();
+        if (dev < 0) return (int)hipErrorInvalidDevice;
+        bool& attr_done = attr_done_dev[dev];
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_BUF);
             if (e != hipSuccess) return (int)e;

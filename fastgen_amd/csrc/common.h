@@ -11,6 +11,13 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define FG_WAVE 64
 
+// Host side: the current device's slot (0..15) of the per-device caches the launchers keep (function attributes belong to the
+// device's copy of the code object; the CU count to the device), or -1.
+inline int fg_device_slot() {
+    int dev = -1;
+    return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) ? dev : -1;
+}
+
 // ---- compute-dtype traits -------------------------------------------------------------------------
 // KC = input channels per K-chunk; a chunk row is always 128 bytes in LDS (64 bf16 / 32 fp32).
 // ST = storage type of activation tensors, WT = element type of packed weights, WPARTS = weight planes per fragment,
@@ -220,6 +227,20 @@ __device__ __forceinline__ f32x4 store4(__bf16* p, f32x4 v) {
     const bf16x4 q = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
     *reinterpret_cast<bf16x4*>(p) = q;
     return f32x4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
+}
+
+// split-bf16 storage of 4 consecutive values: hi plane at p, lo plane lo_off elements behind it (the head-split q | k | v^T of
+// the DiT qkv projection in the bf16x3 mode: the attention kernel then loads operand halves instead of splitting in registers)
+__device__ __forceinline__ f32x4 store4_split(__bf16* p, size_t lo_off, f32x4 v) {
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        hi[j] = (__bf16)v[j];
+        lo[j] = (__bf16)(v[j] - (float)hi[j]);
+    }
+    *reinterpret_cast<bf16x4*>(p) = hi;
+    *reinterpret_cast<bf16x4*>(p + lo_off) = lo;
+    return v;
 }
 
 // raw (un-widened) 4-element activation vectors: lets a load stay in flight without a dependent conversion

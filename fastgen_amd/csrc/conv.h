@@ -36,6 +36,7 @@ struct ConvArgs {
     int gate_stride = 0;
     int act = 0;                  // 0 none, 1 GELU(tanh)
     int heads = 0, head_dim = 0;  // OUT_HEADS: Cout = 3 * heads * head_dim; q_out, k_out [B][heads][T][head_dim], vt_out [B][heads][head_dim][T]
+    size_t heads_lo_off = 0;      // ... in the bf16x3 mode each of the three is TWO bf16 planes: hi at the pointer, lo this many elements behind
 };
 
 enum { PRO_NONE = 0, PRO_GN = 1, PRO_GN_SILU = 2 };

@@ -24,6 +24,8 @@
 #include "conv.h"
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace {
 
 constexpr int PITCH = 144;  // bytes per halo pixel in LDS: 128 B of channels + 16 B pad (odd multiple of 16 B)
@@ -60,7 +62,7 @@ struct Geom {
 // Output-channel tiles per wave.  The 8x8 layers have only B/2 pixel tiles: splitting N over two workgroups (128
 // channels each) doubles the grid so that two workgroups are resident per CU there as well.
 __host__ __device__ constexpr int conv_nt(int ks, int logw, int outmode) {
-    return ((logw == 3 && ks == 3 && outmode == OUT_NHWC) || outmode == OUT_TOK || outmode == OUT_HEADS) ? 1 : 2;
+    return (logw == 3 && ks == 3 && outmode == OUT_NHWC) ? 1 : 2;
 }
 
 // GELU with the tanh approximation (torch.nn.GELU(approximate="tanh"), the DiT feed-forward: DiT/network.py:176)
@@ -139,7 +141,13 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
     // this wave's packed weights: [cout/32][step][kk][lane][8], two consecutive 32-channel groups
     const size_t wstride = (size_t)nsteps * (KK * 512 * WP);
     // weights through a buffer resource: SGPR offsets, no vector address arithmetic (common.h load_frag_rsrc)
-    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const WT*>(a.wpack) + (size_t)(nblk * (4 * NT) + wave * NT) * wstride);
+    // Token GEMMs (OUT_TOK / OUT_HEADS) take any Cout % 64 == 0: in the last 256-column tile the waves past Cout re-do the last valid
+    // 64 columns (loads stay inside the packed weights) and skip the epilogue.
+    constexpr bool TOKM = (OUTMODE == OUT_TOK || OUTMODE == OUT_HEADS);
+    const int wcol0 = nblk * (128 * NT) + wave * (32 * NT);  // first output column of this wave
+    const bool wactive = !TOKM || wcol0 < a.Cout;
+    const int wgroup = wactive ? nblk * (4 * NT) + wave * NT : a.Cout / 32 - NT;
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const WT*>(a.wpack) + (size_t)wgroup * wstride);
     const int wlane = lane * 8;
     const int wst = (int)wstride;
 
@@ -385,8 +393,9 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
         if (t == 1234.5678f) reinterpret_cast<float*>(a.out)[0] = t;
         return;
     }
-    // which plane of a head-split qkv projection this 128-column tile lies in (planes are multiples of 128 wide)
-    const int hplane = (OUTMODE == OUT_HEADS) ? (nblk * 128) / (a.heads * a.head_dim) : 0;
+    if (!wactive) return;  // (no workgroup barrier below this point)
+    // which plane of a head-split qkv projection this wave's 64 columns lie in (planes are multiples of 64 wide)
+    const int hplane = (OUTMODE == OUT_HEADS) ? wcol0 / (a.heads * a.head_dim) : 0;
     if (OUTMODE == OUT_NHWC || OUTMODE == OUT_TOK || (OUTMODE == OUT_QKV && nblk < 2) || (OUTMODE == OUT_HEADS && hplane < 2)) {
         // NHWC tensor, or the q / k plane of a qkv projection ([B][HW][256]; OUT_HEADS: [B][heads][T][head_dim])
         // Transpose each 32-pixel x 64-channel accumulator slab through this wave's private LDS scratch (the A buffers
@@ -468,7 +477,12 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
                     }
                     if (resid) v += widen4(rcur[j]);
                     v *= a.scale;
-                    const f32x4 vr = store4(out + go, v);  // the values as the consumer will read them
+                    f32x4 vr;  // the values as the consumer will read them
+                    if constexpr (OUTMODE == OUT_HEADS && std::is_same<T, bf16x3>::value) {
+                        vr = store4_split(reinterpret_cast<__bf16*>(out) + go, a.heads_lo_off, v);  // q | k as hi and lo bf16 planes
+                    } else {
+                        vr = store4(out + go, v);
+                    }
                     ssum[im] += (vr[0] + vr[1]) + (vr[2] + vr[3]);
                     ssq[im] += (vr[0] * vr[0] + vr[1] * vr[1]) + (vr[2] * vr[2] + vr[3] * vr[3]);
                 }
@@ -508,9 +522,15 @@ __global__ __launch_bounds__(NTHR, 2) void conv_fused_kernel(const ConvArgs a) {
                     const int y = row0 + ((p >> G::LOGTW) & (G::TH - 1));
                     const int n = n_base + (p >> (G::LOGTW + G::LOGTH));
                     if (n < a.B)
-                        store4(vt + ((size_t)n * (OUTMODE == OUT_HEADS ? a.heads * a.head_dim : 256) + cl) * HWo + y * G::W + x,
-                               f32x4{acc[mt][nt][i4] + bias, acc[mt][nt][i4 + 1] + bias, acc[mt][nt][i4 + 2] + bias,
-                                     acc[mt][nt][i4 + 3] + bias});
+                    {
+                        const size_t vo = ((size_t)n * (OUTMODE == OUT_HEADS ? a.heads * a.head_dim : 256) + cl) * HWo + y * G::W + x;
+                        const f32x4 vv = {acc[mt][nt][i4] + bias, acc[mt][nt][i4 + 1] + bias, acc[mt][nt][i4 + 2] + bias,
+                                          acc[mt][nt][i4 + 3] + bias};
+                        if constexpr (OUTMODE == OUT_HEADS && std::is_same<T, bf16x3>::value)
+                            store4_split(reinterpret_cast<__bf16*>(vt) + vo, a.heads_lo_off, vv);  // v^T as hi and lo bf16 planes
+                        else
+                            store4(vt + vo, vv);
+                    }
                 }
             }
         }
@@ -562,14 +582,18 @@ int launch_one(const ConvArgs& a, hipStream_t stream) {
     const int tiles = (G::IMGS > 1) ? (a.B + G::IMGS - 1) / G::IMGS : a.B * G::TPI;
     const size_t lds = 2 * (size_t)G::ABUF + (ABL ? g_debug_extra_lds : 0);
     auto kern = conv_fused_kernel<T, KS, PRO, RES, LOGW, OUTMODE, ABL>;
-    static bool attr_done = false;  // raise the dynamic-LDS cap once per instantiation (never inside stream capture)
-    if (!attr_done || (ABL && g_debug_extra_lds)) {
+    // raise the dynamic-LDS cap once per instantiation and device (never inside stream capture: conv_prepare_all does it up front)
+    static bool attr_done[16] = {};
+    const int dev = fg_device_slot();
+    if (dev < 0) return (int)hipErrorInvalidDevice;
+    if (!attr_done[dev] || (ABL && g_debug_extra_lds)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[dev] = true;
     }
     if (g_prepare_only) return 0;
-    dim3 grid(tiles, a.Cout / (128 * conv_nt(KS, LOGW, OUTMODE)));
+    constexpr int NCOL = 128 * conv_nt(KS, LOGW, OUTMODE);
+    dim3 grid(tiles, (a.Cout + NCOL - 1) / NCOL);  // exact for the convolutions (Cout % 256 == 0); token GEMMs round up
     hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, stream, a);
     return (int)hipGetLastError();
 }
@@ -641,8 +665,8 @@ int launch_conv_fused(int dtype, int ks, int pro, int res, int outmode, const Co
     const int kc = dtype == 1 ? DT<__bf16>::KC : DT<float>::KC;  // 32 for fp32 and bf16x3
     if (a.H != a.W || (a.W != 8 && a.W != 16 && a.W != 32)) return (int)hipErrorInvalidValue;
     const bool tok = outmode == OUT_TOK || outmode == OUT_HEADS;
-    if ((a.C1 % kc) || (a.C2 % kc) || (a.Cout % (tok ? 128 : 256)) || a.B <= 0) return (int)hipErrorInvalidValue;
-    if (outmode == OUT_HEADS && (a.heads <= 0 || (a.head_dim % 4) || a.Cout != 3 * a.heads * a.head_dim || ((a.heads * a.head_dim) % 128) ||
+    if ((a.C1 % kc) || (a.C2 % kc) || (a.Cout % (tok ? 64 : 256)) || a.B <= 0) return (int)hipErrorInvalidValue;
+    if (outmode == OUT_HEADS && (a.heads <= 0 || (a.head_dim % 4) || a.Cout != 3 * a.heads * a.head_dim || ((a.heads * a.head_dim) % 64) ||
                                  !a.q_out || !a.k_out || !a.vt_out))
         return (int)hipErrorInvalidValue;
     if (res == RES_NONE && (a.Hs != a.H || a.Ws != a.W)) return (int)hipErrorInvalidValue;

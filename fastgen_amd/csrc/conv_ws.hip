@@ -404,28 +404,29 @@ __global__ void pack_conv_weights_ws_kernel(const float* __restrict__ w, __bf16*
     }
 }
 
-int g_ws_cus = 0;
+int g_ws_cus[16] = {};  // CU count per device
 
 template <int RES, int LOGW, int ABL = 0, int NQ = 4, int PRO = PRO_GN_SILU>
 int launch_ws_one(const ConvArgs& a, hipStream_t stream, bool prepare_only) {
     using G = WsGeom<LOGW>;
     auto kern = conv3_ws_kernel<RES, LOGW, ABL, NQ, PRO>;
     const size_t lds = ws_lds_bytes();
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[16] = {};
+    const int dev = fg_device_slot();
+    if (dev < 0) return (int)hipErrorInvalidDevice;
+    if (!attr_done[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[dev] = true;
     }
-    if (!g_ws_cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            return (int)hipErrorUnknown;
-        g_ws_cus = n;
+    if (!g_ws_cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return (int)hipErrorUnknown;
+        g_ws_cus[dev] = n;
     }
     if (prepare_only) return 0;
     const int ntiles = a.B * G::TPI;
-    const int grid = ntiles < g_ws_cus ? ntiles : g_ws_cus;
+    const int grid = ntiles < g_ws_cus[dev] ? ntiles : g_ws_cus[dev];
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WS_NTHR), lds, stream, a, ntiles);
     return (int)hipGetLastError();
 }

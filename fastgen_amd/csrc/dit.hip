@@ -239,10 +239,35 @@ __device__ __forceinline__ Frag8<T> dload_v(const typename DT<T>::ST* row, int k
     }
 }
 
+// bf16x3: q, k, v^T arrive as hi and lo bf16 planes (the qkv projection's epilogue wrote them split: conv.hip store4_split)
+struct QKVPlanes {
+    size_t lo_off;  // elements from a hi plane to its lo plane
+};
+__device__ __forceinline__ Frag8<bf16x3> dload_planes(const __bf16* p, size_t lo_off, bool valid) {
+    Frag8<bf16x3> f;
+    f.hi = f.lo = bf16x8{};
+    if (valid) {
+        f.hi = *reinterpret_cast<const bf16x8*>(p);
+        f.lo = *reinterpret_cast<const bf16x8*>(p + lo_off);
+    }
+    return f;
+}
+__device__ __forceinline__ Frag8<bf16x3> dload_v_planes(const __bf16* row, size_t lo_off, int key0) {
+    Frag8<bf16x3> f;
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(row + key0), b = *reinterpret_cast<const bf16x4*>(row + key0 + 8);
+    const bf16x4 c = *reinterpret_cast<const bf16x4*>(row + lo_off + key0), d = *reinterpret_cast<const bf16x4*>(row + lo_off + key0 + 8);
+    f.hi = bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    f.lo = bf16x8{c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]};
+    return f;
+}
+
+// QT: element type of q / k / v^T as stored (bf16x3: __bf16 planes; otherwise the storage type)
 template <typename T, int HD>
-__global__ __launch_bounds__(256) void dit_attention_kernel(const typename DT<T>::ST* __restrict__ q, const typename DT<T>::ST* __restrict__ k,
-                                                            const typename DT<T>::ST* __restrict__ vt, typename DT<T>::ST* __restrict__ out,
-                                                            int BH, int heads) {
+__global__ __launch_bounds__(256) void dit_attention_kernel(const typename DT<T>::WT* __restrict__ q, const typename DT<T>::WT* __restrict__ k,
+                                                            const typename DT<T>::WT* __restrict__ vt, typename DT<T>::ST* __restrict__ out,
+                                                            int BH, int heads, size_t lo_off) {
+    typedef typename DT<T>::WT QT;
+    constexpr bool X3 = std::is_same<T, bf16x3>::value;
     constexpr int Tn = 256, NT = Tn / 32;
     constexpr int KS = (HD + 15) / 16;  // 16-deep steps of the q k^T contraction
     constexpr int DT_ = (HD + 31) / 32;  // 32-wide tiles of the output dims
@@ -254,8 +279,8 @@ __global__ __launch_bounds__(256) void dit_attention_kernel(const typename DT<T>
     if (bh >= BH) return;  // wave-uniform
     const int n = bh / heads, hh = bh - n * heads;
 
-    const typename DT<T>::ST* qrow = q + ((size_t)bh * Tn + q0 + r) * HD + 8 * h;
-    const typename DT<T>::ST* kbase = k + ((size_t)bh * Tn + r) * HD + 8 * h;
+    const QT* qrow = q + ((size_t)bh * Tn + q0 + r) * HD + 8 * h;
+    const QT* kbase = k + ((size_t)bh * Tn + r) * HD + 8 * h;
     f32x16 st[NT];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
@@ -264,10 +289,14 @@ __global__ __launch_bounds__(256) void dit_attention_kernel(const typename DT<T>
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
         const bool valid = kk * 16 + 8 * h < HD;  // HD % 8 == 0: an 8-element fragment is valid or past the end as a whole
-        const Frag8<T> qf = dload<T>(qrow + kk * 16, valid);
+        Frag8<T> qf;
+        if constexpr (X3) qf = dload_planes(qrow + kk * 16, lo_off, valid);
+        else qf = dload<T>(qrow + kk * 16, valid);
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
-            const Frag8<T> kf = dload<T>(kbase + (size_t)kt * 32 * HD + kk * 16, valid);
+            Frag8<T> kf;
+            if constexpr (X3) kf = dload_planes(kbase + (size_t)kt * 32 * HD + kk * 16, lo_off, valid);
+            else kf = dload<T>(kbase + (size_t)kt * 32 * HD + kk * 16, valid);
             mma16(st[kt], kf, qf);
         }
     }
@@ -298,7 +327,7 @@ __global__ __launch_bounds__(256) void dit_attention_kernel(const typename DT<T>
 
     // O[query][dim] = sum_key P[query][key] V[key][dim]
     typedef typename DT<T>::ST ST;
-    const ST* vbase = vt + ((size_t)bh * HD + r) * Tn + 4 * h;
+    const QT* vbase = vt + ((size_t)bh * HD + r) * Tn + 4 * h;
     ST* obase = out + ((size_t)n * Tn + q0) * (heads * HD) + hh * HD + r;
     f32x16 o[DT_];
 #pragma unroll
@@ -311,7 +340,12 @@ __global__ __launch_bounds__(256) void dit_attention_kernel(const typename DT<T>
         for (int s = 0; s < 2; ++s) {
             const Frag8<T> pf = DPFrag<T>::make(st[kt], s);
 #pragma unroll
-            for (int d = 0; d < DT_; ++d) mma16(o[d], pf, dload_v<T>(vbase + (size_t)(d * 32) * Tn, kt * 32 + 16 * s));
+            for (int d = 0; d < DT_; ++d) {
+                Frag8<T> vf;
+                if constexpr (X3) vf = dload_v_planes(vbase + (size_t)(d * 32) * Tn, lo_off, kt * 32 + 16 * s);
+                else vf = dload_v<T>(vbase + (size_t)(d * 32) * Tn, kt * 32 + 16 * s);
+                mma16(o[d], pf, vf);
+            }
         }
 #pragma unroll
     for (int d = 0; d < DT_; ++d)
@@ -381,11 +415,12 @@ int launch_dit_cond(const float* t_emb, const float* r_emb, const float* table, 
     DIT_RET();
 }
 // mode: FG_DTYPE_* (0 exact fp32, 1 bf16, 2 split-bf16 on fp32 tensors).  256 tokens; head_dim 64 or 72.
-int launch_dit_attention(int mode, const void* q, const void* k, const void* vt, void* out, int B, int heads, int head_dim, hipStream_t s) {
+int launch_dit_attention(int mode, const void* q, const void* k, const void* vt, void* out, int B, int heads, int head_dim, size_t lo_off,
+                         hipStream_t s) {
     const int BH = B * heads;
     dim3 g((BH * 8 + 3) / 4), b(256);
-#define DIT_ATT(TT, HD) hipLaunchKernelGGL((dit_attention_kernel<TT, HD>), g, b, 0, s, (const typename DT<TT>::ST*)q, (const typename DT<TT>::ST*)k, \
-                                           (const typename DT<TT>::ST*)vt, (typename DT<TT>::ST*)out, BH, heads)
+#define DIT_ATT(TT, HD) hipLaunchKernelGGL((dit_attention_kernel<TT, HD>), g, b, 0, s, (const typename DT<TT>::WT*)q, (const typename DT<TT>::WT*)k, \
+                                           (const typename DT<TT>::WT*)vt, (typename DT<TT>::ST*)out, BH, heads, lo_off)
     if (head_dim == 72) {
         if (mode == 2) DIT_ATT(bf16x3, 72);
         else if (mode == 1) DIT_ATT(__bf16, 72);

@@ -127,4 +127,6 @@ int launch_dit_patch_embed(int dtype, const float* x, const float* w, const floa
 int launch_dit_fourier(const float* t, float* f, int B, int dim, hipStream_t s);
 int launch_dit_cond(const float* t_emb, const float* r_emb, const float* table, const int64_t* cls, float* c, float* sc, int B, int D,
                     hipStream_t s);
-int launch_dit_attention(int mode, const void* q, const void* k, const void* vt, void* out, int B, int heads, int head_dim, hipStream_t s);
+// mode 2 (bf16x3): q, k, vt are hi / lo bf16 planes, lo_off elements apart (conv.hip OUT_HEADS writes them so); else lo_off unused
+int launch_dit_attention(int mode, const void* q, const void* k, const void* vt, void* out, int B, int heads, int head_dim, size_t lo_off,
+                         hipStream_t s);

@@ -365,6 +365,13 @@ class EDMPrecond(FastGenNetwork):
             if parts[-1] == "weight" and parts[-2] in ("conv0", "skip") and (parts[-3].endswith("_down") or parts[-3].endswith("_up")):
                 node.register_buffer("resample_filter", torch.full((1, 1, 2, 2), 0.25))
         self._engines[_lib.FG_DTYPE_F32] = h
+        # (leaf module, parameter name) of every engine parameter, in engine order (see _engine)
+        self._leafs = []
+        for full in self._param_names:
+            node, parts = self, full.split(".")
+            for p_ in parts[:-1]:
+                node = node._modules[p_]
+            self._leafs.append((node, parts[-1]))
 
     # ------------------------------------------------------------------------------------------------
     def _make_engine(self, dtype: int):
@@ -411,14 +418,18 @@ class EDMPrecond(FastGenNetwork):
         if dt not in self._engines:
             self._engines[dt] = self._make_engine(dt)
         h = self._engines[dt]
-        weights = self._named_weights()
-        for n, p in weights:
-            if hasattr(p, "_local_tensor") or hasattr(p.data, "_local_tensor"):
+        # Is what the engine bound still what the module holds?  One pass over the 421 parameters (storage pointer, in-place
+        # version counter, dtype: any optimizer step, load_state_dict, .to() or FSDP2 all-gather changes one of them), read straight
+        # from the leaf modules' parameter dicts - no named_parameters() generator, no per-call name -> tensor dict.
+        ps = [leaf._parameters[nm] for leaf, nm in self._leafs]
+        for n, p in zip(self._param_names, ps):
+            if hasattr(p, "_local_tensor"):
                 raise RuntimeError(
                     f"parameter {n} is a sharded DTensor: the engine reads whole parameters.  Call the network through "
                     "forward() / jvp() / few_step_sample() / generator_fn(), which all-gather FSDP2 groups around the call")
-        sig = tuple((p.data_ptr(), p._version, p.dtype) for _, p in weights)
+        sig = tuple((p.data_ptr(), p._version, p.dtype) for p in ps)
         if self._bound_sig.get(dt) != sig:
+            weights = list(zip(self._param_names, ps))
             L = _lib.lib()
             refs = []
             for n, p in weights:
