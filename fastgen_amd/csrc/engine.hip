@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <map>
@@ -1235,6 +1236,17 @@ int fg_op_images_to_u8(const float* images, uint8_t* out, int64_t batch, int cha
 }
 int fg_op_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, void* stream) {
     HIP_TRY(launch_randn(out, total, seed, offset, nullptr, (hipStream_t)stream));
+    return FG_OK;
+}
+int fg_op_gemm_bf16(const void* a, const void* w, const float* bias, void* out, int m, int n, int k, int act, const float* gate,
+                    int gate_stride, int gate_rows, const void* resid, int tile_order, void* stream) {
+    GemmArgs g;
+    g.A = a; g.W = w; g.bias = bias; g.out = out; g.M = m; g.N = n; g.K = k; g.act = act;
+    g.gate = gate; g.gate_stride = gate_stride; g.gate_rows = gate_rows > 0 ? gate_rows : 1; g.resid = resid; g.xn = tile_order & 15;
+    g.variant = (tile_order & 16) ? 0 : (tile_order & 32) ? 1 : -1;
+    if (!gemm_bf16_supported(g)) return fail(FG_EINVAL, "fg_op_gemm_bf16: unsupported shape (k %% 64, n %% 16, pointers)");
+    HIP_TRY(launch_gemm_bf16(g, (hipStream_t)stream, true));
+    HIP_TRY(launch_gemm_bf16(g, (hipStream_t)stream));
     return FG_OK;
 }
 

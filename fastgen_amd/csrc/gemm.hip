@@ -1,0 +1,718 @@
+// Token GEMM of the transformer blocks (DiT: fastgen/networks/DiT/network.py:153-201 - qkv, attention.proj, feed_forward.fc1 / fc2;
+// the causal video DiT's block linears take the same kernel), bf16 compute mode: the arithmetic the reference runs these networks
+// in (`precision_amp = "bfloat16"`, configs/experiments/DiT/config_*.py:19-26; Wan: `precision = "bfloat16"`, WanT2V/config_sf.py:19).
+//
+//   out[tok][n] = epilogue( sum_k A[tok][k] W[n][k] + bias[n] )        A: [M][K] bf16 row-major, W: [N][K] bf16 row-major
+//
+// Why not conv_fused_kernel's 1x1 token mode (conv.hip OUT_TOK): that kernel is a convolution kernel - 128 x 128 per 256-thread
+// workgroup, weights streamed L2 -> registers by every wave, one workgroup barrier per 64-deep step of 16 MFMAs per wave; on the
+// DiT-XL shapes it reaches 24 % of the bf16 roof (profiles/r02_dit_*).  A GEMM has no halo and no prologue arithmetic, so both
+// operands can be staged once per workgroup and the tile can be twice as large in both directions:
+//
+//   persistent, one 512-thread workgroup per CU (two waves per SIMD), tile 256 tokens x (64 NT) outputs, NT = 4 | 3
+//   (N % 256 == 0 -> 256 wide; DiT-XL's 1152 / 3456 = 6 / 18 x 192 -> 192 wide), K in steps of 64 through a two-stage LDS ring.
+//   Per step and CU: 32 KiB of A + 32 KiB of W from L2 for 2 x 256 x 256 x 64 FLOP = 74 GB/s per CU at the MFMA roof - a
+//   128 x 256 tile with register-streamed weights would need 112 GB/s against the vector L1's 64 B/clk.
+//   Every wave: 128 tokens x 16 NT outputs = 8 x NT accumulator tiles of v_mfma_f32_16x16x32_bf16, TRANSPOSED (A operand =
+//   weights [16 n x 32 k], B operand = activations [32 k x 16 tokens]) so that a lane ends with 4 CONSECUTIVE outputs of one
+//   token: the epilogue (bias, tanh-GELU, adaLN gate x value + residual, head split) runs on registers and stores 8-byte
+//   pieces, four lanes = one 32-byte run, the NT tiles of a wave back to back = 128 contiguous bytes per token.
+//   LDS image of a stage: 8 planes per operand (plane o = k-octet o of the step: [row][8 bf16 = 16 B]), planes 16 B more than
+//   a multiple of 256 B apart: a fragment read (16 consecutive rows of one plane) is one contiguous 256-byte run, and the
+//   staging store of a quarter wave (8 octets of one row, the coalesced 128-byte global read) lands on 8 different bank groups.
+//   LDS reads: (8 + NT) KiB per wave and 32-deep half step = 96 B/clk/CU at the MFMA roof, of 256.
+//
+// Tile order: workgroup b sits on XCD b % 8.  The 8 XCDs are arranged xm x xn over (token tiles, output tiles); inside its
+// rectangle an XCD walks output tiles fastest, so its 32 workgroups share the A rows they read at about the same time (one
+// HBM / MALL fetch per XCD) and its slice of W (N K 2 / xn bytes) stays in its 4 MiB L2.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+#include "misc.h"
+
+namespace {
+
+constexpr int GM_NTHR = 512;
+constexpr int GM_TM = 256;   // tokens per tile
+constexpr int GM_KC = 64;    // k per pipeline step
+constexpr int GM_PA = GM_TM * 16 + 16;  // bytes between the octet planes of the A image
+
+__device__ __forceinline__ void gm_barrier() {
+    // this wave's LDS traffic retired, then the workgroup barrier; vmcnt is NOT drained (epilogue stores stay in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ float gm_gelu_tanh(float x) {
+    // torch.nn.GELU(approximate="tanh") (DiT/network.py:176); tanh(u) = 1 - 2 / (1 + e^{2u}) on v_exp / v_rcp (bf16 mode)
+    const float u = 0.7978845608028654f * fmaf(0.044715f * x, x * x, x);
+    const float e = __builtin_amdgcn_exp2f(2.0f * 1.44269504088896341f * u);
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+    return 0.5f * x * (1.0f + t);
+}
+
+enum { GM_EPI_TOK = 0, GM_EPI_HEADS = 1 };
+
+template <int NT, int EPI>
+__global__ __launch_bounds__(GM_NTHR) void gemm_bf16_kernel(const GemmArgs a) {
+    constexpr int TN = 64 * NT;             // outputs per tile
+    constexpr int PW = TN * 16 + 16;        // bytes between the octet planes of the W image
+    constexpr int STAGE = 8 * (GM_PA + PW);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;  // token half, output quarter of the tile
+    const int col = lane & 15, g = lane >> 4;
+
+    // ---- this workgroup's tiles -------------------------------------------------------------------------------------
+    const int Mt = (a.M + GM_TM - 1) / GM_TM, Nt = (a.N + TN - 1) / TN;
+    int mlo = 0, nlo = 0, nx = Nt, first, stride, count;
+    if ((gridDim.x & 7) == 0 && a.xn > 0) {
+        const int x = (int)blockIdx.x & 7, xm = 8 / a.xn, xi = x / a.xn, xj = x - xi * a.xn;
+        mlo = (int)((long long)xi * Mt / xm);
+        const int mhi = (int)((long long)(xi + 1) * Mt / xm);
+        nlo = xj * Nt / a.xn;
+        nx = (xj + 1) * Nt / a.xn - nlo;
+        first = (int)blockIdx.x >> 3;
+        stride = (int)gridDim.x >> 3;
+        count = (mhi - mlo) * nx;
+    } else {
+        first = (int)blockIdx.x;
+        stride = (int)gridDim.x;
+        count = Mt * Nt;
+    }
+    const int my_tiles = first < count ? (count - first + stride - 1) / stride : 0;
+    if (my_tiles == 0) return;
+    auto tile_origin = [&](int i, int& m0, int& n0) {
+        const int lt = first + i * stride;
+        const int q = lt / nx;
+        m0 = (mlo + q) * GM_TM;
+        n0 = (nlo + (lt - q * nx)) * TN;
+    };
+    const int nk = a.K / GM_KC;
+    const int S = my_tiles * nk;
+
+    // ---- staging: thread -> (row tid >> 3 + 64 i, octet tid & 7) of both operand tiles ------------------------------
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.A), rsW = make_rsrc(a.W);
+    const int srow = tid >> 3, soct = tid & 7;
+    const int ldsA = soct * GM_PA + srow * 16;
+    const int ldsW = 8 * GM_PA + soct * PW + srow * 16;
+    unsigned offA[4], offW[NT];
+    fg_u32x4 pa[4], pw[NT];
+    auto setup = [&](int i) {
+        int m0, n0;
+        tile_origin(i, m0, n0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) offA[j] = (unsigned)min(m0 + srow + 64 * j, a.M - 1) * (unsigned)(a.K * 2) + soct * 16;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) offW[j] = (unsigned)min(n0 + srow + 64 * j, a.N - 1) * (unsigned)(a.K * 2) + soct * 16;
+    };
+    auto issue = [&](int kidx) {
+        const int so = kidx * (GM_KC * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, offA[j], so, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) pw[j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, offW[j], so, 0);
+    };
+    auto park = [&](char* st) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<fg_u32x4*>(st + ldsA + j * 1024) = pa[j];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) *reinterpret_cast<fg_u32x4*>(st + ldsW + j * 1024) = pw[j];
+    };
+
+    // ---- fragments ----------------------------------------------------------------------------------------------------
+    const int fA = g * GM_PA + (wm * 128 + col) * 16;                 // + 4 j PA + m 256
+    const int fW = 8 * GM_PA + g * PW + (wn * 16 * NT + col) * 16;    // + 4 j PW + nt 256
+    f32x4 acc[8][NT];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](const char* st) {
+        bf16x8 x0[4], x1[4], w0[NT], w1[NT];
+        auto read_x = [&](int j, int half, bf16x8 (&x)[4]) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) x[m] = *reinterpret_cast<const bf16x8*>(st + fA + 4 * j * GM_PA + (half * 4 + m) * 256);
+        };
+        auto read_w = [&](int j, bf16x8 (&w)[NT]) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) w[nt] = *reinterpret_cast<const bf16x8*>(st + fW + 4 * j * PW + nt * 256);
+        };
+        auto mma = [&](int half, const bf16x8 (&x)[4], const bf16x8 (&w)[NT]) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[half * 4 + m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt], x[m], acc[half * 4 + m][nt], 0, 0, 0);
+        };
+        read_w(0, w0);
+        read_x(0, 0, x0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_x(0, 1, x1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, x0, w0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_w(1, w1);
+        read_x(1, 0, x0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, x1, w0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_x(1, 1, x1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, x0, w1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, x1, w1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- epilogue of one finished tile: registers -> global -----------------------------------------------------------
+    auto epilogue = [&](int i) {
+        int m0, n0;
+        tile_origin(i, m0, n0);
+        const int c0 = n0 + wn * 16 * NT + 4 * g;  // + 16 nt: this lane's 4 consecutive outputs
+        f32x4 b4[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            b4[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.bias && c0 + 16 * nt < a.N) b4[nt] = *reinterpret_cast<const f32x4*>(a.bias + c0 + 16 * nt);
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int row = m0 + wm * 128 + m * 16 + col;
+            if (row < a.M) {
+                if constexpr (EPI == GM_EPI_TOK) {
+                    __bf16* orow = reinterpret_cast<__bf16*>(a.out) + (size_t)row * a.N;
+                    const __bf16* rrow = reinterpret_cast<const __bf16*>(a.resid) + (size_t)row * a.N;
+                    const float* grow = a.gate ? a.gate + (size_t)((a.row0 + row) / a.gate_rows) * a.gate_stride : nullptr;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int c = c0 + 16 * nt;
+                        if (c < a.N) {
+                            f32x4 v = acc[m][nt] + b4[nt];
+                            if (a.act == 1) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = gm_gelu_tanh(v[e]);
+                            }
+                            if (grow) v *= *reinterpret_cast<const f32x4*>(grow + c);
+                            if (a.resid) v += load4(rrow + c);
+                            store4(orow + c, v);
+                        }
+                    }
+                } else {
+                    // head-split q | k [B][H][T][hd], v^T [B][H][hd][T] (the operand layouts of dit_attention_kernel)
+                    const int D = a.heads * a.head_dim;
+                    const int b = (a.row0 + row) / a.T, t = a.row0 + row - b * a.T;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int c = c0 + 16 * nt;
+                        if (c < a.N) {
+                            const f32x4 v = acc[m][nt] + b4[nt];
+                            const int plane = c / D, within = c - plane * D;
+                            const int hh = within / a.head_dim, d = within - hh * a.head_dim;
+                            const size_t bh = (size_t)b * a.heads + hh;
+                            if (plane < 2) {
+                                store4(reinterpret_cast<__bf16*>(plane ? a.k : a.q) + (bh * a.T + t) * a.head_dim + d, v);
+                            } else {
+                                __bf16* vp = reinterpret_cast<__bf16*>(a.vt) + (bh * a.head_dim + d) * a.T + t;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) vp[(size_t)e * a.T] = (__bf16)v[e];
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    // ---- step machine: during step s every thread (1) issues the global loads of step s + 1, (2) computes step s out of stage
+    // s & 1, (3) after a tile's last step stores the tile, (4) parks step s + 1 in stage (s + 1) & 1; one barrier per step --------
+    int ti = 0, kk = 0;   // tile / k-step being computed
+    int tn = 0, kn = 0;   // ... being staged
+    setup(0);
+    issue(0);
+    park(smem);
+    if (++kn == nk) kn = 0, ++tn;
+    gm_barrier();
+    for (int s = 0; s < S; ++s) {
+        // (the step behind the last one is staged too, from clamped - valid - addresses into the stage nobody reads any more:
+        // unconditional loads let the compiler count them, a conditional issue makes it drain vmcnt before every step's LDS reads)
+        if (kn == 0) setup(tn);
+        issue(kn);
+        compute(smem + (s & 1) * STAGE);
+        if (kk + 1 == nk) epilogue(ti);
+        park(smem + ((s + 1) & 1) * STAGE);
+        if (++kn == nk) kn = 0, ++tn;
+        if (++kk == nk) kk = 0, ++ti;
+        gm_barrier();
+    }
+}
+
+// ---- the 8-wave ping-pong schedule ----------------------------------------------------------------------------------------
+// Same tile (256 tokens x 256 outputs, 8 waves = 2 token halves x 4 output quarters, 128 x 64 per wave) and the same register
+// epilogue, but (1) the operand tiles go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR round trip, no
+// ds_write - the kernel above spends 830 of every 2048 cycles of LDS time on its 64 KiB of ds_write_b128 per step), and (2) the
+// two waves of a SIMD alternate: the K-step of 64 is cut into four phases of 16 MFMAs (one 64 x 32 quadrant of the wave's
+// outputs), every phase = {memory part: ds_read the fragments a later phase needs + issue one half-tile of DMA + counted
+// vmcnt; barrier; compute part: 16 MFMAs; barrier}, and waves 4-7 run one barrier behind waves 0-3 - at any time one wave of
+// each SIMD is in its MFMA block while its partner is in its memory part (MI355X_MICROARCH.md, two waves per SIMD: the matrix
+// pipe is per-SIMD and paced; a partner's LDS / DMA segment costs the computing wave 40-50 cycles).
+// LDS: 2 buffers x {A rows 0-127, A rows 128-255, W rows 0-127, W rows 128-255} x 16 KiB, each half-tile row-major [128][64 k]
+// with the 16-byte k-octets of row r XOR-ed by (r >> 1) & 7 - applied on the DMA's per-lane SOURCE address (the LDS destination
+// of one wave-instruction is 1 KiB contiguous) and on the fragment read: the 16 lanes of a ds_read_b128 lane group then cover
+// all 64 banks.
+// Half-tile schedule (t = flat K-step index, d = 2 phases between a DMA's issue and the counted wait that retires it, so a
+// half-tile issued in phase p is readable from p + 3; a region is re-issued at the earliest one phase after its last read,
+// whose lgkmcnt(0) sits before that phase's barrier):
+//   phase 0: read W(t) quarters nt 0,1    issue A rows 128-255 of t+1     phase 2: read X(t) m 4-7     issue W rows 0-127 of t+2
+//   phase 1: read W(t) quarters nt 2,3    issue W rows 128-255 of t+1     phase 3: read X(t+1) m 0-3   issue A rows 0-127 of t+2
+// Fragment reads are inline asm: hipcc orders every compiler-visible LDS read behind ALL pending LDS-DMA (vmcnt(0)), which
+// would serialise the pipeline; the waits here are counted by hand (vmcnt(4) = two half-tiles in flight).
+// Ragged edges: the last token tile / output tile is shifted back to end at M / N (rows recomputed by two tiles store the same
+// values), so M, N >= 256 and out must not alias resid.
+#define GM_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+template <int EPI>
+__global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a) {
+    constexpr int TN = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;  // token half (= ping-pong group), output quarter
+    const int col = lane & 15, g = lane >> 4;
+
+    // ---- this workgroup's tiles (as gemm_bf16_kernel) ----------------------------------------------------------------
+    const int Mt = (a.M + GM_TM - 1) / GM_TM, Nt = (a.N + TN - 1) / TN;
+    int mlo = 0, nlo = 0, nx = Nt, first, stride, count;
+    if ((gridDim.x & 7) == 0 && a.xn > 0) {
+        const int x = (int)blockIdx.x & 7, xm = 8 / a.xn, xi = x / a.xn, xj = x - xi * a.xn;
+        mlo = (int)((long long)xi * Mt / xm);
+        const int mhi = (int)((long long)(xi + 1) * Mt / xm);
+        nlo = xj * Nt / a.xn;
+        nx = (xj + 1) * Nt / a.xn - nlo;
+        first = (int)blockIdx.x >> 3;
+        stride = (int)gridDim.x >> 3;
+        count = (mhi - mlo) * nx;
+    } else {
+        first = (int)blockIdx.x;
+        stride = (int)gridDim.x;
+        count = Mt * Nt;
+    }
+    const int my_tiles = first < count ? (count - first + stride - 1) / stride : 0;
+    if (my_tiles == 0) return;
+    auto tile_origin = [&](int i, int& m0, int& n0) {
+        const int lt = first + min(i, my_tiles - 1) * stride;  // (cursors running past the end re-read the last tile)
+        const int q = lt / nx;
+        m0 = min((mlo + q) * GM_TM, a.M - GM_TM);
+        n0 = min((nlo + (lt - q * nx)) * TN, a.N - TN);
+    };
+    const int nk = a.K / GM_KC;
+    const int S = my_tiles * nk;
+    const int K2 = a.K * 2;
+    // ---- DMA: wave w moves the 8-row groups 2 w, 2 w + 1 of every half-tile; lane -> (row lane >> 3 of the group, LDS octet
+    // position lane & 7, which holds k-octet position ^ ((row >> 1) & 7)) ------------------------------------------------
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.A), rsW = make_rsrc(a.W);
+    unsigned voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 8 + (lane >> 3);
+        voff[j] = (unsigned)row * (unsigned)K2 + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    }
+    // regions of buffer b: A half h at b * 65536 + h * 16384, W half h at b * 65536 + 32768 + h * 16384
+    auto dma = [&](const __amdgpu_buffer_rsrc_t& rs, int region, int soff) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(smem + region + (wave * 2 + j) * 1024), 16, voff[j], soff, 0, 0);
+    };
+    // cursors over the flat K-steps t + 1 and t + 2: scalar byte offsets of their A / W tiles' first row at their k
+    struct Cur {
+        int ti, kk, sa, sw;
+    };
+    auto cur_set = [&](Cur& c) {
+        int m0, n0;
+        tile_origin(c.ti, m0, n0);
+        c.sa = (m0 * a.K + c.kk * GM_KC) * 2;
+        c.sw = (n0 * a.K + c.kk * GM_KC) * 2;
+    };
+    auto cur_next = [&](Cur& c) {
+        if (++c.kk == nk) c.kk = 0, ++c.ti;
+        cur_set(c);
+    };
+
+    // ---- fragments ----------------------------------------------------------------------------------------------------
+    const int lrow0 = col * 128 + ((g ^ ((col >> 1) & 7)) * 16), lrow1 = lrow0 ^ 64;   // k-substep 0 / 1
+    const int fxa = wr * 16384;                                  // this wave's A half
+    const int fwb = 32768 + (wc >> 1) * 16384 + (wc & 1) * 8192;  // this wave's 64 W rows
+    bf16x8 X0[4][2], X1[4][2], W0[2][2], W1[2][2];  // [m | nt][k-substep]
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto read_x = [&](bf16x8 (&x)[4][2], int buf, int mh) {
+        const int a0 = buf * 65536 + fxa + lrow0, a1 = buf * 65536 + fxa + lrow1;
+        if (mh == 0) {
+            GM_DSR(x[0][0], a0, 0); GM_DSR(x[0][1], a1, 0); GM_DSR(x[1][0], a0, 2048); GM_DSR(x[1][1], a1, 2048);
+            GM_DSR(x[2][0], a0, 4096); GM_DSR(x[2][1], a1, 4096); GM_DSR(x[3][0], a0, 6144); GM_DSR(x[3][1], a1, 6144);
+        } else {
+            GM_DSR(x[0][0], a0, 8192); GM_DSR(x[0][1], a1, 8192); GM_DSR(x[1][0], a0, 10240); GM_DSR(x[1][1], a1, 10240);
+            GM_DSR(x[2][0], a0, 12288); GM_DSR(x[2][1], a1, 12288); GM_DSR(x[3][0], a0, 14336); GM_DSR(x[3][1], a1, 14336);
+        }
+    };
+    auto read_w = [&](bf16x8 (&w)[2][2], int buf, int nh) {
+        const int a0 = buf * 65536 + fwb + lrow0, a1 = buf * 65536 + fwb + lrow1;
+        if (nh == 0) {
+            GM_DSR(w[0][0], a0, 0); GM_DSR(w[0][1], a1, 0); GM_DSR(w[1][0], a0, 2048); GM_DSR(w[1][1], a1, 2048);
+        } else {
+            GM_DSR(w[0][0], a0, 4096); GM_DSR(w[0][1], a1, 4096); GM_DSR(w[1][0], a0, 6144); GM_DSR(w[1][1], a1, 6144);
+        }
+    };
+    auto mma = [&](int mh, int nh, const bf16x8 (&x)[4][2], const bf16x8 (&w)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mh * 4 + m][nh * 2 + nt] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt][j], x[m][j], acc[mh * 4 + m][nh * 2 + nt], 0, 0, 0);
+    };
+    // end of a memory part: two half-tiles of DMA (4 instructions) may stay in flight, this wave's LDS reads have landed; then
+    // the hand-over barrier.  (vmcnt retires in issue order, stores included: behind an epilogue the first such wait also waits
+    // for the tile's stores.)
+    auto mem_done = [&]() {
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto cmp_done = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+    };
+
+    // ---- epilogue of one 64-token x 32-output quadrant (MH, NH) of this wave, on registers.  v_permlane16_swap exchanges the
+    // odd-numbered output quads of the even 16-lane rows with the even-numbered quads of the odd rows: a lane then holds 8
+    // CONSECUTIVE outputs of its token (n0 + 64 wc + 32 NH + 16 (g & 1) + 8 (g >> 1)): one 16-byte store, four lanes = one
+    // 64-byte run.  be / bo: this lane's bias quads for the even / odd quad of the pair (loaded a K-step earlier: a load waited
+    // for here would wait for the DMA in flight as well).
+    // Measured and rejected (profiles/r02_gemm_*): the quadrants leaving one by one in the memory parts of the next four phases
+    // (stores spread over a K-step, vmcnt budgets widened by the stores in flight: -7 %), and start offsets between XCDs or
+    // between the token-tile groups of an XCD (-3...-8 %).  What the epilogue costs is measured with act bits 4 / 8: at K = 1152
+    // the K-loop alone runs at 1450-1530 TFLOP/s, the epilogue arithmetic takes it to 1210, the stores (HBM write rate, exposed
+    // by the in-order vmcnt) to 900-980.
+    auto slice = [&](auto MH_, auto NH_, int tile, f32x4 be, f32x4 bo) {
+        constexpr int MH = decltype(MH_)::value, NH = decltype(NH_)::value;
+        if (a.act & 8) {  // (timing experiments: no epilogue at all)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                asm volatile("" ::"v"(acc[MH * 4 + m][NH * 2]), "v"(acc[MH * 4 + m][NH * 2 + 1]));
+                acc[MH * 4 + m][NH * 2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[MH * 4 + m][NH * 2 + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            return;
+        }
+        int m0, n0;
+        tile_origin(tile, m0, n0);
+        const int c8 = n0 + wc * 64 + 32 * NH + 16 * (g & 1) + 8 * (g >> 1);      // after the swap: 8 consecutive outputs
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int row = m0 + wr * 128 + (MH * 4 + m) * 16 + col;
+            f32x4 ve = acc[MH * 4 + m][NH * 2] + be, vo = acc[MH * 4 + m][NH * 2 + 1] + bo;
+            acc[MH * 4 + m][NH * 2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[MH * 4 + m][NH * 2 + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (EPI == GM_EPI_TOK && (a.act & 1)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ve[e] = gm_gelu_tanh(ve[e]), vo[e] = gm_gelu_tanh(vo[e]);
+            }
+            {
+                // (inline asm: this hipcc's __builtin_amdgcn_permlane16_swap loses the SECOND result - it copies the first over it -
+                // once the call sits in a larger body; scripts/micro/permlane16_swap_map.hip checks the instruction itself.  The
+                // s_nops cover the VALU -> swap -> VALU wait states the compiler would otherwise insert.)
+                float e0 = ve[0], e1 = ve[1], e2 = ve[2], e3 = ve[3], o0 = vo[0], o1 = vo[1], o2 = vo[2], o3 = vo[3];
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %6\n\t"
+                             "v_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                             : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));
+                ve = f32x4{e0, e1, e2, e3};
+                vo = f32x4{o0, o1, o2, o3};
+            }
+            if constexpr (EPI == GM_EPI_TOK) {
+                if (a.gate) {
+                    const float* grow = a.gate + (size_t)((a.row0 + row) / a.gate_rows) * a.gate_stride + c8;
+                    ve *= *reinterpret_cast<const f32x4*>(grow);
+                    vo *= *reinterpret_cast<const f32x4*>(grow + 4);
+                }
+                if (a.resid) {
+                    const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.resid) + (size_t)row * a.N + c8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ve[e] += (float)r8[e], vo[e] += (float)r8[4 + e];
+                }
+                bf16x8 o8;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o8[e] = (__bf16)ve[e], o8[4 + e] = (__bf16)vo[e];
+                if (a.act & 4) asm volatile("" ::"v"(o8));  // (timing experiments: everything but the store)
+                else *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(a.out) + (size_t)row * a.N + c8) = o8;
+            } else {
+                const int D = a.heads * a.head_dim;  // % 8 == 0: the 8 outputs lie in one plane and one head
+                const int b = (a.row0 + row) / a.T, t = a.row0 + row - b * a.T;
+                const int plane = c8 / D, within = c8 - plane * D;
+                const int hh = within / a.head_dim, d = within - hh * a.head_dim;
+                const size_t bh = (size_t)b * a.heads + hh;
+                if (plane < 2) {
+                    bf16x8 o8;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o8[e] = (__bf16)ve[e], o8[4 + e] = (__bf16)vo[e];
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(plane ? a.k : a.q) + (bh * a.T + t) * a.head_dim + d) = o8;
+                } else {
+                    __bf16* vp = reinterpret_cast<__bf16*>(a.vt) + (bh * a.head_dim + d) * a.T + t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vp[(size_t)e * a.T] = (__bf16)ve[e], vp[(size_t)(4 + e) * a.T] = (__bf16)vo[e];
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+
+    // ---- prologue: K-step 0 whole, the two early half-tiles of K-step 1 ------------------------------------------------
+    Cur c1{0, 0, 0, 0}, c2{0, 0, 0, 0};
+    cur_set(c1);                 // = K-step 0 for now
+    dma(rsA, 0, c1.sa);
+    dma(rsA, 16384, c1.sa + 128 * K2);
+    dma(rsW, 32768, c1.sw);
+    dma(rsW, 49152, c1.sw + 128 * K2);
+    if (S > 1) cur_next(c1);     // K-step 1
+    dma(rsW, 65536 + 32768, c1.sw);
+    dma(rsA, 65536, c1.sa);
+    c2 = c1;
+    if (S > 2) cur_next(c2);     // K-step 2
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    read_x(X0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) asm volatile("s_barrier" ::: "memory");  // the second group runs one barrier behind
+
+    // one K-step = four phases
+    auto kstep = [&](int t) {
+        const int cb = t & 1, nb = cb ^ 1;
+        // phase 0: quadrant (0,0)
+        read_w(W0, cb, 0);
+        dma(rsA, nb * 65536 + 16384, c1.sa + 128 * K2);
+        mem_done();
+        __builtin_amdgcn_s_setprio(1);
+        mma(0, 0, X0, W0);
+        __builtin_amdgcn_s_setprio(0);
+        cmp_done();
+        // phase 1: quadrant (0,1)
+        read_w(W1, cb, 1);
+        dma(rsW, nb * 65536 + 49152, c1.sw + 128 * K2);
+        mem_done();
+        __builtin_amdgcn_s_setprio(1);
+        mma(0, 1, X0, W1);
+        __builtin_amdgcn_s_setprio(0);
+        cmp_done();
+        // phase 2: quadrant (1,1)
+        read_x(X1, cb, 1);
+        dma(rsW, cb * 65536 + 32768, c2.sw);
+        mem_done();
+        __builtin_amdgcn_s_setprio(1);
+        mma(1, 1, X1, W1);
+        __builtin_amdgcn_s_setprio(0);
+        cmp_done();
+        // phase 3: quadrant (1,0)
+        read_x(X0, nb, 0);
+        dma(rsA, cb * 65536, c2.sa);
+        mem_done();
+        __builtin_amdgcn_s_setprio(1);
+        mma(1, 0, X1, W0);
+        __builtin_amdgcn_s_setprio(0);
+        cmp_done();
+    };
+    // (the loop nest keeps the K-steps inside a tile - the hot loop - a loop of its own for the register allocator)
+    int t = 0;
+    auto advance = [&]() {
+        c1 = c2;
+        if (t + 3 < S) cur_next(c2);
+        ++t;
+    };
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        for (int kk = 0; kk + 1 < nk; ++kk) {
+            kstep(t);
+            advance();
+        }
+        // the tile's bias, one K-step ahead of its use: this lane's quads of the four output pairs (own layout, before the swap)
+        f32x4 b00 = {0.f, 0.f, 0.f, 0.f}, b01 = b00, b10 = b00, b11 = b00;
+        if (a.bias) {
+            int m0, n0;
+            tile_origin(ti, m0, n0);
+            const float* bp = a.bias + n0 + wc * 64 + 4 * g;
+            b00 = *reinterpret_cast<const f32x4*>(bp);
+            b01 = *reinterpret_cast<const f32x4*>(bp + 16);
+            b10 = *reinterpret_cast<const f32x4*>(bp + 32);
+            b11 = *reinterpret_cast<const f32x4*>(bp + 48);
+        }
+        kstep(t);
+        slice(I0{}, I0{}, ti, b00, b01);
+        slice(I0{}, I1{}, ti, b10, b11);
+        slice(I1{}, I1{}, ti, b10, b11);
+        slice(I1{}, I0{}, ti, b00, b01);
+        advance();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may land in an LDS allocation this workgroup has given up
+    if (wr == 0) asm volatile("s_barrier" ::: "memory");
+}
+
+__global__ void cvt_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (__bf16)in[i];
+}
+
+int g_gm_cus[16] = {};
+
+template <int NT, int EPI>
+int launch_gm(const GemmArgs& a, hipStream_t s, bool prepare_only) {
+    constexpr int TN = 64 * NT;
+    constexpr int LDS = 2 * 8 * (GM_PA + TN * 16 + 16);
+    auto kern = gemm_bf16_kernel<NT, EPI>;
+    const int dev = fg_device_slot();
+    if (dev < 0) return (int)hipErrorInvalidDevice;
+    static bool attr_done[16] = {};
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done[dev] = true;
+    }
+    if (!g_gm_cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return (int)hipErrorUnknown;
+        g_gm_cus[dev] = n;
+    }
+    if (prepare_only) return 0;
+    const int Mt = (a.M + GM_TM - 1) / GM_TM, Nt = (a.N + TN - 1) / TN;
+    GemmArgs b = a;
+    int grid = g_gm_cus[dev];
+    if ((long long)Mt * Nt < grid) grid = Mt * Nt, b.xn = 0;
+    if (grid & 7) b.xn = 0;
+    if (b.xn > 0) {
+        // XCD grid xm x xn: the widest split of the output tiles that divides them and still leaves every XCD >= 4 token tiles;
+        // an explicit a.xn (tuning) is taken when it divides
+        int xn = 1;
+        for (int c = 8; c >= 1; c >>= 1)
+            if (Nt % c == 0 && Mt / (8 / c) >= 4) {
+                xn = c;
+                break;
+            }
+        if (a.xn <= 8 && (a.xn & (a.xn - 1)) == 0 && Nt % a.xn == 0 && a.xn != 1) xn = a.xn;
+        b.xn = xn;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(GM_NTHR), LDS, s, b);
+    return (int)hipGetLastError();
+}
+
+template <int EPI>
+int launch_pp(const GemmArgs& a, hipStream_t s, bool prepare_only) {
+    constexpr int LDS = 131072;
+    auto kern = gemm_bf16_pp_kernel<EPI>;
+    const int dev = fg_device_slot();
+    if (dev < 0) return (int)hipErrorInvalidDevice;
+    static bool attr_done[16] = {};
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done[dev] = true;
+    }
+    if (!g_gm_cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return (int)hipErrorUnknown;
+        g_gm_cus[dev] = n;
+    }
+    if (prepare_only) return 0;
+    const int Mt = (a.M + GM_TM - 1) / GM_TM, Nt = (a.N + 255) / 256;
+    GemmArgs b = a;
+    int grid = g_gm_cus[dev];
+    if ((long long)Mt * Nt < grid) grid = Mt * Nt, b.xn = 0;
+    if (grid & 7) b.xn = 0;
+    if (b.xn > 0) {
+        int xn = 1;
+        for (int c = 8; c >= 1; c >>= 1)
+            if (Nt % c == 0 && Mt / (8 / c) >= 4) {
+                xn = c;
+                break;
+            }
+        if (a.xn <= 8 && (a.xn & (a.xn - 1)) == 0 && Nt % a.xn == 0 && a.xn != 1) xn = a.xn;
+        b.xn = xn;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(GM_NTHR), LDS, s, b);
+    return (int)hipGetLastError();
+}
+
+int gm_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+// 0: gemm_bf16_kernel (register-staged), 1: gemm_bf16_pp_kernel (LDS-DMA, ping-pong) where the shape allows
+int gm_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FASTGEN_AMD_GEMM_PP");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v;
+}
+
+}  // namespace
+
+bool gemm_bf16_supported(const GemmArgs& a) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % GM_KC) || (a.N % 16)) return false;
+    if ((size_t)a.N * a.K * 2 >= (1ull << 31)) return false;  // staging offsets into W stay below the buffer resource's 2 GiB
+    if (a.heads > 0 && (a.head_dim % 4 || a.N != 3 * a.heads * a.head_dim || a.T <= 0 || !a.q || !a.k || !a.vt)) return false;
+    if (a.heads <= 0 && !a.out) return false;
+    if (a.gate && a.gate_rows <= 0) return false;
+    return a.A && a.W;
+}
+
+// xn: 0 = linear tile order, 1 = choose the XCD grid, 2 / 4 / 8 = force that many output-tile columns of XCDs
+int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only) {
+    if (!prepare_only && !gemm_bf16_supported(a)) return (int)hipErrorInvalidValue;
+    const bool heads = a.heads > 0;
+    const bool n3 = !prepare_only && (a.N % 256) != 0 && (a.N % 192) == 0;
+    if (prepare_only) {
+        int rc;
+        if ((rc = launch_gm<4, GM_EPI_TOK>(a, s, true)) || (rc = launch_gm<3, GM_EPI_TOK>(a, s, true)) ||
+            (rc = launch_gm<4, GM_EPI_HEADS>(a, s, true)) || (rc = launch_gm<3, GM_EPI_HEADS>(a, s, true)) ||
+            (rc = launch_pp<GM_EPI_TOK>(a, s, true)) || (rc = launch_pp<GM_EPI_HEADS>(a, s, true)))
+            return rc;
+        return 0;
+    }
+    // rows per launch: staging offsets into A stay below the buffer resource's 2 GiB
+    const int rows_max = (int)(((1ull << 31) - 1) / ((size_t)a.K * 2)) / GM_TM * GM_TM;
+    for (int r0 = 0; r0 < a.M; r0 += rows_max) {
+        GemmArgs b = a;
+        b.row0 = a.row0 + r0;
+        b.M = a.M - r0 < rows_max ? a.M - r0 : rows_max;
+        b.A = reinterpret_cast<const __bf16*>(a.A) + (size_t)r0 * a.K;
+        if (a.out) b.out = reinterpret_cast<__bf16*>(a.out) + (size_t)r0 * a.N;
+        if (a.resid) b.resid = reinterpret_cast<const __bf16*>(a.resid) + (size_t)r0 * a.N;
+        // the ping-pong kernel shifts ragged edge tiles back (rows / columns computed twice): not for an in-place residual
+        const bool pp = (a.variant < 0 ? gm_variant() : a.variant) == 1 && b.M >= GM_TM && a.N >= 256 && a.K >= 2 * GM_KC && !(a.resid && a.resid == a.out);
+        const int rc = pp ? (heads ? launch_pp<GM_EPI_HEADS>(b, s, false) : launch_pp<GM_EPI_TOK>(b, s, false))
+                          : heads ? (n3 ? launch_gm<3, GM_EPI_HEADS>(b, s, false) : launch_gm<4, GM_EPI_HEADS>(b, s, false))
+                                  : (n3 ? launch_gm<3, GM_EPI_TOK>(b, s, false) : launch_gm<4, GM_EPI_TOK>(b, s, false));
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int launch_cvt_bf16(const float* in, void* out, size_t n, hipStream_t s) {
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, s, in, (__bf16*)out, n);
+    return (int)hipGetLastError();
+}

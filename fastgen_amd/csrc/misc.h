@@ -130,3 +130,28 @@ int launch_dit_cond(const float* t_emb, const float* r_emb, const float* table, 
 // mode 2 (bf16x3): q, k, vt are hi / lo bf16 planes, lo_off elements apart (conv.hip OUT_HEADS writes them so); else lo_off unused
 int launch_dit_attention(int mode, const void* q, const void* k, const void* vt, void* out, int B, int heads, int head_dim, size_t lo_off,
                          hipStream_t s);
+
+// gemm.hip: token GEMM of the transformer blocks in the bf16 compute mode.  out[tok][n] = epilogue(sum_k A[tok][k] W[n][k] + bias[n]),
+// A [M][K] bf16, W [N][K] bf16 (launch_cvt_bf16 of the fp32 parameter), K % 64 == 0, N % 16 == 0.
+// Token epilogue (heads == 0): v = acc + bias; act == 1: tanh-GELU; gate: v *= gate[((row0 + row) / gate_rows) * gate_stride + n];
+// resid: v += resid[row][n]; out [M][N] bf16.  Head-split epilogue (heads > 0, N = 3 heads head_dim): q | k [B][heads][T][head_dim],
+// v^T [B][heads][head_dim][T] with B index (row0 + row) / T.
+struct GemmArgs {
+    const void* A = nullptr;
+    const void* W = nullptr;
+    const float* bias = nullptr;
+    void* out = nullptr;
+    int M = 0, N = 0, K = 0;
+    int act = 0;
+    const float* gate = nullptr;
+    int gate_stride = 0, gate_rows = 1;
+    const void* resid = nullptr;
+    void *q = nullptr, *k = nullptr, *vt = nullptr;
+    int heads = 0, head_dim = 0, T = 0;
+    int row0 = 0;  // global index of row 0 (set by the launcher when it cuts M into pieces below the 2 GiB buffer-offset range)
+    int variant = -1;  // -1: default (env FASTGEN_AMD_GEMM_PP, 1 unless set to 0); 0 register-staged kernel; 1 LDS-DMA ping-pong kernel
+    int xn = 1;    // 0: linear tile order; 1: XCD-aware order, split chosen by the launcher; 2 / 4 / 8: that many XCD columns over N
+};
+bool gemm_bf16_supported(const GemmArgs& a);
+int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only = false);
+int launch_cvt_bf16(const float* in, void* out, size_t n, hipStream_t s);

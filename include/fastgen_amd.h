@@ -317,6 +317,14 @@ FG_API int fg_op_images_to_u8(const float* images, uint8_t* out, int64_t batch, 
                        void* stream);
 /* Standard normal draws: Philox4x32-10(key = seed, counter = (offset, index/4)) + Box-Muller. */
 FG_API int fg_op_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, void* stream);
+/* The transformer blocks' token GEMM in the bf16 compute mode (gemm.hip; reference: the nn.Linear calls of DiTBlock,
+ * fastgen/networks/DiT/network.py:168-198, under bf16 autocast): out[m][n] = resid[m][n] + gate[(m / gate_rows) * gate_stride + n] *
+ * act(sum_k a[m][k] w[n][k] + bias[n]) with a [m][k], w [n][k], resid / out [m][n] in bf16, fp32 accumulation, bias / gate fp32;
+ * act 0 none, 1 GELU(tanh); bias, gate, resid nullable.  k % 64 == 0, n % 16 == 0.  tile_order: 0 linear, 1 XCD-aware (launcher's
+ * choice), 2 / 4 / 8 XCD columns over n; + 16 forces the register-staged kernel, + 32 the LDS-DMA ping-pong kernel (default: the
+ * latter where m, n >= 256).  Exposed for the parity tests and scripts/gemm_bench.py. */
+FG_API int fg_op_gemm_bf16(const void* a, const void* w, const float* bias, void* out, int m, int n, int k, int act, const float* gate,
+                           int gate_stride, int gate_rows, const void* resid, int tile_order, void* stream);
 
 #ifdef __cplusplus
 }

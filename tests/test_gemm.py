@@ -1,0 +1,85 @@
+"""Token GEMM of the transformer blocks (fastgen_amd/csrc/gemm.hip, `fg_op_gemm_bf16`): the `nn.Linear` calls of the reference's
+DiTBlock (fastgen/networks/DiT/network.py:168-198) as they run under bf16 autocast - bf16 operands, fp32 accumulation - with the fused
+epilogues (bias, tanh-GELU, adaLN gate x value + residual).  Checked against torch fp32 matmul on the SAME bf16 operands: the only
+differences are the accumulation order and the final bf16 rounding, so the tolerance is one bf16 ulp of the result (2^-8 relative
+to the row scale) for every shape, tile order, ragged token count and epilogue."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(a, w, bias=None, act=0, gate=None, gate_rows=1, resid=None, order=1):
+    from fastgen_amd import _lib
+
+    m, k = a.shape
+    n = w.shape[0]
+    out = torch.empty(m, n, dtype=torch.bfloat16, device=a.device)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    _lib.check(_lib.lib().fg_op_gemm_bf16(p(a), p(w), p(bias), p(out), m, n, k, act, p(gate), gate.shape[1] if gate is not None else 0,
+                                          gate_rows, p(resid), order, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    return out
+
+
+def _ref(a, w, bias=None, act=0, gate=None, gate_rows=1, resid=None):
+    v = a.float() @ w.float().t()
+    if bias is not None:
+        v = v + bias
+    if act == 1:
+        v = torch.nn.functional.gelu(v, approximate="tanh")
+    if gate is not None:
+        v = v * gate.repeat_interleave(gate_rows, dim=0)[: v.shape[0]]
+    if resid is not None:
+        v = v + resid.float()
+    return v
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 256, 64), (512, 192, 128), (1000, 1152, 1152), (4680, 1536, 1536), (77, 3456, 1152),
+                                    (2048, 4608, 1152), (2048, 1152, 4608), (300, 64, 256), (513, 384, 384)])
+@pytest.mark.parametrize("order", [0, 1, 16 + 1, 32 + 0, 32 + 1])
+def test_plain_gemm_matches_fp32_matmul_of_the_same_operands(m, n, k, order):
+    g = torch.Generator().manual_seed(m * 7 + n * 3 + k)
+    a = torch.randn(m, k, generator=g).bfloat16().cuda()
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).bfloat16().cuda()
+    bias = torch.randn(n, generator=g).cuda()
+    got = _run(a, w, bias, order=order).float()
+    want = _ref(a, w, bias)
+    err = (got - want).abs().max().item()
+    assert err <= 2 ** -8 * want.abs().max().item() + 1e-6, (m, n, k, order, err)
+
+
+@pytest.mark.parametrize("order", [0, 1, 2, 16 + 1, 32 + 2])
+def test_epilogues(order):
+    m, n, k, rows = 1300, 1152, 1152, 256
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(m, k, generator=g).bfloat16().cuda()
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).bfloat16().cuda()
+    bias = torch.randn(n, generator=g).cuda()
+    gate = torch.randn((m + rows - 1) // rows, 6 * n, generator=g).cuda()[:, 2 * n: 3 * n]  # a chunk of the adaLN vector: strided rows
+    resid = torch.randn(m, n, generator=g).bfloat16().cuda()
+    # GELU(tanh)
+    got = _run(a, w, bias, act=1, order=order).float()
+    want = _ref(a, w, bias, act=1)
+    assert (got - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-3
+    # gate x value + residual; the gate rows are `rows` tokens each and 6 n floats apart
+    from fastgen_amd import _lib
+
+    out = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(_lib.lib().fg_op_gemm_bf16(p(a), p(w), p(bias), p(out), m, n, k, 0, p(gate), 6 * n, rows, p(resid), order,
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    want = _ref(a, w, bias, gate=gate.contiguous(), gate_rows=rows, resid=resid)
+    assert (out.float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-3
+
+
+def test_unsupported_shapes_are_refused():
+    from fastgen_amd import _lib
+
+    a = torch.zeros(64, 96, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(64, 96, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(_lib.FastGenAMDError):
+        _run(a, w)  # k % 64 != 0
