@@ -33,6 +33,12 @@ class fg_dit_config(ctypes.Structure):
                 ("num_heads", c_int), ("mlp_hidden", c_int), ("embedding_rows", c_int), ("r_timestep", c_int), ("compute_dtype", c_int)]
 
 
+class fg_wan_config(ctypes.Structure):
+    _fields_ = [("num_heads", c_int), ("head_dim", c_int), ("in_channels", c_int), ("out_channels", c_int), ("text_dim", c_int),
+                ("freq_dim", c_int), ("ffn_dim", c_int), ("num_layers", c_int), ("rope_max_seq_len", c_int), ("chunk_size", c_int),
+                ("total_num_frames", c_int), ("eps", c_float)]
+
+
 # name -> (restype, argtypes); every symbol include/fastgen_amd.h declares
 SIGNATURES = {
     "fg_last_error": (c_char_p, []),
@@ -89,6 +95,17 @@ SIGNATURES = {
     "fg_dit_pack_weights": (c_int, [c_void_p, c_void_p]),
     "fg_dit_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "fg_dit_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "fg_wan_create": (c_int, [POINTER(fg_wan_config), POINTER(c_void_p)]),
+    "fg_wan_destroy": (None, [c_void_p]),
+    "fg_wan_num_params": (c_int, [c_void_p]),
+    "fg_wan_param_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int), POINTER(c_int64)]),
+    "fg_wan_bind_param": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
+    "fg_wan_pack_weights": (c_int, [c_void_p, c_void_p]),
+    "fg_wan_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int, c_int]),
+    "fg_wan_clear_caches": (c_int, [c_void_p, c_void_p]),
+    "fg_wan_set_text": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "fg_wan_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
+                               c_void_p]),
     "fg_disc_edm_num_params": (c_int, [c_int]),
     "fg_disc_edm_workspace_bytes": (c_size_t, [c_int, c_int]),
     "fg_disc_edm_run": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
@@ -100,6 +117,7 @@ SIGNATURES = {
     "fg_edm_set_training": (c_int, [c_void_p, c_int]),
     "fg_op_images_to_u8": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "fg_op_randn": (c_int, [c_void_p, c_int64, c_uint64, c_uint64, c_void_p]),
+    "fg_op_attention128": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "fg_op_gemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
                                 c_int, c_void_p]),
 }

@@ -365,6 +365,11 @@ int ln_mod_d(int D, const void* x, const float* mod, int ms, int so, int co, voi
         case 768: hipLaunchKernelGGL((ln_modulate_kernel<ST, 768>), g, b, 0, s, (const ST*)x, mod, ms, so, co, (ST*)y, ntok, tpi); break;
         case 1024: hipLaunchKernelGGL((ln_modulate_kernel<ST, 1024>), g, b, 0, s, (const ST*)x, mod, ms, so, co, (ST*)y, ntok, tpi); break;
         case 1152: hipLaunchKernelGGL((ln_modulate_kernel<ST, 1152>), g, b, 0, s, (const ST*)x, mod, ms, so, co, (ST*)y, ntok, tpi); break;
+        // the causal video DiT's widths (engine_wan.inc)
+        case 256: hipLaunchKernelGGL((ln_modulate_kernel<ST, 256>), g, b, 0, s, (const ST*)x, mod, ms, so, co, (ST*)y, ntok, tpi); break;
+        case 1536: hipLaunchKernelGGL((ln_modulate_kernel<ST, 1536>), g, b, 0, s, (const ST*)x, mod, ms, so, co, (ST*)y, ntok, tpi); break;
+        case 2048: hipLaunchKernelGGL((ln_modulate_kernel<ST, 2048>), g, b, 0, s, (const ST*)x, mod, ms, so, co, (ST*)y, ntok, tpi); break;
+        case 5120: hipLaunchKernelGGL((ln_modulate_kernel<ST, 5120>), g, b, 0, s, (const ST*)x, mod, ms, so, co, (ST*)y, ntok, tpi); break;
         default: return (int)hipErrorInvalidValue;
     }
     DIT_RET();

@@ -1141,6 +1141,7 @@ int fg_edm_run_block(fg_edm* h, int index, const float* x1, int c1, const float*
 
 #include "engine_train.inc"  // block / network backward, forward-mode pass and their entry points
 #include "engine_dit.inc"    // the DiT engine (fg_dit_*)
+#include "engine_wan.inc"    // the causal video DiT engine (fg_wan_*)
 
 int fg_op_gn_coeffs(const float* x1, int c1, const float* x2, int c2, const float* gamma, const float* beta, float eps,
                     float* ab_out, int batch, int hw, void* stream) {
@@ -1236,6 +1237,12 @@ int fg_op_images_to_u8(const float* images, uint8_t* out, int64_t batch, int cha
 }
 int fg_op_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, void* stream) {
     HIP_TRY(launch_randn(out, total, seed, offset, nullptr, (hipStream_t)stream));
+    return FG_OK;
+}
+int fg_op_attention128(const void* q, const void* k, const void* v, void* out, int batch, int heads, int lq, int lkv, void* stream) {
+    if (!q || !k || !v || !out || batch <= 0 || heads <= 0 || lq <= 0 || lkv <= 0) return fail(FG_EINVAL, "fg_op_attention128: bad argument");
+    const int D = heads * 128;
+    HIP_TRY(launch_fa128(q, D, (int64_t)lq * D, k, v, D, (int64_t)lkv * D, out, D, (int64_t)lq * D, batch, heads, lq, lkv, (hipStream_t)stream));
     return FG_OK;
 }
 int fg_op_gemm_bf16(const void* a, const void* w, const float* bias, void* out, int m, int n, int k, int act, const float* gate,

@@ -155,3 +155,22 @@ struct GemmArgs {
 bool gemm_bf16_supported(const GemmArgs& a);
 int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only = false);
 int launch_cvt_bf16(const float* in, void* out, size_t n, hipStream_t s);
+
+// wan.hip: the non-GEMM pieces of the causal video DiT (reference fastgen/networks/Wan/network_causal.py); bf16 token tensors
+int launch_wan_patch_embed(const float* x, const float* w, const float* bias, void* out, int B, int C, int Fr, int H, int W, int D, hipStream_t s);
+int launch_wan_mod(const float* table, const float* tproj, float* mod, int rows, int J, int D, hipStream_t s);
+int launch_wan_outmod(const float* table, const float* temb, float* mod, int rows, int D, hipStream_t s);
+int launch_silu(const float* x, float* y, int64_t n, hipStream_t s);
+int launch_cvt_rows_bf16(const float* x, void* y, int64_t n, hipStream_t s);
+int launch_wan_rope_table(const float2* tab_t, const float2* tab_h, const float2* tab_w, float2* cs, int L, int fs, int gw, int start, int S,
+                          int nt, int nh, int nw, hipStream_t s);
+// RMSNorm over D (w nullable: plain copy) + optional interleaved-pair RoPE (cs [L][64] {cos, sin}) of rows [rows][ld_src], row
+// (b = r / L, l = r % L) written to dst + b * dst_bs + (dst_row0 + l) * ld_dst
+int launch_rms_rope(int D, const void* src, int ld_src, const float* w, float eps, const float2* cs, void* dst, int64_t dst_bs, int dst_row0,
+                    int ld_dst, int rows, int L, hipStream_t s);
+// softmax(q k^T / sqrt(128)) v per (batch, head), head dim 128: q [B][Lq] rows of ldq elements (head h at column 128 h), k / v
+// [B][Lkv] rows of ldk, out [B][Lq] rows of ldo; *_bs = elements between batches
+int launch_fa128(const void* q, int ldq, int64_t q_bs, const void* k, const void* v, int ldk, int64_t kv_bs, void* out, int ldo, int64_t o_bs,
+                 int B, int heads, int Lq, int Lkv, hipStream_t s);
+int launch_wan_final(int D, const void* x, const float* mod, const float* w, const float* bias, float* out, int ntok, int Fr, int gh, int gw, int C,
+                     float eps, hipStream_t s);

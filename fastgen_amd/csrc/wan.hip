@@ -1,0 +1,398 @@
+// Causal video DiT (SURVEY 8(f)3 / 8(a) "CausVid"): the pieces of the reference's CausalWan forward that are not GEMMs
+// (fastgen/networks/Wan/network_causal.py; the block linears run on gemm.hip).  bf16 token tensors, fp32 statistics / softmax /
+// modulation: the arithmetic the reference runs this network in (`precision = "bfloat16"`, configs/experiments/WanT2V/config_sf.py:19;
+// the norms and the adaLN arithmetic in fp32: `_wan_block_forward_inline_cache`, :467-550).
+//   wan_patch_embed_kernel   Conv3d(kernel = stride = (1,2,2)) + bias, tokens ordered (frame, row, column)
+//   wan_mod_kernel           {shift, scale, gate} x {attention, feed-forward} = scale_shift_table + time_proj(silu(temb)) per frame (:478-480)
+//   wan_rope_table_kernel    cos / sin of the chunk's tokens with the temporal offset of `_rope_forward_with_time_offset` (:79-128)
+//   rms_rope_kernel          RMSNorm over the full inner dimension ("rms_norm_across_heads") * weight, interleaved-pair RoPE
+//                            (`apply_rotary_emb`, :274-289), scattered into the KV cache rows of the chunk (:386-390); also the plain copy of v
+//   fa128_kernel             attention of the chunk's queries over the cached frames + the chunk (:377-412) and over the text (:331-360):
+//                            head dim 128, any number of keys, online softmax
+//   wan_final_kernel         per-frame output modulation + proj_out + un-patchify (fastgen/networks/Wan/network.py:226-262)
+#include <type_traits>
+
+#include "common.h"
+#include "misc.h"
+
+namespace {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// x [B][C][F][H][W] fp32 -> tokens [B][F * gh * gw][D] bf16
+__global__ __launch_bounds__(256) void wan_patch_embed_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                              __bf16* __restrict__ out, int B, int C, int Fr, int H, int W, int D) {
+    const int gh = H / 2, gw = W / 2, fs = gh * gw;
+    const int64_t total = (int64_t)B * Fr * fs * D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int d = (int)(i % D);
+        const int64_t tok = i / D;
+        const int hw = (int)(tok % fs), f = (int)((tok / fs) % Fr), b = (int)(tok / ((int64_t)fs * Fr));
+        const int gy = hw / gw, gx = hw - gy * gw;
+        float a = bias[d];
+        const float* wr = w + (size_t)d * C * 4;
+        for (int c = 0; c < C; ++c) {
+            const float* xp = x + ((((size_t)b * C + c) * Fr + f) * H + 2 * gy) * W + 2 * gx;
+            a = fmaf(wr[c * 4 + 0], xp[0], a);
+            a = fmaf(wr[c * 4 + 1], xp[1], a);
+            a = fmaf(wr[c * 4 + 2], xp[W], a);
+            a = fmaf(wr[c * 4 + 3], xp[W + 1], a);
+        }
+        out[i] = (__bf16)a;
+    }
+}
+
+// mod[bf][j][d] = table[j][d] + tproj[bf][j * D + d]
+__global__ void wan_mod_kernel(const float* __restrict__ table, const float* __restrict__ tproj, float* __restrict__ mod, int rows, int J, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * J * D) return;
+    mod[i] = table[i % ((int64_t)J * D)] + tproj[i];
+}
+// out[r][0][d] = table[0][d] + temb[r][d], out[r][1][d] = table[1][d] + temb[r][d]   (the output layer's {shift, scale})
+__global__ void wan_outmod_kernel(const float* __restrict__ table, const float* __restrict__ temb, float* __restrict__ mod, int rows, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * 2 * D) return;
+    const int d = (int)(i % D);
+    const int64_t r = i / (2 * (int64_t)D);
+    mod[i] = table[i % (2 * (int64_t)D)] + temb[r * D + d];
+}
+__global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = x[i] / (1.0f + expf(-x[i]));
+}
+__global__ void cvt_rows_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (__bf16)x[i];
+}
+
+// cs[l][i] = {cos, sin} of pair i (0 .. hd / 2) of chunk token l = (f, gy, gx): pairs [0, nt) take the frame axis at min(start + f, S - 1),
+// [nt, nt + nh) the row axis, the rest the column axis; tab: per axis [S][pairs of the axis] {cos, sin} (fp32 of float64 angles, host-built)
+__global__ void wan_rope_table_kernel(const float2* __restrict__ tab_t, const float2* __restrict__ tab_h, const float2* __restrict__ tab_w,
+                                      float2* __restrict__ cs, int L, int fs, int gw, int start, int S, int nt, int nh, int nw) {
+    const int half = nt + nh + nw;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L * half) return;
+    const int l = i / half, p = i - l * half;
+    const int f = l / fs, hw = l - f * fs, gy = hw / gw, gx = hw - gy * gw;
+    float2 v;
+    if (p < nt) v = tab_t[(size_t)min(start + f, S - 1) * nt + p];
+    else if (p < nt + nh) v = tab_h[(size_t)gy * nh + (p - nt)];
+    else v = tab_w[(size_t)gx * nw + (p - nt - nh)];
+    cs[i] = v;
+}
+
+// One wave per row: y = x * rsqrt(mean(x^2) + eps) * w (w == nullptr: plain copy), then (cs != nullptr) the interleaved-pair rotation
+// of every head with the row's table entry cs[row % L]; row r = (batch r / L, token r % L) goes to dst + batch * dst_bs + (dst_row0 +
+// token) * ld_dst.  D = 128 NP, lane l holds the pairs l + 64 j of the row (element pair 2 (l + 64 j), +1): pair index inside its
+// head = (l + 64 j) % 64 = l.
+template <int NP>
+__global__ __launch_bounds__(256) void rms_rope_kernel(const __bf16* __restrict__ src, int ld_src, const float* __restrict__ w, float eps,
+                                                       const float2* __restrict__ cs, __bf16* __restrict__ dst, int64_t dst_bs, int dst_row0,
+                                                       int ld_dst, int rows, int L) {
+    constexpr int D = 128 * NP;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const __bf16* x = src + (size_t)row * ld_src;
+    float v[2 * NP];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const bf16x2 q = *reinterpret_cast<const bf16x2*>(x + 2 * (lane + 64 * j));
+        v[2 * j] = (float)q[0], v[2 * j + 1] = (float)q[1];
+        ss = fmaf(v[2 * j], v[2 * j], fmaf(v[2 * j + 1], v[2 * j + 1], ss));
+    }
+    const int b = row / L, l = row - b * L;
+    if (w) {
+        const float r = 1.0f / sqrtf(wsum(ss) * (1.0f / D) + eps);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const f32x2 wq = *reinterpret_cast<const f32x2*>(w + 2 * (lane + 64 * j));
+            v[2 * j] *= r * wq[0], v[2 * j + 1] *= r * wq[1];
+        }
+    }
+    if (cs) {
+        const float2 c = cs[(size_t)l * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const float a = v[2 * j], bb = v[2 * j + 1];
+            v[2 * j] = a * c.x - bb * c.y;
+            v[2 * j + 1] = a * c.y + bb * c.x;
+        }
+    }
+    __bf16* y = dst + (size_t)b * dst_bs + (size_t)(dst_row0 + l) * ld_dst;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) *reinterpret_cast<bf16x2*>(y + 2 * (lane + 64 * j)) = bf16x2{(__bf16)v[2 * j], (__bf16)v[2 * j + 1]};
+}
+
+// ---- attention, head dim 128 ------------------------------------------------------------------------------------------------
+// grid (ceil(Lq / 128), heads, batch), 256 threads: a wave owns 32 queries end to end; the workgroup walks the keys in tiles of
+// 32, each tile's K and V rows (32 x 128 bf16 = 8 KiB each) staged once in LDS for its four waves (double-buffered; the loads of
+// tile t + 1 are in flight during tile t).  S^T = K Q^T (keys on the accumulator rows, the QUERY on the lane) and
+// O^T = V^T P^T (output dims on the rows, the query on the lane): the online-softmax state of a query is one lane's scalars and
+// the P^T accumulators feed the second product directly as its B operand.  V stays row-major in memory and in LDS; its
+// K-contiguous fragments (8 keys of one output dim) come from ds_read_b64_tr_b16.  LDS image of both tiles: 256-byte rows,
+// 16-byte chunk ch of row r at 16 (ch ^ (((r & 3) << 2) | ((r >> 2) & 3))): conflict-free for the ds_read_b128 row reads of K and
+// for the transposed reads of V (cdna_hip_programming.md T10, image (b)).
+__device__ __forceinline__ int fa_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+__device__ __forceinline__ s16x4 fa_tr_read(const char* lds_addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(uint32_t)(uintptr_t)lds_addr);
+}
+
+__global__ __launch_bounds__(256) void fa128_kernel(const __bf16* __restrict__ q, int ldq, int64_t q_bs, const __bf16* __restrict__ k,
+                                                    const __bf16* __restrict__ v, int ldk, int64_t kv_bs, __bf16* __restrict__ out, int ldo,
+                                                    int64_t o_bs, int Lq, int Lkv, float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (K tile 8 KiB | V tile 8 KiB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    // this lane's query row (clamped: rows past Lq compute on the last row and are not stored)
+    const __bf16* qrow = q + (size_t)b * q_bs + (size_t)min(q0 + r, Lq - 1) * ldq + head * 128 + 8 * h;
+    bf16x8 qf[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + kk * 16);
+    const __bf16* kb = k + (size_t)b * kv_bs + head * 128;
+    const __bf16* vb = v + (size_t)b * kv_bs + head * 128;
+
+    // staging: thread -> rows tid >> 4 and 16 + (tid >> 4), chunk tid & 15 of both tiles
+    const int srow = tid >> 4, sch = tid & 15;
+    fg_u32x4 kreg[2], vreg[2];
+    auto issue = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t key = (size_t)min(t * 32 + srow + 16 * i, Lkv - 1);
+            kreg[i] = *reinterpret_cast<const fg_u32x4*>(kb + key * ldk + sch * 8);
+            vreg[i] = *reinterpret_cast<const fg_u32x4*>(vb + key * ldk + sch * 8);
+        }
+    };
+    auto park = [&](char* st) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<fg_u32x4*>(st + fa_off(srow + 16 * i, sch)) = kreg[i];
+            *reinterpret_cast<fg_u32x4*>(st + 8192 + fa_off(srow + 16 * i, sch)) = vreg[i];
+        }
+    };
+
+    f32x16 ot[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ot[d][i] = 0.f;
+    float m = -INFINITY, lsum = 0.f;
+
+    // transposed-read lane addresses inside a V tile: group (h, c = (lane >> 4) & 1), lane 4 q + p of the group supplies
+    // off(r0 + q, c0 + (p >> 1)) + 8 (p & 1); r0 = 16 s + 4 h (+ 8), c0 = 4 dt + 2 c
+    const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, gc = (lane >> 4) & 1;
+
+    const int nt = (Lkv + 31) / 32;
+    issue(0);
+    park(smem);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const char* st = smem + (t & 1) * 16384;
+        if (t + 1 < nt) issue(t + 1);
+        // S^T[key][query]
+        f32x16 s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(st + fa_off(r, 2 * kk + h));
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
+        }
+        // online softmax; keys past Lkv (last tile) are masked
+        float mt = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (t * 32 + acc_row(i, h) >= Lkv) s[i] = -INFINITY;
+            mt = fmaxf(mt, s[i]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float mn = fmaxf(m, mt);
+        const float alpha = __builtin_amdgcn_exp2f((m - mn) * scale_log2e);  // m = -inf at the first tile: exp2(-inf) = 0
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            s[i] = __builtin_amdgcn_exp2f((s[i] - mn) * scale_log2e);
+            ps += s[i];
+        }
+        ps += __shfl_xor(ps, 32);
+        lsum = lsum * alpha + ps;
+        m = mn;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {  // wave-uniform: the running maximum of some query of this wave moved
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ot[d][i] *= alpha;
+        }
+        // O^T[dim][query] += V^T[dim][key] P^T[key][query]
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[8 * sx + j];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int r0 = 16 * sx + 4 * h, c0 = 4 * d + 2 * gc;
+                const s16x4 lo = fa_tr_read(st + 8192 + fa_off(r0 + gq, c0 + (gp >> 1)) + 8 * (gp & 1));
+                const s16x4 hi = fa_tr_read(st + 8192 + fa_off(r0 + 8 + gq, c0 + (gp >> 1)) + 8 * (gp & 1));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, ot[d], 0, 0, 0);
+            }
+        }
+        if (t + 1 < nt) park(smem + ((t + 1) & 1) * 16384);
+        __syncthreads();
+    }
+    // out[query][head * 128 + dim]: this lane holds dims 32 d + acc_row(i, h) of its query
+    if (q0 + r < Lq) {
+        const float inv = 1.0f / lsum;
+        __bf16* orow = out + (size_t)b * o_bs + (size_t)(q0 + r) * ldo + head * 128;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const bf16x4 o4 = {(__bf16)(ot[d][4 * i4] * inv), (__bf16)(ot[d][4 * i4 + 1] * inv), (__bf16)(ot[d][4 * i4 + 2] * inv),
+                                   (__bf16)(ot[d][4 * i4 + 3] * inv)};
+                *reinterpret_cast<bf16x4*>(orow + 32 * d + 8 * i4 + 4 * h) = o4;
+            }
+    }
+}
+
+// LayerNorm(eps, no affine) -> (1 + scale) y + shift with mod[tok / rows_per_mod] = {shift, scale} [2][D] -> proj_out -> un-patchify.
+// One wave per token; D = 128 NP.  out [B][C][F][H][W] fp32, feature o = (py 2 + px) C + c.
+template <int NP>
+__global__ __launch_bounds__(256) void wan_final_kernel(const __bf16* __restrict__ x, const float* __restrict__ mod, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int ntok, int Fr, int gh, int gw,
+                                                        int C, float eps) {
+    constexpr int D = 128 * NP;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= ntok) return;
+    const int fs = gh * gw;
+    const int bf = tok / fs, hw = tok - bf * fs, b = bf / Fr, f = bf - b * Fr, gy = hw / gw, gx = hw - gy * gw;
+    float v[2 * NP];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const bf16x2 q = *reinterpret_cast<const bf16x2*>(x + (size_t)tok * D + 2 * (lane + 64 * j));
+        v[2 * j] = (float)q[0], v[2 * j + 1] = (float)q[1];
+        s += v[2 * j] + v[2 * j + 1];
+    }
+    const float mean = wsum(s) * (1.0f / D);
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 2 * NP; ++e) {
+        v[e] -= mean;
+        ss = fmaf(v[e], v[e], ss);
+    }
+    const float rstd = 1.0f / sqrtf(wsum(ss) * (1.0f / D) + eps);
+    const float* mrow = mod + (size_t)bf * 2 * D;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int c = 2 * (lane + 64 * j);
+        const f32x2 sh = *reinterpret_cast<const f32x2*>(mrow + c), sc = *reinterpret_cast<const f32x2*>(mrow + D + c);
+        v[2 * j] = fmaf(v[2 * j] * rstd, 1.0f + sc[0], sh[0]);
+        v[2 * j + 1] = fmaf(v[2 * j + 1] * rstd, 1.0f + sc[1], sh[1]);
+    }
+    const int H = 2 * gh, W = 2 * gw;
+    for (int o = 0; o < 4 * C; ++o) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const f32x2 q = *reinterpret_cast<const f32x2*>(w + (size_t)o * D + 2 * (lane + 64 * j));
+            a = fmaf(v[2 * j], q[0], a);
+            a = fmaf(v[2 * j + 1], q[1], a);
+        }
+        a = wsum(a);
+        if (lane == 0) {
+            const int c = o % C, pq = o / C, py = pq >> 1, px = pq & 1;
+            out[((((size_t)b * C + c) * Fr + f) * H + 2 * gy + py) * W + 2 * gx + px] = a + bias[o];
+        }
+    }
+}
+
+#define WAN_RET() return (int)hipGetLastError()
+
+}  // namespace
+
+int launch_wan_patch_embed(const float* x, const float* w, const float* bias, void* out, int B, int C, int Fr, int H, int W, int D, hipStream_t s) {
+    const int64_t total = (int64_t)B * Fr * (H / 2) * (W / 2) * D;
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(wan_patch_embed_kernel, dim3((unsigned)(blocks > 262144 ? 262144 : blocks)), dim3(256), 0, s, x, w, bias, (__bf16*)out, B, C,
+                       Fr, H, W, D);
+    WAN_RET();
+}
+int launch_wan_mod(const float* table, const float* tproj, float* mod, int rows, int J, int D, hipStream_t s) {
+    const int64_t n = (int64_t)rows * J * D;
+    hipLaunchKernelGGL(wan_mod_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, table, tproj, mod, rows, J, D);
+    WAN_RET();
+}
+int launch_wan_outmod(const float* table, const float* temb, float* mod, int rows, int D, hipStream_t s) {
+    const int64_t n = (int64_t)rows * 2 * D;
+    hipLaunchKernelGGL(wan_outmod_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, table, temb, mod, rows, D);
+    WAN_RET();
+}
+int launch_silu(const float* x, float* y, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(silu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n);
+    WAN_RET();
+}
+int launch_cvt_rows_bf16(const float* x, void* y, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(cvt_rows_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, (__bf16*)y, n);
+    WAN_RET();
+}
+int launch_wan_rope_table(const float2* tab_t, const float2* tab_h, const float2* tab_w, float2* cs, int L, int fs, int gw, int start, int S,
+                          int nt, int nh, int nw, hipStream_t s) {
+    const int n = L * (nt + nh + nw);
+    hipLaunchKernelGGL(wan_rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, s, tab_t, tab_h, tab_w, cs, L, fs, gw, start, S, nt, nh, nw);
+    WAN_RET();
+}
+// D = 128 NP with NP in {2, 3, 12, 16, 40} (256, 384, 1536 = the 1.3B network, 2048, 5120 = the 14B network)
+int launch_rms_rope(int D, const void* src, int ld_src, const float* w, float eps, const float2* cs, void* dst, int64_t dst_bs, int dst_row0,
+                    int ld_dst, int rows, int L, hipStream_t s) {
+    dim3 g((rows + 3) / 4), b(256);
+#define RR(NP) hipLaunchKernelGGL(rms_rope_kernel<NP>, g, b, 0, s, (const __bf16*)src, ld_src, w, eps, cs, (__bf16*)dst, dst_bs, dst_row0, ld_dst, rows, L)
+    switch (D) {
+        case 256: RR(2); break;
+        case 384: RR(3); break;
+        case 1536: RR(12); break;
+        case 2048: RR(16); break;
+        case 5120: RR(40); break;
+        default: return (int)hipErrorInvalidValue;
+    }
+#undef RR
+    WAN_RET();
+}
+int launch_fa128(const void* q, int ldq, int64_t q_bs, const void* k, const void* v, int ldk, int64_t kv_bs, void* out, int ldo, int64_t o_bs,
+                 int B, int heads, int Lq, int Lkv, hipStream_t s) {
+    if (Lq <= 0 || Lkv <= 0 || (ldq % 8) || (ldk % 8) || (ldo % 4)) return (int)hipErrorInvalidValue;
+    dim3 g((Lq + 127) / 128, heads, B);
+    hipLaunchKernelGGL(fa128_kernel, g, dim3(256), 32768, s, (const __bf16*)q, ldq, q_bs, (const __bf16*)k, (const __bf16*)v, ldk, kv_bs,
+                       (__bf16*)out, ldo, o_bs, Lq, Lkv, 1.44269504088896341f / sqrtf(128.0f));
+    WAN_RET();
+}
+int launch_wan_final(int D, const void* x, const float* mod, const float* w, const float* bias, float* out, int ntok, int Fr, int gh, int gw, int C,
+                     float eps, hipStream_t s) {
+    dim3 g((ntok + 3) / 4), b(256);
+#define WF(NP) hipLaunchKernelGGL(wan_final_kernel<NP>, g, b, 0, s, (const __bf16*)x, mod, w, bias, out, ntok, Fr, gh, gw, C, eps)
+    switch (D) {
+        case 256: WF(2); break;
+        case 384: WF(3); break;
+        case 1536: WF(12); break;
+        case 2048: WF(16); break;
+        case 5120: WF(40); break;
+        default: return (int)hipErrorInvalidValue;
+    }
+#undef WF
+    WAN_RET();
+}

@@ -1,0 +1,182 @@
+"""`CausalWan` drop-in for the reference's `fastgen.networks.Wan.network_causal.CausalWan` (the causal video DiT that
+`CausVidModel._student_sample_loop` drives chunk by chunk, fastgen/methods/distribution_matching/causvid.py:87-185), backed by
+libfastgen_amd.so (`fg_wan_*`: bf16 token GEMMs on gemm.hip, per-frame adaLN, RMSNorm + RoPE with a frame offset, KV-cache
+attention, output projection - fastgen_amd/csrc/wan.hip, engine_wan.inc).
+
+The reference builds its transformer with `WanTransformer3DModel.from_pretrained(model_id)` (Wan/network.py:641-693: hub
+weights and config, unavailable offline); here the fields of that config are constructor keywords (defaults = Wan2.1-T2V-1.3B) and
+the parameters carry the same state-dict keys (`transformer.` + diffusers' names), so a converted checkpoint loads with
+`load_state_dict`.  PARITY UNPINNED (the arithmetic lives in un-vendored diffusers: oracle/wan_ref.py restates it).
+
+This round: autoregressive inference (`is_ar=True`, one cache tag).  Raises (never falls back): autograd, feature taps, r / image
+conditioning, teacher-forcing block masks (`is_ar=False` with all frames), any device but a HIP GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import weakref
+from typing import Any, Dict, Optional, Set
+
+import torch
+import torch.nn as nn
+
+from fastgen_amd import _lib
+from fastgen_amd.networks.EDM import network as _edm
+from fastgen_amd.networks.network import FastGenNetwork
+from fastgen_amd.networks.noise_schedule import NET_PRED_TYPES
+
+
+class CausalWan(FastGenNetwork):
+    def __init__(self, num_attention_heads: int = 12, attention_head_dim: int = 128, in_channels: int = 16, out_channels: int = 16,
+                 text_dim: int = 4096, freq_dim: int = 256, ffn_dim: int = 8960, num_layers: int = 30, eps: float = 1e-6,
+                 rope_max_seq_len: int = 1024, r_timestep: bool = False, net_pred_type: str = "flow", schedule_type: str = "rf",
+                 chunk_size: int = 3, total_num_frames: int = 21, enable_logvar_linear: bool = True, **model_kwargs):
+        for k in ("model_id_or_local_path", "load_pretrained", "disable_efficient_attn", "disable_grad_ckpt", "use_fsdp_checkpoint",
+                  "r_embedder_init", "time_cond_type", "norm_temb", "encoder_depth", "delete_cache_on_clear"):
+            v = model_kwargs.pop(k, None)  # reference knobs without meaning here (hub ids, autograd plumbing) ...
+            if k in ("norm_temb",) and v:  # ... except those that change the arithmetic
+                raise NotImplementedError(f"{k}={v!r} is not implemented")
+            if k == "encoder_depth" and v is not None:
+                raise NotImplementedError("encoder_depth is not implemented")
+        super().__init__(net_pred_type=net_pred_type, schedule_type=schedule_type, **model_kwargs)
+        if r_timestep:
+            raise NotImplementedError("r_timestep=True (a second time embedder) is not implemented for the causal video DiT path")
+        self.chunk_size, self.total_num_frames = chunk_size, total_num_frames
+        cfg = _lib.fg_wan_config()
+        cfg.num_heads, cfg.head_dim, cfg.in_channels, cfg.out_channels = num_attention_heads, attention_head_dim, in_channels, out_channels
+        cfg.text_dim, cfg.freq_dim, cfg.ffn_dim, cfg.num_layers = text_dim, freq_dim, ffn_dim, num_layers
+        cfg.rope_max_seq_len, cfg.chunk_size, cfg.total_num_frames, cfg.eps = rope_max_seq_len, chunk_size, total_num_frames, eps
+        self._cfg, self.in_channels = cfg, in_channels
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().fg_wan_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._h = h
+        self._names, self._bound_sig, self._refs, self._ws = [], None, [], None
+        self._text_key = None
+        L = _lib.lib()
+        name, ndim, shape = ctypes.c_char_p(), ctypes.c_int(), (ctypes.c_int64 * 5)()
+        g = torch.Generator().manual_seed(0)
+        for i in range(L.fg_wan_num_params(h)):
+            _lib.check(L.fg_wan_param_info(h, i, ctypes.byref(name), ctypes.byref(ndim), shape))
+            full, shp = name.value.decode(), tuple(shape[j] for j in range(ndim.value))
+            if "logvar_linear" in full and not enable_logvar_linear:
+                continue
+            self._names.append(full)
+            node, parts = self, full.split(".")
+            for p in parts[:-1]:
+                if p not in node._modules:
+                    node.add_module(p, _edm._Node())
+                node = node._modules[p]
+            node.register_parameter(parts[-1], nn.Parameter(self._init_value(full, shp, g)))
+
+    @staticmethod
+    def _init_value(name: str, shape, g) -> torch.Tensor:
+        """torch defaults of the modules diffusers builds (Linear / Conv3d: uniform(+-1/sqrt(fan_in)); RMSNorm / LayerNorm weights 1,
+        biases of norms 0; scale_shift_table randn / sqrt(dim))."""
+        if name.endswith("scale_shift_table"):
+            return torch.randn(shape, generator=g) / shape[-1] ** 0.5
+        if name.endswith(("norm_q.weight", "norm_k.weight", "norm2.weight")):
+            return torch.ones(shape)
+        if name.endswith("norm2.bias"):
+            return torch.zeros(shape)
+        fan_in = 1
+        for s_ in (shape[1:] if len(shape) > 1 else shape):
+            fan_in *= s_
+        return (torch.rand(shape, generator=g) * 2 - 1) * fan_in ** -0.5
+
+    def __del__(self):
+        try:
+            _lib.lib().fg_wan_destroy(self._h)
+        except Exception:
+            pass
+
+    # ---- library plumbing -------------------------------------------------------------------------------------------------
+    def _stream(self, dev):
+        return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def _bind(self, dev: torch.device):
+        tensors = dict(self.named_parameters())
+        names = [n for n in self._names if "logvar_linear" not in n]
+        sig = tuple((tensors[n].data_ptr(), tensors[n]._version, tensors[n].dtype) for n in names)
+        if self._bound_sig != sig:
+            L, refs = _lib.lib(), []
+            for n in names:
+                p = tensors[n]
+                if p.device.type != "cuda":
+                    raise RuntimeError(f"parameter {n} is on {p.device}; fastgen_amd runs on a HIP GPU only (no CPU path)")
+                q = p.detach()
+                if q.dtype != torch.float32 or not q.is_contiguous():
+                    q = q.to(torch.float32).contiguous()
+                refs.append(q)
+                _lib.check(L.fg_wan_bind_param(self._h, n.encode(), ctypes.c_void_p(q.data_ptr()), q.numel()))
+            _lib.check(L.fg_wan_pack_weights(self._h, self._stream(dev)))
+            self._refs, self._bound_sig, self._text_key = refs, sig, None
+
+    def _workspace(self, dev, B, F, H, W) -> torch.Tensor:
+        need = _lib.lib().fg_wan_workspace_bytes(self._h, B, F, H, W)
+        if need == 0:
+            raise ValueError(f"bad chunk shape: batch {B}, frames {F}, {H}x{W} (height and width must be even)")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        return self._ws
+
+    def clear_caches(self) -> None:
+        """`CausalWan.clear_caches` (network_causal.py:1030-1054)."""
+        if torch.cuda.is_available():
+            _lib.check(_lib.lib().fg_wan_clear_caches(self._h, self._stream(torch.device("cuda", torch.cuda.current_device()))))
+        self._text_key = None
+
+    def forward(self, x_t: torch.Tensor, t: torch.Tensor, condition: Optional[Any] = None, r: Optional[torch.Tensor] = None,
+                return_features_early: bool = False, feature_indices: Optional[Set[int]] = None, return_logvar: bool = False,
+                unpatchify_features: bool = True, fwd_pred_type: Optional[str] = None, skip_layers=None, cache_tag: str = "pos",
+                cur_start_frame: int = 0, store_kv: bool = False, is_ar: bool = False, **fwd_kwargs):
+        if feature_indices or return_features_early or return_logvar or skip_layers or r is not None:
+            raise NotImplementedError("feature taps / logvar / skip_layers / r are not implemented for the causal video DiT path")
+        if fwd_kwargs:
+            raise TypeError(f"unexpected forward kwargs: {sorted(fwd_kwargs)}")
+        if not is_ar:
+            raise NotImplementedError("only the autoregressive call (is_ar=True: KV-cache attention) is implemented; the teacher-forcing "
+                                      "block-mask call is a training path")
+        if cache_tag != "pos":
+            raise NotImplementedError("one cache tag ('pos') is implemented")
+        if fwd_pred_type is None:
+            fwd_pred_type = self.net_pred_type
+        else:
+            assert fwd_pred_type in NET_PRED_TYPES, f"{fwd_pred_type} is not supported as fwd_pred_type"
+        if torch.is_grad_enabled() and (x_t.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("fastgen_amd.CausalWan: the backward pass is not implemented; call under torch.no_grad() / "
+                                      "torch.inference_mode() (sampling)")
+        if x_t.device.type != "cuda":
+            raise RuntimeError("fastgen_amd runs on a HIP GPU only (no CPU path); got a tensor on " + str(x_t.device))
+        if condition is None:
+            raise ValueError("CausalWan.forward needs the text condition [B, L, text_dim]")
+        condition = torch.stack(condition, dim=0) if isinstance(condition, list) else condition
+        B, C, F, H, W = x_t.shape
+        dev = x_t.device
+        if C != self.in_channels:
+            raise ValueError(f"x_t must have {self.in_channels} channels, got {C}")
+        self._bind(dev)
+        ws = self._workspace(dev, B, F, H, W)
+        L = _lib.lib()
+        # the text condition: embedded (and its cross-attention k / v cached) once per tensor, as the reference's static cache
+        # (the same tensor OBJECT at the same in-place version; a new object with recycled storage is embedded again)
+        ver = 0 if condition.is_inference() else condition._version
+        same = self._text_key is not None and self._text_key[0]() is condition and self._text_key[1:] == (ver, tuple(condition.shape))
+        if not same:
+            c32 = condition.detach().to(device=dev, dtype=torch.float32).contiguous()
+            if c32.shape[0] != B:
+                raise ValueError(f"condition batch {c32.shape[0]} != {B}")
+            _lib.check(L.fg_wan_set_text(self._h, ctypes.c_void_p(c32.data_ptr()), B, c32.shape[1], ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                         self._stream(dev)))
+            self._text_key = (weakref.ref(condition), ver, tuple(condition.shape))
+        # per-frame timesteps in the embedder's units (`_compute_timestep_inputs`, :1063-1075: rescale_t, [B] -> [B, F])
+        t_in = torch.atleast_1d(t.detach()).to(dev)
+        ts = self.noise_scheduler.rescale_t(t_in)
+        ts = (ts.view(-1, 1).expand(B, F) if ts.ndim == 1 else ts).to(torch.float32).contiguous()
+        x32 = x_t.detach().to(torch.float32).contiguous()
+        out = torch.empty_like(x32)
+        _lib.check(L.fg_wan_forward(self._h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(ts.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                    B, F, H, W, int(cur_start_frame), int(bool(store_kv)), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                    self._stream(dev)))
+        out = out.to(x_t.dtype)
+        t_conv = t_in[:, None, :, None, None] if t_in.ndim == 2 else t_in
+        return self.noise_scheduler.convert_model_output(x_t, out, t_conv, src_pred_type=self.net_pred_type, target_pred_type=fwd_pred_type)

@@ -310,6 +310,53 @@ FG_API size_t fg_dit_workspace_bytes(const fg_dit* h, int batch);
 FG_API int fg_dit_forward(fg_dit* h, const float* x_t, const float* t, const float* r, const int64_t* class_ids, float* out,
                           float* cond_out, int batch, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- Causal video DiT (SURVEY 8(f)3 and the CausVid row of 8(a); reference fastgen/networks/Wan/network_causal.py `CausalWan`, driven
+ * chunk by chunk by `CausVidModel._student_sample_loop`, fastgen/methods/distribution_matching/causvid.py:87-185) --------------
+ * The arithmetic of this network is diffusers' WanTransformer3DModel (un-vendored, diffusers==0.35.1): the HIP path follows the
+ * restatement in oracle/wan_ref.py - PARITY UNPINNED.  bf16 token tensors and GEMM operands with fp32 accumulation,
+ * fp32 norms / softmax / modulation: the reference runs this network in bf16 (configs/experiments/WanT2V/config_sf.py:19).
+ * fg_wan_config = the fields of the transformer's config the path reads.  Supported: head_dim 128, inner dim (heads x 128) in
+ * {256, 384, 1536 (1.3B), 2048, 5120 (14B)}, patch (1,2,2), ffn_dim / text_dim % 64 == 0, freq_dim 256, cross_attn_norm. */
+typedef struct fg_wan_config {
+    int num_heads;         /* 12 */
+    int head_dim;          /* 128 */
+    int in_channels;       /* 16 */
+    int out_channels;      /* 16 */
+    int text_dim;          /* 4096 */
+    int freq_dim;          /* 256 */
+    int ffn_dim;           /* 8960 */
+    int num_layers;        /* 30 */
+    int rope_max_seq_len;  /* 1024 */
+    int chunk_size;        /* CausalFastGenNetwork.chunk_size, 3 (frames per autoregressive chunk; the sampler's business) */
+    int total_num_frames;  /* 21: capacity of the self-attention KV caches, in frames */
+    float eps;             /* 1e-6 */
+} fg_wan_config;
+typedef struct fg_wan fg_wan; /* opaque */
+
+FG_API int fg_wan_create(const fg_wan_config* cfg, fg_wan** out);
+FG_API void fg_wan_destroy(fg_wan* h);
+/* State-dict view: `transformer.` + diffusers' parameter names (the reference's CausalWan.state_dict()); shapes up to 5-d (the
+ * Conv3d patch embedding); bind / pack as for fg_edm. */
+FG_API int fg_wan_num_params(const fg_wan* h);
+FG_API int fg_wan_param_info(const fg_wan* h, int index, const char** name, int* ndim, int64_t shape[5]);
+FG_API int fg_wan_bind_param(fg_wan* h, const char* name, const float* device_ptr, int64_t numel);
+FG_API int fg_wan_pack_weights(fg_wan* h, void* stream);
+/* Workspace for one forward over a chunk of `frames` latent frames of height x width (also enough for fg_wan_set_text). */
+FG_API size_t fg_wan_workspace_bytes(const fg_wan* h, int batch, int frames, int height, int width);
+/* `CausalWan.clear_caches` (:1030-1054): zero the self-attention caches, forget the text (cross-attention) caches. */
+FG_API int fg_wan_clear_caches(fg_wan* h, void* stream);
+/* The text condition: text [B, text_len, text_dim] fp32 (the text encoder's output).  Runs condition_embedder.text_embedder and
+ * every block's attn2 k / v projections (+ norm_k) once: the reference's static cross-attention cache (:331-360). */
+FG_API int fg_wan_set_text(fg_wan* h, const float* text, int batch, int text_len, void* workspace, size_t workspace_bytes, void* stream);
+/* One network call of the autoregressive sampler: `CausalWan.forward(x_t, t, cache_tag="pos", cur_start_frame, store_kv, is_ar=True)`
+ * up to the raw network output (:1077-1160; the flow -> x0 conversion stays with the caller).  x_t, out: [B, C, frames, H, W] fp32;
+ * t_frames: [B * frames] fp32 AS THE EMBEDDER SEES THEM (rescale_t: 1000 t, `_compute_timestep_inputs` :1063-1075).  The chunk's
+ * keys / values are written to cache rows [cur_start_frame * frame_seqlen, +frames * frame_seqlen) in every call and attention runs
+ * over rows [0, that end): with store_kv = 0 the rows are rewritten by the chunk's later store_kv = 1 call, as in the reference's
+ * loop (causvid.py:150-172), where only that call moves the cache length. */
+FG_API int fg_wan_forward(fg_wan* h, const float* x_t, const float* t_frames, float* out, int batch, int frames, int height, int width,
+                          int cur_start_frame, int store_kv, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Samples to image bytes, the step after generator_fn in the reference's sample writer
  * (scripts/fid/compute_fid_from_ckpts.py:199): out[n,y,x,c] = uint8(clip(images[n,c,y,x] * 127.5 + 128, 0, 255)),
  * fp32 multiply then add, truncation; NaN -> 0.  images NCHW fp32, out NHWC bytes. */
@@ -317,6 +364,10 @@ FG_API int fg_op_images_to_u8(const float* images, uint8_t* out, int64_t batch, 
                        void* stream);
 /* Standard normal draws: Philox4x32-10(key = seed, counter = (offset, index/4)) + Box-Muller. */
 FG_API int fg_op_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, void* stream);
+/* softmax(q k^T / sqrt(128)) v per (batch, head), head dim 128, bf16 tensors q / out [batch, lq, heads * 128], k / v
+ * [batch, lkv, heads * 128], fp32 softmax (wan.hip fa128_kernel: the causal video DiT's KV-cache and text attention,
+ * fastgen/networks/Wan/network_causal.py:331-412).  Exposed for the parity tests. */
+FG_API int fg_op_attention128(const void* q, const void* k, const void* v, void* out, int batch, int heads, int lq, int lkv, void* stream);
 /* The transformer blocks' token GEMM in the bf16 compute mode (gemm.hip; reference: the nn.Linear calls of DiTBlock,
  * fastgen/networks/DiT/network.py:168-198, under bf16 autocast): out[m][n] = resid[m][n] + gate[(m / gate_rows) * gate_stride + n] *
  * act(sum_k a[m][k] w[n][k] + bias[n]) with a [m][k], w [n][k], resid / out [m][n] in bf16, fp32 accumulation, bias / gate fp32;

@@ -1,0 +1,135 @@
+"""Causal video DiT (SURVEY 8(f)3 + the CausVid row of 8(a)).  PARITY UNPINNED: the network's arithmetic lives in un-vendored
+diffusers (oracle/wan_ref.py's header); these tests hold the HIP path (fg_wan_*, through the drop-in module) to the restatement.
+
+CPU: properties of the restatement itself (RoPE frame offset, cache-append attention == attention over the concatenated frames),
+the module's state dict against the restated key list, loud failure without a GPU.
+GPU (-m gpu): attention kernel vs torch SDPA; network calls of the autoregressive sampler (chunk 0 with store_kv, chunk 1 over the
+cache) and the whole CausVid student loop against the oracle.  Tolerance: the HIP path runs bf16 operands (the reference's
+precision for this network) against the fp32 oracle: relative L2 <= 2e-2 per call, <= 3e-2 after the multi-chunk loop."""
+import ctypes
+
+import pytest
+import torch
+
+from oracle import wan_ref as R
+
+KW = dict(num_attention_heads=2, attention_head_dim=128, text_dim=128, ffn_dim=512, num_layers=2, chunk_size=2, total_num_frames=6)
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).norm() / b.float().norm())
+
+
+def test_rope_offset_is_a_slice_of_the_full_table():
+    cfg = R.TINY
+    c_all, s_all = R.rope_for_chunk(cfg, 6, 3, 4, 0)
+    c, s = R.rope_for_chunk(cfg, 2, 3, 4, 2)
+    assert torch.equal(c, c_all[2 * 12: 4 * 12]) and torch.equal(s, s_all[2 * 12: 4 * 12])
+    # axis split of head dim 128: 44 | 42 | 42, every frequency twice
+    cos, _, dims = R.rope_tables(cfg)
+    assert dims == (44, 42, 42) and torch.equal(cos[0][:, 0::2], cos[0][:, 1::2])
+
+
+def test_oracle_cache_append_equals_attention_over_all_frames():
+    """Chunk 1 computed over the cache that chunk 0's store_kv call left == chunk 1's rows of one call over both chunks in which
+    chunk 0's queries are irrelevant: run the two-chunk call with the same per-frame inputs and compare the later frames' attention
+    inputs through the first block's output."""
+    cfg = R.TINY
+    net = R.CausalWanRef(R.random_state_dict(cfg, 3), cfg)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 16, 4, 4, 6, generator=g)
+    text = torch.randn(1, 8, cfg.text_dim, generator=g)
+    t = torch.tensor([0.0])
+    net.forward(x[:, :, :2], t, text, 0, store_kv=True)
+    tr1 = {}
+    net.forward(x[:, :, 2:], t, text, 2, store_kv=False, trace=tr1)
+    net2 = R.CausalWanRef(R.random_state_dict(cfg, 3), cfg)
+    tr2 = {}
+    net2.forward(x, t, text, 0, store_kv=False, trace=tr2)  # all four frames at once: every query sees all 4 frames (no mask)
+    # block 0's self-attention of frames 2-3 differs (they now also see each other AND frames 0-1 exactly as before): same keys, so
+    # the first block's output rows of frames 2-3 agree
+    L = 2 * 2 * 3
+    assert torch.allclose(tr1["block0"][:, :L], tr2["block0"][:, L:], atol=2e-5)
+
+
+def test_module_state_dict_matches_the_restated_key_list():
+    from fastgen_amd.networks.Wan.network_causal import CausalWan
+
+    net = CausalWan(**KW)
+    want = R.state_dict_shapes(R.TINY)
+    got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert got == want and list(got) == list(want)
+    res = net.load_state_dict(R.random_state_dict(R.TINY, 5), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    with pytest.raises(RuntimeError, match="HIP GPU only"):
+        with torch.no_grad():
+            net(torch.zeros(1, 16, 2, 4, 6), torch.tensor([0.5]), condition=torch.zeros(1, 8, 128), is_ar=True)
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros(1, 16, 2, 4, 6), torch.tensor([0.5]), condition=torch.zeros(1, 8, 128), is_ar=True)  # grad mode
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,Lq,Lkv", [(1, 2, 128, 128), (2, 3, 200, 333), (1, 12, 96, 1000), (1, 2, 48, 17), (1, 1, 4680, 4680)])
+def test_attention128_matches_sdpa(B, H, Lq, Lkv):
+    from fastgen_amd import _lib
+
+    g = torch.Generator().manual_seed(Lq + Lkv)
+    q = torch.randn(B, Lq, H * 128, generator=g).bfloat16().cuda()
+    k = torch.randn(B, Lkv, H * 128, generator=g).bfloat16().cuda()
+    v = torch.randn(B, Lkv, H * 128, generator=g).bfloat16().cuda()
+    out = torch.empty_like(q)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(_lib.lib().fg_op_attention128(p(q), p(k), p(v), p(out), B, H, Lq, Lkv, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    want = R.sdpa(q.float().view(B, Lq, H, 128), k.float().view(B, Lkv, H, 128), v.float().view(B, Lkv, H, 128))
+    assert _rel(out, want) < 1e-2, _rel(out, want)
+
+
+def _nets(seed=7):
+    from fastgen_amd.networks.Wan.network_causal import CausalWan
+
+    sd = R.random_state_dict(R.TINY, seed)
+    ref = R.CausalWanRef(sd, R.TINY)
+    net = CausalWan(**KW)
+    net.load_state_dict(sd, strict=True)
+    return ref, net.cuda().eval()
+
+
+@pytest.mark.gpu
+def test_autoregressive_calls_against_oracle():
+    ref, net = _nets()
+    g = torch.Generator().manual_seed(8)
+    B, H, W = 2, 16, 24
+    x = torch.randn(B, 16, 4, H, W, generator=g)
+    text = torch.randn(B, 40, 128, generator=g)
+    with torch.inference_mode():
+        # chunk 0 at t = 0.8 (no cache yet), then its cache-fill call at t = 0, then chunk 1 over the cache
+        for (lo, hi, t, store) in [(0, 2, 0.8, False), (0, 2, 0.0, True), (2, 4, 0.6, False), (2, 4, 0.0, True)]:
+            tt = torch.full((B,), t, dtype=torch.float64)
+            want = ref.forward(x[:, :, lo:hi], tt, text, cur_start_frame=lo, store_kv=store)
+            got = net(x[:, :, lo:hi].cuda(), tt.cuda(), condition=text.cuda(), fwd_pred_type="flow", cur_start_frame=lo, store_kv=store, is_ar=True)
+            assert got.shape == want.shape
+            assert _rel(got.cpu(), want) < 2e-2, (lo, t, store, _rel(got.cpu(), want))
+        # the x0 conversion of the RF schedule: x0 = x_t - t * flow
+        tt = torch.full((B,), 0.6, dtype=torch.float64)
+        got = net(x[:, :, 2:4].cuda(), tt.cuda(), condition=text.cuda(), fwd_pred_type="x0", cur_start_frame=2, is_ar=True)
+        want = x[:, :, 2:4] - 0.6 * ref.forward(x[:, :, 2:4], tt, text, cur_start_frame=2)
+        assert _rel(got.cpu(), want) < 2e-2
+        net.clear_caches()
+
+
+@pytest.mark.gpu
+def test_causvid_student_loop_against_oracle():
+    from fastgen_amd.methods.distribution_matching.causvid import CausVidModel
+
+    ref, net = _nets(9)
+    g = torch.Generator().manual_seed(10)
+    B, H, W = 1, 16, 16
+    noise = torch.randn(B, 16, 5, H, W, generator=g)  # 5 frames, chunk_size 2: chunks of 3 + 2 frames (the remainder goes first)
+    text = torch.randn(B, 16, 128, generator=g)
+    t_list = [0.999, 0.7, 0.3, 0.0]
+    got = CausVidModel.generator_fn(net, noise.cuda(), student_sample_steps=3, t_list=t_list, condition=text.cuda(), student_sample_type="ode")
+    tl = torch.tensor(t_list, dtype=torch.float64)
+    want = R.student_sample_loop(ref, noise * 0.999, tl, text, sample_type="ode")  # latents = noise * sigma(t0) on the RF schedule
+    assert got.shape == want.shape
+    assert _rel(got.cpu(), want) < 3e-2, _rel(got.cpu(), want)
