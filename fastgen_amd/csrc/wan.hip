@@ -10,6 +10,8 @@
 //   fa128_kernel             attention of the chunk's queries over the cached frames + the chunk (:377-412) and over the text (:331-360):
 //                            head dim 128, any number of keys, online softmax
 //   wan_final_kernel         per-frame output modulation + proj_out + un-patchify (fastgen/networks/Wan/network.py:226-262)
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -147,14 +149,19 @@ __device__ __forceinline__ s16x4 fa_tr_read(const char* lds_addr) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(uint32_t)(uintptr_t)lds_addr);
 }
 
-__global__ __launch_bounds__(256) void fa128_kernel(const __bf16* __restrict__ q, int ldq, int64_t q_bs, const __bf16* __restrict__ k,
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void fa128_kernel(const __bf16* __restrict__ q, int ldq, int64_t q_bs, const __bf16* __restrict__ k,
                                                     const __bf16* __restrict__ v, int ldk, int64_t kv_bs, __bf16* __restrict__ out, int ldo,
-                                                    int64_t o_bs, int Lq, int Lkv, float scale_log2e) {
+                                                    int64_t o_bs, int Lq, int Lkv, float scale_log2e, int nsplit, float* __restrict__ po,
+                                                    float* __restrict__ plse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (K tile 8 KiB | V tile 8 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // blockIdx.x = query tile * nsplit + split: with nsplit > 1 the workgroup covers the key tiles [t0, t1) of its split and leaves a
+    // normalised partial output + the log2-domain log-sum-exp of its keys; fa128_combine_kernel merges the splits
+    const int qt = (int)blockIdx.x / nsplit, split = (int)blockIdx.x - qt * nsplit;
+    const int q0 = qt * 128 + wave * 32;
     // this lane's query row (clamped: rows past Lq compute on the last row and are not stored)
     const __bf16* qrow = q + (size_t)b * q_bs + (size_t)min(q0 + r, Lq - 1) * ldq + head * 128 + 8 * h;
     bf16x8 qf[8];
@@ -193,11 +200,12 @@ __global__ __launch_bounds__(256) void fa128_kernel(const __bf16* __restrict__ q
     // off(r0 + q, c0 + (p >> 1)) + 8 (p & 1); r0 = 16 s + 4 h (+ 8), c0 = 4 dt + 2 c
     const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, gc = (lane >> 4) & 1;
 
-    const int nt = (Lkv + 31) / 32;
-    issue(0);
-    park(smem);
+    const int ntiles = (Lkv + 31) / 32;
+    const int t0 = (int)((long long)split * ntiles / nsplit), nt = (int)((long long)(split + 1) * ntiles / nsplit);
+    issue(t0);
+    park(smem + (t0 & 1) * 16384);
     __syncthreads();
-    for (int t = 0; t < nt; ++t) {
+    for (int t = t0; t < nt; ++t) {
         const char* st = smem + (t & 1) * 16384;
         if (t + 1 < nt) issue(t + 1);
         // S^T[key][query]
@@ -211,11 +219,13 @@ __global__ __launch_bounds__(256) void fa128_kernel(const __bf16* __restrict__ q
         }
         // online softmax; keys past Lkv (last tile) are masked
         float mt = -INFINITY;
+        if (t == ntiles - 1) {  // (wave-uniform) only the last key tile can be ragged
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (t * 32 + acc_row(i, h) >= Lkv) s[i] = -INFINITY;
-            mt = fmaxf(mt, s[i]);
+            for (int i = 0; i < 16; ++i)
+                if (t * 32 + acc_row(i, h) >= Lkv) s[i] = -INFINITY;
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mt = fmaxf(mt, s[i]);
         mt = fmaxf(mt, __shfl_xor(mt, 32));
         const float mn = fmaxf(m, mt);
         const float alpha = __builtin_amdgcn_exp2f((m - mn) * scale_log2e);  // m = -inf at the first tile: exp2(-inf) = 0
@@ -254,6 +264,21 @@ __global__ __launch_bounds__(256) void fa128_kernel(const __bf16* __restrict__ q
         __syncthreads();
     }
     // out[query][head * 128 + dim]: this lane holds dims 32 d + acc_row(i, h) of its query
+    if (nsplit > 1) {
+        if (q0 + r < Lq) {
+            const float inv = 1.0f / lsum;
+            const size_t row = (size_t)b * Lq + q0 + r, rows = (size_t)gridDim.z * Lq;
+            float* orow = po + ((size_t)split * rows + row) * (gridDim.y * 128) + head * 128;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4)
+                    *reinterpret_cast<f32x4*>(orow + 32 * d + 8 * i4 + 4 * h) =
+                        f32x4{ot[d][4 * i4] * inv, ot[d][4 * i4 + 1] * inv, ot[d][4 * i4 + 2] * inv, ot[d][4 * i4 + 3] * inv};
+            if (h == 0) plse[((size_t)split * rows + row) * gridDim.y + head] = m * scale_log2e + __builtin_amdgcn_logf(lsum);
+        }
+        return;
+    }
     if (q0 + r < Lq) {
         const float inv = 1.0f / lsum;
         __bf16* orow = out + (size_t)b * o_bs + (size_t)(q0 + r) * ldo + head * 128;
@@ -266,6 +291,29 @@ __global__ __launch_bounds__(256) void fa128_kernel(const __bf16* __restrict__ q
                 *reinterpret_cast<bf16x4*>(orow + 32 * d + 8 * i4 + 4 * h) = o4;
             }
     }
+}
+
+// out[row][c] = sum_s w_s po[s][row][c] / sum_s w_s,  w_s = 2^(plse[s][row][head(c)] - max_s): the merge of fa128_kernel's key splits
+__global__ void fa128_combine_kernel(const float* __restrict__ po, const float* __restrict__ plse, __bf16* __restrict__ out, int ldo,
+                                     int64_t o_bs, int64_t rows, int Lq, int heads, int nsplit) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (row, 4 consecutive columns)
+    const int D4 = heads * 32;
+    if (i >= rows * D4) return;
+    const int64_t row = i / D4;
+    const int c = (int)(i - row * D4) * 4, head = c >> 7;
+    float mx = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, plse[((size_t)s * rows + row) * heads + head]);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float ws = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float w = __builtin_amdgcn_exp2f(plse[((size_t)s * rows + row) * heads + head] - mx);
+        acc += w * *reinterpret_cast<const f32x4*>(po + ((size_t)s * rows + row) * (heads * 128) + c);
+        ws += w;
+    }
+    const float inv = 1.0f / ws;
+    const int64_t b = row / Lq, l = row - b * Lq;
+    *reinterpret_cast<bf16x4*>(out + (size_t)b * o_bs + (size_t)l * ldo + c) =
+        bf16x4{(__bf16)(acc[0] * inv), (__bf16)(acc[1] * inv), (__bf16)(acc[2] * inv), (__bf16)(acc[3] * inv)};
 }
 
 // LayerNorm(eps, no affine) -> (1 + scale) y + shift with mod[tok / rows_per_mod] = {shift, scale} [2][D] -> proj_out -> un-patchify.
@@ -373,12 +421,44 @@ int launch_rms_rope(int D, const void* src, int ld_src, const float* w, float ep
 #undef RR
     WAN_RET();
 }
+// Key splits: how many workgroups share one query tile's keys, so that short grids (one sample: ceil(Lq / 128) x heads workgroups)
+// still fill 256 CUs x 3 resident workgroups; every split keeps >= 8 key tiles.  scratch (nullable -> no split) holds the splits'
+// partial outputs and log-sum-exps: fa128_scratch_bytes(B, heads, Lq).
+constexpr int FA_MAX_SPLIT = 8;
+size_t fa128_scratch_bytes(int B, int heads, int Lq) { return (size_t)FA_MAX_SPLIT * B * Lq * ((size_t)heads * 128 + heads) * 4 + 256; }
 int launch_fa128(const void* q, int ldq, int64_t q_bs, const void* k, const void* v, int ldk, int64_t kv_bs, void* out, int ldo, int64_t o_bs,
-                 int B, int heads, int Lq, int Lkv, hipStream_t s) {
+                 int B, int heads, int Lq, int Lkv, hipStream_t s, void* scratch) {
     if (Lq <= 0 || Lkv <= 0 || (ldq % 8) || (ldk % 8) || (ldo % 4)) return (int)hipErrorInvalidValue;
-    dim3 g((Lq + 127) / 128, heads, B);
-    hipLaunchKernelGGL(fa128_kernel, g, dim3(256), 32768, s, (const __bf16*)q, ldq, q_bs, (const __bf16*)k, (const __bf16*)v, ldk, kv_bs,
-                       (__bf16*)out, ldo, o_bs, Lq, Lkv, 1.44269504088896341f / sqrtf(128.0f));
+    const int qtiles = (Lq + 127) / 128, ktiles = (Lkv + 31) / 32;
+    const long long base = (long long)qtiles * heads * B, slots = 256 * 3;
+    int nsplit = 1;
+    if (scratch && base < 2 * slots) {
+        double best = 0.0;
+        for (int c = 1; c <= FA_MAX_SPLIT && ktiles / c >= 8; ++c) {
+            const long long tot = base * c;
+            const double eff = (double)tot / (double)(((tot + slots - 1) / slots) * slots);
+            if (eff > best + 0.02) best = eff, nsplit = c;
+        }
+    }
+    float* po = (float*)scratch;
+    float* plse = po ? po + (size_t)FA_MAX_SPLIT * B * Lq * heads * 128 : nullptr;
+    dim3 g(qtiles * nsplit, heads, B);
+    static int minw = -1;  // waves per SIMD the kernel is compiled for (register budget 168 | 256): FASTGEN_AMD_FA_WAVES = 3 (default) | 2
+    if (minw < 0) {
+        const char* e = getenv("FASTGEN_AMD_FA_WAVES");
+        minw = (e && e[0] == '2') ? 2 : 3;
+    }
+    if (minw == 3)
+        hipLaunchKernelGGL(fa128_kernel<3>, g, dim3(256), 32768, s, (const __bf16*)q, ldq, q_bs, (const __bf16*)k, (const __bf16*)v, ldk, kv_bs,
+                           (__bf16*)out, ldo, o_bs, Lq, Lkv, 1.44269504088896341f / sqrtf(128.0f), nsplit, po, plse);
+    else
+        hipLaunchKernelGGL(fa128_kernel<2>, g, dim3(256), 32768, s, (const __bf16*)q, ldq, q_bs, (const __bf16*)k, (const __bf16*)v, ldk, kv_bs,
+                           (__bf16*)out, ldo, o_bs, Lq, Lkv, 1.44269504088896341f / sqrtf(128.0f), nsplit, po, plse);
+    if (nsplit > 1) {
+        const int64_t rows = (int64_t)B * Lq, n = rows * heads * 32;
+        hipLaunchKernelGGL(fa128_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, po, plse, (__bf16*)out, ldo, o_bs, rows, Lq,
+                           heads, nsplit);
+    }
     WAN_RET();
 }
 int launch_wan_final(int D, const void* x, const float* mod, const float* w, const float* bias, float* out, int ntok, int Fr, int gh, int gw, int C,
