@@ -1239,14 +1239,15 @@ int fg_op_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, void*
     HIP_TRY(launch_randn(out, total, seed, offset, nullptr, (hipStream_t)stream));
     return FG_OK;
 }
-int fg_op_attention128(const void* q, const void* k, const void* v, void* out, int batch, int heads, int lq, int lkv, void* stream) {
-    if (!q || !k || !v || !out || batch <= 0 || heads <= 0 || lq <= 0 || lkv <= 0) return fail(FG_EINVAL, "fg_op_attention128: bad argument");
-    const int D = heads * 128;
+int fg_op_attention(const void* q, const void* k, const void* v, void* out, int batch, int heads, int head_dim, int lq, int lkv, void* stream) {
+    if (!q || !k || !v || !out || batch <= 0 || heads <= 0 || lq <= 0 || lkv <= 0 || (head_dim != 128 && head_dim != 72))
+        return fail(FG_EINVAL, "fg_op_attention: bad argument (head_dim 128 or 72)");
+    const int D = heads * head_dim;
     // key-split scratch for short grids (freed after the stream has drained: a test entry point, not a hot path)
     void* scratch = nullptr;
     HIP_TRY(hipMalloc(&scratch, fa128_scratch_bytes(batch, heads, lq)));
-    const int rc = launch_fa128(q, D, (int64_t)lq * D, k, v, D, (int64_t)lkv * D, out, D, (int64_t)lq * D, batch, heads, lq, lkv,
-                                (hipStream_t)stream, scratch);
+    const int rc = launch_fa(head_dim, q, D, (int64_t)lq * D, k, v, D, (int64_t)lkv * D, out, D, (int64_t)lq * D, batch, heads, lq, lkv,
+                             (hipStream_t)stream, scratch);
     (void)hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(scratch);
     HIP_TRY(rc);

@@ -172,6 +172,9 @@ int launch_rms_rope(int D, const void* src, int ld_src, const float* w, float ep
 // [B][Lkv] rows of ldk, out [B][Lq] rows of ldo; *_bs = elements between batches
 // scratch: fa128_scratch_bytes(B, heads, Lq) bytes for key-split partials (nullptr: never split)
 size_t fa128_scratch_bytes(int B, int heads, int Lq);
+// the same kernel for head dim hd = 128 | 72 (DiT-XL/2's 16 x 72)
+int launch_fa(int hd, const void* q, int ldq, int64_t q_bs, const void* k, const void* v, int ldk, int64_t kv_bs, void* out, int ldo, int64_t o_bs,
+              int B, int heads, int Lq, int Lkv, hipStream_t s, void* scratch = nullptr);
 int launch_fa128(const void* q, int ldq, int64_t q_bs, const void* k, const void* v, int ldk, int64_t kv_bs, void* out, int ldo, int64_t o_bs,
                  int B, int heads, int Lq, int Lkv, hipStream_t s, void* scratch = nullptr);
 int launch_wan_final(int D, const void* x, const float* mod, const float* w, const float* bias, float* out, int ntok, int Fr, int gh, int gw, int C,

@@ -149,12 +149,23 @@ __device__ __forceinline__ s16x4 fa_tr_read(const char* lds_addr) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(uint32_t)(uintptr_t)lds_addr);
 }
 
-template <int MINW>
-__global__ __launch_bounds__(256, MINW) void fa128_kernel(const __bf16* __restrict__ q, int ldq, int64_t q_bs, const __bf16* __restrict__ k,
-                                                    const __bf16* __restrict__ v, int ldk, int64_t kv_bs, __bf16* __restrict__ out, int ldo,
-                                                    int64_t o_bs, int Lq, int Lkv, float scale_log2e, int nsplit, float* __restrict__ po,
-                                                    float* __restrict__ plse) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (K tile 8 KiB | V tile 8 KiB)
+// HD = 128 (the video DiT) or 72 (DiT-XL/2, 256 tokens: timm Attention as DiTBlock uses it, fastgen/networks/DiT/network.py:168, 191).
+// HD = 72: LDS rows are 144 bytes apart (9 x 16 B: 16 consecutive rows at one chunk fall on 16 different 16-byte slots without
+// a swizzle); the fifth 16-deep step of the q k^T contraction is half empty (its upper half is zero on the q side, finite row
+// spill-over on the k side), the third 32-wide tile of output dims is computed from spill-over and only its first 8 dims stored.
+template <int HD, int MINW>
+__global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict__ q, int ldq, int64_t q_bs, const __bf16* __restrict__ k,
+                                                       const __bf16* __restrict__ v, int ldk, int64_t kv_bs, __bf16* __restrict__ out, int ldo,
+                                                       int64_t o_bs, int Lq, int Lkv, float scale_log2e, int nsplit, float* __restrict__ po,
+                                                       float* __restrict__ plse) {
+    constexpr int KS = (HD + 15) / 16;   // 16-deep steps of q k^T
+    constexpr int DT_ = (HD + 31) / 32;  // 32-wide tiles of output dims
+    constexpr int RP = HD * 2;           // LDS row pitch
+    constexpr int TILE = 32 * RP;        // bytes of one K or V tile
+    constexpr int BUF = 2 * TILE + (HD == 128 ? 0 : 256);  // a buffer = K tile | V tile (| slack for the reads past the last V row)
+    constexpr int CPR = HD / 8;          // 16-byte chunks per row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto off = [](int row, int ch) { return HD == 128 ? fa_off(row, ch) : row * RP + ch * 16; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
@@ -163,35 +174,42 @@ __global__ __launch_bounds__(256, MINW) void fa128_kernel(const __bf16* __restri
     const int qt = (int)blockIdx.x / nsplit, split = (int)blockIdx.x - qt * nsplit;
     const int q0 = qt * 128 + wave * 32;
     // this lane's query row (clamped: rows past Lq compute on the last row and are not stored)
-    const __bf16* qrow = q + (size_t)b * q_bs + (size_t)min(q0 + r, Lq - 1) * ldq + head * 128 + 8 * h;
-    bf16x8 qf[8];
+    const __bf16* qrow = q + (size_t)b * q_bs + (size_t)min(q0 + r, Lq - 1) * ldq + head * HD + 8 * h;
+    bf16x8 qf[KS];
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + kk * 16);
-    const __bf16* kb = k + (size_t)b * kv_bs + head * 128;
-    const __bf16* vb = v + (size_t)b * kv_bs + head * 128;
+    for (int kk = 0; kk < KS; ++kk) {
+        qf[kk] = bf16x8{};
+        if (kk * 16 + 8 * h < HD) qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + kk * 16);
+    }
+    const __bf16* kb = k + (size_t)b * kv_bs + head * HD;
+    const __bf16* vb = v + (size_t)b * kv_bs + head * HD;
 
-    // staging: thread -> rows tid >> 4 and 16 + (tid >> 4), chunk tid & 15 of both tiles
-    const int srow = tid >> 4, sch = tid & 15;
-    fg_u32x4 kreg[2], vreg[2];
+    // staging: 32 rows x CPR chunks of both tiles over 256 threads
+    constexpr int NPC = (32 * CPR + 255) / 256;
+    fg_u32x4 kreg[NPC], vreg[NPC];
     auto issue = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const size_t key = (size_t)min(t * 32 + srow + 16 * i, Lkv - 1);
-            kreg[i] = *reinterpret_cast<const fg_u32x4*>(kb + key * ldk + sch * 8);
-            vreg[i] = *reinterpret_cast<const fg_u32x4*>(vb + key * ldk + sch * 8);
+        for (int i = 0; i < NPC; ++i) {
+            const int p = min(tid + 256 * i, 32 * CPR - 1);
+            const size_t key = (size_t)min(t * 32 + p / CPR, Lkv - 1);
+            kreg[i] = *reinterpret_cast<const fg_u32x4*>(kb + key * ldk + (p % CPR) * 8);
+            vreg[i] = *reinterpret_cast<const fg_u32x4*>(vb + key * ldk + (p % CPR) * 8);
         }
     };
     auto park = [&](char* st) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<fg_u32x4*>(st + fa_off(srow + 16 * i, sch)) = kreg[i];
-            *reinterpret_cast<fg_u32x4*>(st + 8192 + fa_off(srow + 16 * i, sch)) = vreg[i];
+        for (int i = 0; i < NPC; ++i) {
+            const int p = tid + 256 * i;
+            if (p < 32 * CPR) {
+                *reinterpret_cast<fg_u32x4*>(st + off(p / CPR, p % CPR)) = kreg[i];
+                *reinterpret_cast<fg_u32x4*>(st + TILE + off(p / CPR, p % CPR)) = vreg[i];
+            }
         }
     };
 
-    f32x16 ot[4];
+    f32x16 ot[DT_];
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+    for (int d = 0; d < DT_; ++d)
 #pragma unroll
         for (int i = 0; i < 16; ++i) ot[d][i] = 0.f;
     float m = -INFINITY, lsum = 0.f;
@@ -202,19 +220,23 @@ __global__ __launch_bounds__(256, MINW) void fa128_kernel(const __bf16* __restri
 
     const int ntiles = (Lkv + 31) / 32;
     const int t0 = (int)((long long)split * ntiles / nsplit), nt = (int)((long long)(split + 1) * ntiles / nsplit);
+    if (HD != 128 && tid < 32) {  // the slack behind both V tiles is read (never used): keep it finite
+        *reinterpret_cast<fg_u32x4*>(smem + 2 * TILE + tid * 8) = fg_u32x4{0, 0, 0, 0};
+        *reinterpret_cast<fg_u32x4*>(smem + BUF + 2 * TILE + tid * 8) = fg_u32x4{0, 0, 0, 0};
+    }
     issue(t0);
-    park(smem + (t0 & 1) * 16384);
+    park(smem + (t0 & 1) * BUF);
     __syncthreads();
     for (int t = t0; t < nt; ++t) {
-        const char* st = smem + (t & 1) * 16384;
+        const char* st = smem + (t & 1) * BUF;
         if (t + 1 < nt) issue(t + 1);
         // S^T[key][query]
         f32x16 s;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(st + fa_off(r, 2 * kk + h));
+        for (int kk = 0; kk < KS; ++kk) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(st + off(r, 2 * kk + h));
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
         }
         // online softmax; keys past Lkv (last tile) are masked
@@ -240,7 +262,7 @@ __global__ __launch_bounds__(256, MINW) void fa128_kernel(const __bf16* __restri
         m = mn;
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {  // wave-uniform: the running maximum of some query of this wave moved
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
+            for (int d = 0; d < DT_; ++d)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) ot[d][i] *= alpha;
         }
@@ -251,63 +273,65 @@ __global__ __launch_bounds__(256, MINW) void fa128_kernel(const __bf16* __restri
 #pragma unroll
             for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[8 * sx + j];
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
+            for (int d = 0; d < DT_; ++d) {
                 const int r0 = 16 * sx + 4 * h, c0 = 4 * d + 2 * gc;
-                const s16x4 lo = fa_tr_read(st + 8192 + fa_off(r0 + gq, c0 + (gp >> 1)) + 8 * (gp & 1));
-                const s16x4 hi = fa_tr_read(st + 8192 + fa_off(r0 + 8 + gq, c0 + (gp >> 1)) + 8 * (gp & 1));
+                const s16x4 lo = fa_tr_read(st + TILE + off(r0 + gq, c0 + (gp >> 1)) + 8 * (gp & 1));
+                const s16x4 hi = fa_tr_read(st + TILE + off(r0 + 8 + gq, c0 + (gp >> 1)) + 8 * (gp & 1));
                 typedef __attribute__((ext_vector_type(8))) short s16x8;
                 const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, ot[d], 0, 0, 0);
             }
         }
-        if (t + 1 < nt) park(smem + ((t + 1) & 1) * 16384);
+        if (t + 1 < nt) park(smem + ((t + 1) & 1) * BUF);
         __syncthreads();
     }
-    // out[query][head * 128 + dim]: this lane holds dims 32 d + acc_row(i, h) of its query
+    // out[query][head * HD + dim]: this lane holds dims 32 d + acc_row(i, h) = 32 d + 8 i4 + 4 h + e of its query
     if (nsplit > 1) {
         if (q0 + r < Lq) {
             const float inv = 1.0f / lsum;
             const size_t row = (size_t)b * Lq + q0 + r, rows = (size_t)gridDim.z * Lq;
-            float* orow = po + ((size_t)split * rows + row) * (gridDim.y * 128) + head * 128;
+            float* orow = po + ((size_t)split * rows + row) * (gridDim.y * HD) + head * HD;
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
+            for (int d = 0; d < DT_; ++d)
 #pragma unroll
                 for (int i4 = 0; i4 < 4; ++i4)
-                    *reinterpret_cast<f32x4*>(orow + 32 * d + 8 * i4 + 4 * h) =
-                        f32x4{ot[d][4 * i4] * inv, ot[d][4 * i4 + 1] * inv, ot[d][4 * i4 + 2] * inv, ot[d][4 * i4 + 3] * inv};
+                    if (32 * d + 8 * i4 + 4 * h < HD)
+                        *reinterpret_cast<f32x4*>(orow + 32 * d + 8 * i4 + 4 * h) =
+                            f32x4{ot[d][4 * i4] * inv, ot[d][4 * i4 + 1] * inv, ot[d][4 * i4 + 2] * inv, ot[d][4 * i4 + 3] * inv};
             if (h == 0) plse[((size_t)split * rows + row) * gridDim.y + head] = m * scale_log2e + __builtin_amdgcn_logf(lsum);
         }
         return;
     }
     if (q0 + r < Lq) {
         const float inv = 1.0f / lsum;
-        __bf16* orow = out + (size_t)b * o_bs + (size_t)(q0 + r) * ldo + head * 128;
+        __bf16* orow = out + (size_t)b * o_bs + (size_t)(q0 + r) * ldo + head * HD;
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+        for (int d = 0; d < DT_; ++d)
 #pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-                const bf16x4 o4 = {(__bf16)(ot[d][4 * i4] * inv), (__bf16)(ot[d][4 * i4 + 1] * inv), (__bf16)(ot[d][4 * i4 + 2] * inv),
-                                   (__bf16)(ot[d][4 * i4 + 3] * inv)};
-                *reinterpret_cast<bf16x4*>(orow + 32 * d + 8 * i4 + 4 * h) = o4;
-            }
+            for (int i4 = 0; i4 < 4; ++i4)
+                if (32 * d + 8 * i4 + 4 * h < HD) {
+                    const bf16x4 o4 = {(__bf16)(ot[d][4 * i4] * inv), (__bf16)(ot[d][4 * i4 + 1] * inv), (__bf16)(ot[d][4 * i4 + 2] * inv),
+                                       (__bf16)(ot[d][4 * i4 + 3] * inv)};
+                    *reinterpret_cast<bf16x4*>(orow + 32 * d + 8 * i4 + 4 * h) = o4;
+                }
     }
 }
 
 // out[row][c] = sum_s w_s po[s][row][c] / sum_s w_s,  w_s = 2^(plse[s][row][head(c)] - max_s): the merge of fa128_kernel's key splits
 __global__ void fa128_combine_kernel(const float* __restrict__ po, const float* __restrict__ plse, __bf16* __restrict__ out, int ldo,
-                                     int64_t o_bs, int64_t rows, int Lq, int heads, int nsplit) {
+                                     int64_t o_bs, int64_t rows, int Lq, int heads, int nsplit, int hd) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (row, 4 consecutive columns)
-    const int D4 = heads * 32;
+    const int D4 = heads * hd / 4;
     if (i >= rows * D4) return;
     const int64_t row = i / D4;
-    const int c = (int)(i - row * D4) * 4, head = c >> 7;
+    const int c = (int)(i - row * D4) * 4, head = c / hd;
     float mx = -INFINITY;
     for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, plse[((size_t)s * rows + row) * heads + head]);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float ws = 0.f;
     for (int s = 0; s < nsplit; ++s) {
         const float w = __builtin_amdgcn_exp2f(plse[((size_t)s * rows + row) * heads + head] - mx);
-        acc += w * *reinterpret_cast<const f32x4*>(po + ((size_t)s * rows + row) * (heads * 128) + c);
+        acc += w * *reinterpret_cast<const f32x4*>(po + ((size_t)s * rows + row) * (heads * hd) + c);
         ws += w;
     }
     const float inv = 1.0f / ws;
@@ -426,9 +450,9 @@ int launch_rms_rope(int D, const void* src, int ld_src, const float* w, float ep
 // partial outputs and log-sum-exps: fa128_scratch_bytes(B, heads, Lq).
 constexpr int FA_MAX_SPLIT = 8;
 size_t fa128_scratch_bytes(int B, int heads, int Lq) { return (size_t)FA_MAX_SPLIT * B * Lq * ((size_t)heads * 128 + heads) * 4 + 256; }
-int launch_fa128(const void* q, int ldq, int64_t q_bs, const void* k, const void* v, int ldk, int64_t kv_bs, void* out, int ldo, int64_t o_bs,
-                 int B, int heads, int Lq, int Lkv, hipStream_t s, void* scratch) {
-    if (Lq <= 0 || Lkv <= 0 || (ldq % 8) || (ldk % 8) || (ldo % 4)) return (int)hipErrorInvalidValue;
+int launch_fa(int hd, const void* q, int ldq, int64_t q_bs, const void* k, const void* v, int ldk, int64_t kv_bs, void* out, int ldo, int64_t o_bs,
+              int B, int heads, int Lq, int Lkv, hipStream_t s, void* scratch) {
+    if ((hd != 128 && hd != 72) || Lq <= 0 || Lkv <= 0 || (ldq % 8) || (ldk % 8) || (ldo % 4)) return (int)hipErrorInvalidValue;
     const int qtiles = (Lq + 127) / 128, ktiles = (Lkv + 31) / 32;
     const long long base = (long long)qtiles * heads * B, slots = 256 * 3;
     int nsplit = 1;
@@ -441,25 +465,35 @@ int launch_fa128(const void* q, int ldq, int64_t q_bs, const void* k, const void
         }
     }
     float* po = (float*)scratch;
-    float* plse = po ? po + (size_t)FA_MAX_SPLIT * B * Lq * heads * 128 : nullptr;
+    float* plse = po ? po + (size_t)FA_MAX_SPLIT * B * Lq * heads * hd : nullptr;
     dim3 g(qtiles * nsplit, heads, B);
     static int minw = -1;  // waves per SIMD the kernel is compiled for (register budget 168 | 256): FASTGEN_AMD_FA_WAVES = 3 (default) | 2
     if (minw < 0) {
         const char* e = getenv("FASTGEN_AMD_FA_WAVES");
         minw = (e && e[0] == '2') ? 2 : 3;
     }
-    if (minw == 3)
-        hipLaunchKernelGGL(fa128_kernel<3>, g, dim3(256), 32768, s, (const __bf16*)q, ldq, q_bs, (const __bf16*)k, (const __bf16*)v, ldk, kv_bs,
-                           (__bf16*)out, ldo, o_bs, Lq, Lkv, 1.44269504088896341f / sqrtf(128.0f), nsplit, po, plse);
-    else
-        hipLaunchKernelGGL(fa128_kernel<2>, g, dim3(256), 32768, s, (const __bf16*)q, ldq, q_bs, (const __bf16*)k, (const __bf16*)v, ldk, kv_bs,
-                           (__bf16*)out, ldo, o_bs, Lq, Lkv, 1.44269504088896341f / sqrtf(128.0f), nsplit, po, plse);
+    const float sc = 1.44269504088896341f / sqrtf((float)hd);
+#define FA_GO(HD, MW, LDS)                                                                                                                  \
+    hipLaunchKernelGGL((fa_kernel<HD, MW>), g, dim3(256), LDS, s, (const __bf16*)q, ldq, q_bs, (const __bf16*)k, (const __bf16*)v, ldk, kv_bs, \
+                       (__bf16*)out, ldo, o_bs, Lq, Lkv, sc, nsplit, po, plse)
+    if (hd == 128) {
+        if (minw == 3) FA_GO(128, 3, 32768);
+        else FA_GO(128, 2, 32768);
+    } else {
+        if (minw == 3) FA_GO(72, 3, 2 * (2 * 32 * 144 + 256));
+        else FA_GO(72, 2, 2 * (2 * 32 * 144 + 256));
+    }
+#undef FA_GO
     if (nsplit > 1) {
-        const int64_t rows = (int64_t)B * Lq, n = rows * heads * 32;
+        const int64_t rows = (int64_t)B * Lq, n = rows * heads * hd / 4;
         hipLaunchKernelGGL(fa128_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, po, plse, (__bf16*)out, ldo, o_bs, rows, Lq,
-                           heads, nsplit);
+                           heads, nsplit, hd);
     }
     WAN_RET();
+}
+int launch_fa128(const void* q, int ldq, int64_t q_bs, const void* k, const void* v, int ldk, int64_t kv_bs, void* out, int ldo, int64_t o_bs,
+                 int B, int heads, int Lq, int Lkv, hipStream_t s, void* scratch) {
+    return launch_fa(128, q, ldq, q_bs, k, v, ldk, kv_bs, out, ldo, o_bs, B, heads, Lq, Lkv, s, scratch);
 }
 int launch_wan_final(int D, const void* x, const float* mod, const float* w, const float* bias, float* out, int ntok, int Fr, int gh, int gw, int C,
                      float eps, hipStream_t s) {

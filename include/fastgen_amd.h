@@ -364,10 +364,12 @@ FG_API int fg_op_images_to_u8(const float* images, uint8_t* out, int64_t batch, 
                        void* stream);
 /* Standard normal draws: Philox4x32-10(key = seed, counter = (offset, index/4)) + Box-Muller. */
 FG_API int fg_op_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, void* stream);
-/* softmax(q k^T / sqrt(128)) v per (batch, head), head dim 128, bf16 tensors q / out [batch, lq, heads * 128], k / v
- * [batch, lkv, heads * 128], fp32 softmax (wan.hip fa128_kernel: the causal video DiT's KV-cache and text attention,
- * fastgen/networks/Wan/network_causal.py:331-412).  Exposed for the parity tests. */
-FG_API int fg_op_attention128(const void* q, const void* k, const void* v, void* out, int batch, int heads, int lq, int lkv, void* stream);
+/* softmax(q k^T / sqrt(head_dim)) v per (batch, head), head_dim 128 or 72, bf16 tensors q / out [batch, lq, heads * head_dim], k / v
+ * [batch, lkv, heads * head_dim], fp32 online softmax (wan.hip fa_kernel: the causal video DiT's KV-cache and text attention,
+ * fastgen/networks/Wan/network_causal.py:331-412, and DiT-XL/2's 16 x 72 attention, fastgen/networks/DiT/network.py:168,191).
+ * Exposed for the parity tests. */
+FG_API int fg_op_attention(const void* q, const void* k, const void* v, void* out, int batch, int heads, int head_dim, int lq, int lkv,
+                           void* stream);
 /* The transformer blocks' token GEMM in the bf16 compute mode (gemm.hip; reference: the nn.Linear calls of DiTBlock,
  * fastgen/networks/DiT/network.py:168-198, under bf16 autocast): out[m][n] = resid[m][n] + gate[(m / gate_rows) * gate_stride + n] *
  * act(sum_k a[m][k] w[n][k] + bias[n]) with a [m][k], w [n][k], resid / out [m][n] in bf16, fp32 accumulation, bias / gate fp32;
