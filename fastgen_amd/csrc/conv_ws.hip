@@ -60,8 +60,11 @@ __device__ __forceinline__ void ws_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// TRANSPOSED product (A operand = weights [16 ch x 32 k], B operand = activations [32 k x 16 px]; both operands have the same lane
+// layout, so this is just the argument order): a lane ends with 4 CONSECUTIVE channels of one pixel and the hand-off is 32
+// ds_write_b128 per lane and tile instead of 128 ds_write_b32 (the structure proven in conv_ws3.hip)
 __device__ __forceinline__ void mma32(f32x4& acc, const Frag8<__bf16>& a, const Frag8<__bf16>& b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.v, a.v, acc, 0, 0, 0);
 }
 
 // ABL: compile-time ablation mask for scripts/conv_ablate.py (0 in production): 1 no staging, 2 no retire (drain),
@@ -120,8 +123,6 @@ __global__ __launch_bounds__(WS_NTHR) void conv3_ws_kernel(const ConvArgs a, con
             for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         const int lane_off = g * G::PLANE + col * WS_PA;
-        // hand-off address of this lane's accumulator column: pixel (row mt, column 4 g + i), channel wave*64 + nt*16 + col
-        const int dl = g * 4096 + (wave * 64 + col) * 4;
 
         ws_barrier();  // step 0 is staged
         int c = 0;
@@ -168,12 +169,14 @@ __global__ __launch_bounds__(WS_NTHR) void conv3_ws_kernel(const ConvArgs a, con
 #pragma unroll
                 for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            *reinterpret_cast<float*>(dbuf + (mt * 16 + i) * 1024 + nt * 64 + dl) = acc[mt][nt][i];
-                            acc[mt][nt][i] = 0.f;
-                        }
+                    for (int nt = 0; nt < 4; ++nt) {
+                        // this lane's quad: pixel (row mt, column col), channels wave*64 + nt*16 + 4 g .. +3 = 16-byte slot
+                        // wave*16 + nt*4 + g of the pixel's 1 KiB row, XOR-ed with col & 7: the 8 lanes of a ds_write_b128 group
+                        // (8 pixels, 1 KiB apart) land on 8 different slots; the producers read slot q of pixel p at q ^ (p & 7)
+                        const int slot = ((wave * 16 + nt * 4 + g) ^ (col & 7)) << 4;
+                        *reinterpret_cast<f32x4*>(dbuf + mt * 16384 + col * 1024 + slot) = acc[mt][nt];
+                        acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
             }
             c = cn;
             ws_barrier();
@@ -312,7 +315,8 @@ __global__ __launch_bounds__(WS_NTHR) void conv3_ws_kernel(const ConvArgs a, con
 #pragma unroll
         for (int j = 0; j < WS_QJ; ++j) {
             dv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (!(ABL & 64)) dv[j] = *reinterpret_cast<const f32x4*>(dsrc + j * 4096 + (q << 4));
+            // pixel p = part * (128 / NQ) + 4 j + psub: its slots are XOR-ed with p & 7 = ((j & 1) << 2) + psub (128 / NQ is a multiple of 8)
+            if (!(ABL & 64)) dv[j] = *reinterpret_cast<const f32x4*>(dsrc + j * 4096 + ((q ^ (((j & 1) << 2) + psub)) << 4));
         }
 #pragma unroll
         for (int j = 0; j < WS_QJ; ++j) {
