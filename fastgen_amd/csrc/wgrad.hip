@@ -131,47 +131,97 @@ __global__ __launch_bounds__(WG_THREADS, X3 ? 1 : 2) void conv_wgrad_kernel(cons
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    for (int t = t_begin; t < t_end; ++t) {
+    // ---- staging through registers, one tile ahead: the global loads of tile t + 1 are issued before tile t's MFMAs and parked in
+    // LDS behind them (the split-bf16 mode runs ONE workgroup per CU: without this its load -> barrier -> MFMA phases ran
+    // back to back with the matrix pipe idle during every load, profiles/r01_wgrad_pmc.txt: 59 % of the cycles in waits)
+    constexpr int NDY = (TPX * 16) / WG_THREADS;                          // 8-channel pieces of the dY tile per thread
+    constexpr int NA = (HALO * (CI / 8) + WG_THREADS - 1) / WG_THREADS;   // ... of the activation halo (the last one ragged)
+    Frag8<ST> rdy[NDY], ra[NA];
+    bool ain[NA];
+    auto issue = [&](int t) __attribute__((always_inline)) {
         const int n = t / TPI, slot = t - n * TPI;
         const int row0 = (slot / TCOLS) * TH, col0 = (slot % TCOLS) * TW;
-        // ---- park the tiles in LDS as they lie in memory ---------------------------------------------------------
 #pragma unroll
-        for (int i = 0; i < (TPX * WG_CO * 2 / 16) / WG_THREADS; ++i) {  // 4 (8) x 16 bytes per thread
+        for (int i = 0; i < NDY; ++i) {
             const int c = tid + WG_THREADS * i;
             const int k = c >> 4, ch = c & 15;  // 16 chunks of 8 channels per pixel
             const int y = row0 + k / TW, x = col0 + k % TW;
-            const ST* src = dy + ((size_t)(n * W + y) * W + x) * Cout + cob + ch * 8;
+            rdy[i] = load_frag(dy + ((size_t)(n * W + y) * W + x) * Cout + cob + ch * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int c = min(tid + WG_THREADS * i, HALO * (CI / 8) - 1);
+            const int hp = c / (CI / 8), ch = c % (CI / 8);
+            const int y = row0 + hp / HW_ - PAD, x = col0 + hp % HW_ - PAD;
+            ain[i] = y >= 0 && y < W && x >= 0 && x < W;
+            ra[i] = load_frag(act + ((size_t)(n * W + (ain[i] ? y : 0)) * W + (ain[i] ? x : 0)) * Cin + ci0 + ch * 8);
+        }
+    };
+    auto park = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) {
+            const int c = tid + WG_THREADS * i;
+            const int k = c >> 4, ch = c & 15;
             if constexpr (X3) {
                 float v[8];
-                widen8(load_frag(src), v);
+                widen8(rdy[i], v);
                 bf16x8 hi, lo;
                 split8(v, hi, lo);
                 *reinterpret_cast<bf16x8*>(s_dy + k * WG_DYP + ch * 16) = hi;
                 *reinterpret_cast<bf16x8*>(s_dy + LO + k * WG_DYP + ch * 16) = lo;
             } else {
-                *reinterpret_cast<uint4*>(s_dy + k * WG_DYP + ch * 16) = *reinterpret_cast<const uint4*>(src);
+                *reinterpret_cast<bf16x8*>(s_dy + k * WG_DYP + ch * 16) = rdy[i].v;
             }
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int c = tid + WG_THREADS * i;
+            if (c < HALO * (CI / 8)) {
+                const int hp = c / (CI / 8), ch = c % (CI / 8);
+                if constexpr (X3) {
+                    float v[8];
+                    widen8(ra[i], v);
+                    bf16x8 hi, lo;
+                    split8(v, hi, lo);
+                    if (!ain[i]) hi = lo = bf16x8{};
+                    *reinterpret_cast<bf16x8*>(s_a + hp * WG_AP + ch * 16) = hi;
+                    *reinterpret_cast<bf16x8*>(s_a + LO + hp * WG_AP + ch * 16) = lo;
+                } else {
+                    *reinterpret_cast<bf16x8*>(s_a + hp * WG_AP + ch * 16) = ain[i] ? ra[i].v : bf16x8{};
+                }
+            }
+        }
+    };
+    // (the bf16 3x3 kernel runs two workgroups per CU inside a 256-register budget: no room for a tile in flight - and its second
+    // workgroup already covers the loads)
+    constexpr bool PREF = X3 || KS == 1;
+    if (PREF && t_begin < t_end) issue(t_begin);
+    // the unpipelined form: every piece goes global -> LDS on its own (no tile's worth of registers held)
+    auto stage_direct = [&](int t) __attribute__((always_inline)) {
+        const int n = t / TPI, slot = t - n * TPI;
+        const int row0 = (slot / TCOLS) * TH, col0 = (slot % TCOLS) * TW;
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) {
+            const int c = tid + WG_THREADS * i;
+            const int k = c >> 4, ch = c & 15;
+            const int y = row0 + k / TW, x = col0 + k % TW;
+            *reinterpret_cast<uint4*>(s_dy + k * WG_DYP + ch * 16) =
+                *reinterpret_cast<const uint4*>(dy + ((size_t)(n * W + y) * W + x) * Cout + cob + ch * 8);
         }
         for (int c = tid; c < HALO * (CI / 8); c += WG_THREADS) {
             const int hp = c / (CI / 8), ch = c % (CI / 8);
             const int y = row0 + hp / HW_ - PAD, x = col0 + hp % HW_ - PAD;
             const bool in = y >= 0 && y < W && x >= 0 && x < W;
-            const ST* src = act + ((size_t)(n * W + (in ? y : 0)) * W + (in ? x : 0)) * Cin + ci0 + ch * 8;
-            if constexpr (X3) {
-                float v[8];
-                widen8(load_frag(src), v);
-                bf16x8 hi, lo;
-                split8(v, hi, lo);
-                if (!in) hi = lo = bf16x8{};
-                *reinterpret_cast<bf16x8*>(s_a + hp * WG_AP + ch * 16) = hi;
-                *reinterpret_cast<bf16x8*>(s_a + LO + hp * WG_AP + ch * 16) = lo;
-            } else {
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (in) v = *reinterpret_cast<const uint4*>(src);
-                *reinterpret_cast<uint4*>(s_a + hp * WG_AP + ch * 16) = v;
-            }
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (in) v = *reinterpret_cast<const uint4*>(act + ((size_t)(n * W + y) * W + x) * Cin + ci0 + ch * 8);
+            *reinterpret_cast<uint4*>(s_a + hp * WG_AP + ch * 16) = v;
         }
+    };
+    for (int t = t_begin; t < t_end; ++t) {
+        if constexpr (PREF) park();
+        else stage_direct(t);
         __syncthreads();
+        if (PREF && t + 1 < t_end) issue(t + 1);
         // ---- k-steps x taps MFMAs ------------------------------------------------------------------------------------
         if constexpr (ROLL) {
             // Tap (ky, kx) of tile row s reads halo row s + ky shifted by kx: the same fragment serves (s, ky), (s+1, ky-1) and
