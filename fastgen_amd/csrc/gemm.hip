@@ -45,11 +45,12 @@ __device__ __forceinline__ void gm_barrier() {
 }
 
 __device__ __forceinline__ float gm_gelu_tanh(float x) {
-    // torch.nn.GELU(approximate="tanh") (DiT/network.py:176); tanh(u) = 1 - 2 / (1 + e^{2u}) on v_exp / v_rcp (bf16 mode)
-    const float u = 0.7978845608028654f * fmaf(0.044715f * x, x * x, x);
-    const float e = __builtin_amdgcn_exp2f(2.0f * 1.44269504088896341f * u);
-    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
-    return 0.5f * x * (1.0f + t);
+    // torch.nn.GELU(approximate="tanh") (DiT/network.py:176): 0.5 x (1 + tanh(u)) = x sigmoid(2 u), u = sqrt(2/pi) (x + 0.044715 x^3),
+    // as x / (1 + 2^(-z)) with z = 2 u log2(e) = x (c0 + c1 x^2): seven VALU operations, two of them transcendental (v_exp / v_rcp, bf16
+    // mode) - the epilogue of the fc1 GEMM evaluates 128 of these per lane and tile
+    constexpr float c0 = 2.0f * 0.7978845608028654f * 1.44269504088896341f, c1 = c0 * 0.044715f;
+    const float z = x * fmaf(x * x, c1, c0);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-z));
 }
 
 enum { GM_EPI_TOK = 0, GM_EPI_HEADS = 1 };
@@ -274,8 +275,8 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_kernel(const GemmArgs a) {
 //   phase 1: read W(t) quarters nt 2,3    issue W rows 128-255 of t+1     phase 3: read X(t+1) m 0-3   issue A rows 0-127 of t+2
 // Fragment reads are inline asm: hipcc orders every compiler-visible LDS read behind ALL pending LDS-DMA (vmcnt(0)), which
 // would serialise the pipeline; the waits here are counted by hand (vmcnt(4) = two half-tiles in flight).
-// Ragged edges: the last token tile / output tile is shifted back to end at M / N (rows recomputed by two tiles store the same
-// values), so M, N >= 256 and out must not alias resid.
+// Ragged edges: the last token tile / output tile is shifted back to end at M / N (M, N >= 256); what it recomputes of its neighbour
+// tile is not stored again.
 #define GM_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
 template <int EPI>
@@ -314,6 +315,13 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         const int q = lt / nx;
         m0 = min((mlo + q) * GM_TM, a.M - GM_TM);
         n0 = min((nlo + (lt - q * nx)) * TN, a.N - TN);
+    };
+    // where the tile would start without the shift: rows / columns below are the neighbour tile's and are not stored again
+    auto tile_keep_from = [&](int i, int& mk, int& nk_) {
+        const int lt = first + min(i, my_tiles - 1) * stride;
+        const int q = lt / nx;
+        mk = (mlo + q) * GM_TM;
+        nk_ = (nlo + (lt - q * nx)) * TN;
     };
     const int nk = a.K / GM_KC;
     const int S = my_tiles * nk;
@@ -420,12 +428,16 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
             }
             return;
         }
-        int m0, n0;
+        int m0, n0, mk, nk_;
         tile_origin(tile, m0, n0);
+        tile_keep_from(tile, mk, nk_);
         const int c8 = n0 + wc * 64 + 32 * NH + 16 * (g & 1) + 8 * (g >> 1);      // after the swap: 8 consecutive outputs
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int row = m0 + wr * 128 + (MH * 4 + m) * 16 + col;
+            // a ragged last tile was shifted back to end at M / N: what it recomputes of its neighbour is not stored again (two
+            // workgroups, usually on two XCDs, writing the same lines cost 20 % at N = 3456 - and an in-place residual stays exact)
+            const bool keep = row >= mk && c8 >= nk_;
             f32x4 ve = acc[MH * 4 + m][NH * 2] + be, vo = acc[MH * 4 + m][NH * 2 + 1] + bo;
             acc[MH * 4 + m][NH * 2] = f32x4{0.f, 0.f, 0.f, 0.f};
             acc[MH * 4 + m][NH * 2 + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -444,6 +456,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
                 ve = f32x4{e0, e1, e2, e3};
                 vo = f32x4{o0, o1, o2, o3};
             }
+            if (!keep) continue;
             if constexpr (EPI == GM_EPI_TOK) {
                 if (a.gate) {
                     const float* grow = a.gate + (size_t)((a.row0 + row) / a.gate_rows) * a.gate_stride + c8;
@@ -701,8 +714,7 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only) {
         b.A = reinterpret_cast<const __bf16*>(a.A) + (size_t)r0 * a.K;
         if (a.out) b.out = reinterpret_cast<__bf16*>(a.out) + (size_t)r0 * a.N;
         if (a.resid) b.resid = reinterpret_cast<const __bf16*>(a.resid) + (size_t)r0 * a.N;
-        // the ping-pong kernel shifts ragged edge tiles back (rows / columns computed twice): not for an in-place residual
-        const bool pp = (a.variant < 0 ? gm_variant() : a.variant) == 1 && b.M >= GM_TM && a.N >= 256 && a.K >= 2 * GM_KC && !(a.resid && a.resid == a.out);
+        const bool pp = (a.variant < 0 ? gm_variant() : a.variant) == 1 && b.M >= GM_TM && a.N >= 256 && a.K >= 2 * GM_KC;
         const int rc = pp ? (heads ? launch_pp<GM_EPI_HEADS>(b, s, false) : launch_pp<GM_EPI_TOK>(b, s, false))
                           : heads ? (n3 ? launch_gm<3, GM_EPI_HEADS>(b, s, false) : launch_gm<4, GM_EPI_HEADS>(b, s, false))
                                   : (n3 ? launch_gm<3, GM_EPI_TOK>(b, s, false) : launch_gm<4, GM_EPI_TOK>(b, s, false));

@@ -13,6 +13,11 @@ ORDERS = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--order=")
 L = _lib.lib()
 p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+_w = torch.randn(8192, 8192, device="cuda").bfloat16()
+for _ in range(50):  # bring the chip to its loaded clock / power state before the first timed shape
+    _w @ _w
+torch.cuda.synchronize()
+del _w
 for name, n, k, act in [("qkv-like 1152->3456", 3456, 1152, 0), ("proj 1152->1152", 1152, 1152, 0), ("fc1 1152->4608 gelu", 4608, 1152, 1),
                         ("fc2 4608->1152", 1152, 4608, 0), ("wan 1536->1536", 1536, 1536, 0), ("wan ffn 1536->8960 gelu", 8960, 1536, 1),
                         ("wan ffn 8960->1536", 1536, 8960, 0)]:
