@@ -53,7 +53,7 @@ __device__ __forceinline__ float gm_gelu_tanh(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-z));
 }
 
-enum { GM_EPI_TOK = 0, GM_EPI_HEADS = 1 };
+enum { GM_EPI_TOK = 0, GM_EPI_HEADS = 1, GM_EPI_RAW = 2 };
 
 template <int NT, int EPI>
 __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_kernel(const GemmArgs a) {
@@ -308,22 +308,27 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         stride = (int)gridDim.x;
         count = Mt * Nt;
     }
-    const int my_tiles = first < count ? (count - first + stride - 1) / stride : 0;
+    // split-K (EPI == GM_EPI_RAW): a work item is (tile, split); the ks splits of a tile are neighbours in the enumeration (same
+    // XCD: they read the same A rows and W rows at different k) and leave fp32 partial sums for gemm_splitk_finish_kernel
+    const int ks = (EPI == GM_EPI_RAW) ? a.ksplit : 1;
+    count *= ks;
+    const int my_tiles = first < count ? (count - first + stride - 1) / stride : 0;  // work items of this workgroup
     if (my_tiles == 0) return;
     auto tile_origin = [&](int i, int& m0, int& n0) {
-        const int lt = first + min(i, my_tiles - 1) * stride;  // (cursors running past the end re-read the last tile)
+        const int lt = (first + min(i, my_tiles - 1) * stride) / ks;  // (cursors running past the end re-read the last tile)
         const int q = lt / nx;
         m0 = min((mlo + q) * GM_TM, a.M - GM_TM);
         n0 = min((nlo + (lt - q * nx)) * TN, a.N - TN);
     };
+    auto item_split = [&](int i) { return (first + min(i, my_tiles - 1) * stride) % ks; };
     // where the tile would start without the shift: rows / columns below are the neighbour tile's and are not stored again
     auto tile_keep_from = [&](int i, int& mk, int& nk_) {
-        const int lt = first + min(i, my_tiles - 1) * stride;
+        const int lt = (first + min(i, my_tiles - 1) * stride) / ks;
         const int q = lt / nx;
         mk = (mlo + q) * GM_TM;
         nk_ = (nlo + (lt - q * nx)) * TN;
     };
-    const int nk = a.K / GM_KC;
+    const int nk = (a.K / GM_KC) / ks;  // K-steps per work item
     const int S = my_tiles * nk;
     const int K2 = a.K * 2;
     // ---- DMA: wave w moves the 8-row groups 2 w, 2 w + 1 of every half-tile; lane -> (row lane >> 3 of the group, LDS octet
@@ -348,8 +353,9 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
     auto cur_set = [&](Cur& c) {
         int m0, n0;
         tile_origin(c.ti, m0, n0);
-        c.sa = (m0 * a.K + c.kk * GM_KC) * 2;
-        c.sw = (n0 * a.K + c.kk * GM_KC) * 2;
+        const int k0 = (item_split(c.ti) * nk + c.kk) * GM_KC;
+        c.sa = (m0 * a.K + k0) * 2;
+        c.sw = (n0 * a.K + k0) * 2;
     };
     auto cur_next = [&](Cur& c) {
         if (++c.kk == nk) c.kk = 0, ++c.ti;
@@ -457,7 +463,11 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
                 vo = f32x4{o0, o1, o2, o3};
             }
             if (!keep) continue;
-            if constexpr (EPI == GM_EPI_TOK) {
+            if constexpr (EPI == GM_EPI_RAW) {
+                float* prow = a.scratch + ((size_t)item_split(tile) * a.M + row) * a.N + c8;
+                *reinterpret_cast<f32x4*>(prow) = ve;
+                *reinterpret_cast<f32x4*>(prow + 4) = vo;
+            } else if constexpr (EPI == GM_EPI_TOK) {
                 if (a.gate) {
                     const float* grow = a.gate + (size_t)((a.row0 + row) / a.gate_rows) * a.gate_stride + c8;
                     ve *= *reinterpret_cast<const f32x4*>(grow);
@@ -564,7 +574,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         }
         // the tile's bias, one K-step ahead of its use: this lane's quads of the four output pairs (own layout, before the swap)
         f32x4 b00 = {0.f, 0.f, 0.f, 0.f}, b01 = b00, b10 = b00, b11 = b00;
-        if (a.bias) {
+        if (a.bias && EPI != GM_EPI_RAW) {
             int m0, n0;
             tile_origin(ti, m0, n0);
             const float* bp = a.bias + n0 + wc * 64 + 4 * g;
@@ -582,6 +592,40 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may land in an LDS allocation this workgroup has given up
     if (wr == 0) asm volatile("s_barrier" ::: "memory");
+}
+
+// out[row][c .. c + 7] = epilogue(sum over the K splits of their fp32 partial sums): bias, tanh-GELU, gate x value + residual as in the
+// kernels' own token epilogue
+__global__ void gemm_splitk_finish_kernel(const GemmArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int N8 = a.N / 8;
+    if (i >= (int64_t)a.M * N8) return;
+    const int row = (int)(i / N8), c = (int)(i - (int64_t)row * N8) * 8;
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    for (int s = 0; s < a.ksplit; ++s) {
+        const float* p = a.scratch + ((size_t)s * a.M + row) * a.N + c;
+        v0 += *reinterpret_cast<const f32x4*>(p);
+        v1 += *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    if (a.bias) v0 += *reinterpret_cast<const f32x4*>(a.bias + c), v1 += *reinterpret_cast<const f32x4*>(a.bias + c + 4);
+    if (a.act & 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v0[e] = gm_gelu_tanh(v0[e]), v1[e] = gm_gelu_tanh(v1[e]);
+    }
+    if (a.gate) {
+        const float* gr = a.gate + (size_t)((a.row0 + row) / a.gate_rows) * a.gate_stride + c;
+        v0 *= *reinterpret_cast<const f32x4*>(gr);
+        v1 *= *reinterpret_cast<const f32x4*>(gr + 4);
+    }
+    if (a.resid) {
+        const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.resid) + (size_t)row * a.N + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v0[e] += (float)r8[e], v1[e] += (float)r8[4 + e];
+    }
+    bf16x8 o8;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o8[e] = (__bf16)v0[e], o8[4 + e] = (__bf16)v1[e];
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(a.out) + (size_t)row * a.N + c) = o8;
 }
 
 __global__ void cvt_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n) {
@@ -651,7 +695,8 @@ int launch_pp(const GemmArgs& a, hipStream_t s, bool prepare_only) {
     const int Mt = (a.M + GM_TM - 1) / GM_TM, Nt = (a.N + 255) / 256;
     GemmArgs b = a;
     int grid = g_gm_cus[dev];
-    if ((long long)Mt * Nt < grid) grid = Mt * Nt, b.xn = 0;
+    const long long items = (long long)Mt * Nt * (EPI == GM_EPI_RAW ? a.ksplit : 1);
+    if (items < grid) grid = (int)items, b.xn = 0;
     if (grid & 7) b.xn = 0;
     if (b.xn > 0) {
         int xn = 1;
@@ -664,7 +709,24 @@ int launch_pp(const GemmArgs& a, hipStream_t s, bool prepare_only) {
         b.xn = xn;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(GM_NTHR), LDS, s, b);
+    if (EPI == GM_EPI_RAW) {
+        const int64_t n = (int64_t)a.M * (a.N / 8);
+        hipLaunchKernelGGL(gemm_splitk_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, b);
+    }
     return (int)hipGetLastError();
+}
+
+// Split-K for short grids: with fewer 256 x 256 tiles than half the CUs (the video DiT's 4 680-token chunk x 1 536 outputs = 114
+// tiles) the K range of every tile is cut into ks pieces (ks | K / 64, tiles x ks <= CUs) that leave fp32 partial sums in the
+// caller's scratch; a finishing pass sums them and applies the token epilogue.
+int gm_pick_ksplit(const GemmArgs& a, int cus) {
+    if (!a.scratch || a.heads > 0 || (a.N % 8)) return 1;
+    const long long tiles = (long long)((a.M + GM_TM - 1) / GM_TM) * ((a.N + 255) / 256);
+    const int nk = a.K / GM_KC;
+    if (tiles * 2 > cus || nk < 16) return 1;
+    for (int ks = 4; ks >= 2; --ks)
+        if (nk % ks == 0 && tiles * ks <= cus && nk / ks >= 8 && (size_t)ks * a.M * a.N * 4 <= a.scratch_bytes) return ks;
+    return 1;
 }
 
 int gm_env(const char* name, int dflt) {
@@ -701,7 +763,7 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only) {
         int rc;
         if ((rc = launch_gm<4, GM_EPI_TOK>(a, s, true)) || (rc = launch_gm<3, GM_EPI_TOK>(a, s, true)) ||
             (rc = launch_gm<4, GM_EPI_HEADS>(a, s, true)) || (rc = launch_gm<3, GM_EPI_HEADS>(a, s, true)) ||
-            (rc = launch_pp<GM_EPI_TOK>(a, s, true)) || (rc = launch_pp<GM_EPI_HEADS>(a, s, true)))
+            (rc = launch_pp<GM_EPI_TOK>(a, s, true)) || (rc = launch_pp<GM_EPI_HEADS>(a, s, true)) || (rc = launch_pp<GM_EPI_RAW>(a, s, true)))
             return rc;
         return 0;
     }
@@ -715,6 +777,15 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only) {
         if (a.out) b.out = reinterpret_cast<__bf16*>(a.out) + (size_t)r0 * a.N;
         if (a.resid) b.resid = reinterpret_cast<const __bf16*>(a.resid) + (size_t)r0 * a.N;
         const bool pp = (a.variant < 0 ? gm_variant() : a.variant) == 1 && b.M >= GM_TM && a.N >= 256 && a.K >= 2 * GM_KC;
+        if (pp && !heads && rows_max >= a.M) {
+            const int dev = fg_device_slot();
+            b.ksplit = gm_pick_ksplit(b, dev >= 0 && g_gm_cus[dev] ? g_gm_cus[dev] : 256);
+            if (b.ksplit > 1) {
+                const int rc2 = launch_pp<GM_EPI_RAW>(b, s, false);
+                if (rc2) return rc2;
+                continue;
+            }
+        }
         const int rc = pp ? (heads ? launch_pp<GM_EPI_HEADS>(b, s, false) : launch_pp<GM_EPI_TOK>(b, s, false))
                           : heads ? (n3 ? launch_gm<3, GM_EPI_HEADS>(b, s, false) : launch_gm<4, GM_EPI_HEADS>(b, s, false))
                                   : (n3 ? launch_gm<3, GM_EPI_TOK>(b, s, false) : launch_gm<4, GM_EPI_TOK>(b, s, false));

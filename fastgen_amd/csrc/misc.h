@@ -149,6 +149,9 @@ struct GemmArgs {
     void *q = nullptr, *k = nullptr, *vt = nullptr;
     int heads = 0, head_dim = 0, T = 0;
     int row0 = 0;  // global index of row 0 (set by the launcher when it cuts M into pieces below the 2 GiB buffer-offset range)
+    float* scratch = nullptr;     // optional fp32 scratch for split-K partial sums (short grids; see gemm.hip gm_pick_ksplit)
+    size_t scratch_bytes = 0;
+    int ksplit = 1;               // set by the launcher
     int variant = -1;  // -1: default (env FASTGEN_AMD_GEMM_PP, 1 unless set to 0); 0 register-staged kernel; 1 LDS-DMA ping-pong kernel
     int xn = 1;    // 0: linear tile order; 1: XCD-aware order, split chosen by the launcher; 2 / 4 / 8: that many XCD columns over N
 };

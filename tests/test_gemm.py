@@ -76,6 +76,24 @@ def test_epilogues(order):
     assert (out.float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-3
 
 
+@pytest.mark.parametrize("m,n,k", [(4680, 1536, 1536), (4680, 1536, 8960), (1000, 512, 2048), (256, 256, 1024)])
+def test_split_k_on_short_grids(m, n, k):
+    """The video DiT's one-sample chunk: 4 680 tokens x 1 536 outputs = 114 tiles for 256 CUs; with scratch the launcher cuts K."""
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g).bfloat16().cuda()
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).bfloat16().cuda()
+    bias = torch.randn(n, generator=g).cuda()
+    rows = 1560
+    gate = torch.randn((m + rows - 1) // rows, n, generator=g).cuda()
+    resid = torch.randn(m, n, generator=g).bfloat16().cuda()
+    want = _ref(a, w, bias, gate=gate, gate_rows=rows, resid=resid)
+    got = _run(a, w, bias, gate=gate, gate_rows=rows, resid=resid, order=64 + 32 + 1)
+    assert (got.float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-3
+    want = _ref(a, w, bias, act=1)
+    got = _run(a, w, bias, act=1, order=64 + 1)
+    assert (got.float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-3
+
+
 def test_unsupported_shapes_are_refused():
     from fastgen_amd import _lib
 
