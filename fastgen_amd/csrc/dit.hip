@@ -74,6 +74,30 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const ST* __restrict__
     }
 }
 
+// the same with y written as [hi | lo] bf16 planes ([ntok][2 D]: the A operand of the split-bf16 token GEMM, gemm.hip launch_gemm_x3)
+template <int D>
+__global__ __launch_bounds__(256) void ln_modulate_split_kernel(const float* __restrict__ x, const float* __restrict__ mod, int mod_stride,
+                                                                int shift_off, int scale_off, __bf16* __restrict__ y, int ntok, int tpi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= ntok) return;
+    const int n = tok / tpi;
+    float v[D / 64];
+    ln_token<float, D>(x + (size_t)tok * D, lane, v);
+    const float* mrow = mod + (size_t)n * mod_stride;
+#pragma unroll
+    for (int j = 0; j < D / 128; ++j) {
+        const int c = 2 * lane + 128 * j;
+        const f32x2 sc = ld2(mrow + scale_off + c), sh = ld2(mrow + shift_off + c);
+        const float a = fmaf(v[2 * j], 1.0f + sc[0], sh[0]), b = fmaf(v[2 * j + 1], 1.0f + sc[1], sh[1]);
+        const bf16x2 hi = {(__bf16)a, (__bf16)b};
+        const bf16x2 lo = {(__bf16)(a - (float)hi[0]), (__bf16)(b - (float)hi[1])};
+        *reinterpret_cast<bf16x2*>(y + (size_t)tok * 2 * D + c) = hi;
+        *reinterpret_cast<bf16x2*>(y + (size_t)tok * 2 * D + D + c) = lo;
+    }
+}
+
 // OutputProjection + unpatchify: out[n][c][gy p + py][gx p + px] = b[o] + sum_d W[o][d] y[d],  o = (py p + px) C + c,
 // y = LN(x) (1 + scale) + shift with {shift, scale} = mod[n][0:D], mod[n][D:2D]  (chunk order of :220)
 template <typename ST, int D>
@@ -389,6 +413,20 @@ int final_d(int D, const void* x, const float* mod, const float* w, const float*
 
 }  // namespace
 
+int launch_dit_ln_modulate_split(int D, const float* x, const float* mod, int mod_stride, int shift_off, int scale_off, void* y, int ntok,
+                                 int tokens_per_image, hipStream_t s) {
+    dim3 g((ntok + 3) / 4), b(256);
+#define LNS(DD) hipLaunchKernelGGL((ln_modulate_split_kernel<DD>), g, b, 0, s, x, mod, mod_stride, shift_off, scale_off, (__bf16*)y, ntok, tokens_per_image)
+    switch (D) {
+        case 384: LNS(384); break;
+        case 768: LNS(768); break;
+        case 1024: LNS(1024); break;
+        case 1152: LNS(1152); break;
+        default: return (int)hipErrorInvalidValue;
+    }
+#undef LNS
+    DIT_RET();
+}
 // dtype: storage of the token tensors (1 bf16, 0 fp32)
 int launch_dit_ln_modulate(int dtype, int D, const void* x, const float* mod, int mod_stride, int shift_off, int scale_off, void* y,
                            int ntok, int tokens_per_image, hipStream_t s) {

@@ -53,7 +53,7 @@ __device__ __forceinline__ float gm_gelu_tanh(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-z));
 }
 
-enum { GM_EPI_TOK = 0, GM_EPI_HEADS = 1, GM_EPI_RAW = 2 };
+enum { GM_EPI_TOK = 0, GM_EPI_HEADS = 1, GM_EPI_RAW = 2, GM_EPI_TOK32 = 3, GM_EPI_SPLIT = 4, GM_EPI_HEADS32 = 5 };
 
 template <int NT, int EPI>
 __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_kernel(const GemmArgs a) {
@@ -330,21 +330,29 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
     };
     const int nk = (a.K / GM_KC) / ks;  // K-steps per work item
     const int S = my_tiles * nk;
-    const int K2 = a.K * 2;
+    // row pitches in bytes (split-bf16 flavour: A rows hold [hi | lo] = 2 K1 elements, W rows [hi | lo | hi] = 3 K1 = K elements)
+    const int KA2 = (a.lda ? a.lda : a.K) * 2, KW2 = (a.ldw ? a.ldw : a.K) * 2;
     // ---- DMA: wave w moves the 8-row groups 2 w, 2 w + 1 of every half-tile; lane -> (row lane >> 3 of the group, LDS octet
     // position lane & 7, which holds k-octet position ^ ((row >> 1) & 7)) ------------------------------------------------
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.A), rsW = make_rsrc(a.W);
-    unsigned voff[2];
+    unsigned voffA[2], voffW[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = (wave * 2 + j) * 8 + (lane >> 3);
-        voff[j] = (unsigned)row * (unsigned)K2 + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+        const unsigned sw = (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+        voffA[j] = (unsigned)row * (unsigned)KA2 + sw;
+        voffW[j] = (unsigned)row * (unsigned)KW2 + sw;
     }
     // regions of buffer b: A half h at b * 65536 + h * 16384, W half h at b * 65536 + 32768 + h * 16384
-    auto dma = [&](const __amdgpu_buffer_rsrc_t& rs, int region, int soff) {
+    auto dmaA = [&](int region, int soff) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(smem + region + (wave * 2 + j) * 1024), 16, voff[j], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(smem + region + (wave * 2 + j) * 1024), 16, voffA[j], soff, 0, 0);
+    };
+    auto dmaW = [&](int region, int soff) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(smem + region + (wave * 2 + j) * 1024), 16, voffW[j], soff, 0, 0);
     };
     // cursors over the flat K-steps t + 1 and t + 2: scalar byte offsets of their A / W tiles' first row at their k
     struct Cur {
@@ -353,9 +361,10 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
     auto cur_set = [&](Cur& c) {
         int m0, n0;
         tile_origin(c.ti, m0, n0);
-        const int k0 = (item_split(c.ti) * nk + c.kk) * GM_KC;
-        c.sa = (m0 * a.K + k0) * 2;
-        c.sw = (n0 * a.K + k0) * 2;
+        const int ks_ = item_split(c.ti) * nk + c.kk;                       // K-step of the (virtual) contraction
+        const int ka = (a.a_wrap && ks_ >= a.a_wrap) ? ks_ - a.a_wrap : ks_;  // split-bf16: A' = [hi | hi | lo] read out of [hi | lo]
+        c.sa = m0 * KA2 + ka * (GM_KC * 2);
+        c.sw = n0 * KW2 + ks_ * (GM_KC * 2);
     };
     auto cur_next = [&](Cur& c) {
         if (++c.kk == nk) c.kk = 0, ++c.ti;
@@ -447,7 +456,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
             f32x4 ve = acc[MH * 4 + m][NH * 2] + be, vo = acc[MH * 4 + m][NH * 2 + 1] + bo;
             acc[MH * 4 + m][NH * 2] = f32x4{0.f, 0.f, 0.f, 0.f};
             acc[MH * 4 + m][NH * 2 + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (EPI == GM_EPI_TOK && (a.act & 1)) {
+            if ((EPI == GM_EPI_TOK || EPI == GM_EPI_SPLIT || EPI == GM_EPI_TOK32) && (a.act & 1)) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ve[e] = gm_gelu_tanh(ve[e]), vo[e] = gm_gelu_tanh(vo[e]);
             }
@@ -463,7 +472,58 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
                 vo = f32x4{o0, o1, o2, o3};
             }
             if (!keep) continue;
-            if constexpr (EPI == GM_EPI_RAW) {
+            if constexpr (EPI == GM_EPI_TOK32 || EPI == GM_EPI_SPLIT) {
+                // split-bf16 flavour: fp32 gate / residual arithmetic; out fp32 [M][N] (TOK32) or [hi | lo] bf16 planes [M][2 N], the
+                // next GEMM's A operand (SPLIT)
+                if (a.gate) {
+                    const float* grow = a.gate + (size_t)((a.row0 + row) / a.gate_rows) * a.gate_stride + c8;
+                    ve *= *reinterpret_cast<const f32x4*>(grow);
+                    vo *= *reinterpret_cast<const f32x4*>(grow + 4);
+                }
+                if (a.resid) {
+                    const float* rr = reinterpret_cast<const float*>(a.resid) + (size_t)row * a.N + c8;
+                    ve += *reinterpret_cast<const f32x4*>(rr);
+                    vo += *reinterpret_cast<const f32x4*>(rr + 4);
+                }
+                if constexpr (EPI == GM_EPI_TOK32) {
+                    float* orow = reinterpret_cast<float*>(a.out) + (size_t)row * a.N + c8;
+                    *reinterpret_cast<f32x4*>(orow) = ve;
+                    *reinterpret_cast<f32x4*>(orow + 4) = vo;
+                } else {
+                    bf16x8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hi[e] = (__bf16)ve[e], hi[4 + e] = (__bf16)vo[e];
+                        lo[e] = (__bf16)(ve[e] - (float)hi[e]), lo[4 + e] = (__bf16)(vo[e] - (float)hi[4 + e]);
+                    }
+                    __bf16* orow = reinterpret_cast<__bf16*>(a.out) + (size_t)row * 2 * a.N + c8;
+                    *reinterpret_cast<bf16x8*>(orow) = hi;
+                    *reinterpret_cast<bf16x8*>(orow + a.N) = lo;
+                }
+            } else if constexpr (EPI == GM_EPI_HEADS32) {
+                // head-split q | k [B][H][T][hd] and v^T [B][H][hd][T] as hi / lo bf16 planes lo_off elements apart: the operand layout
+                // of dit_attention_kernel<bf16x3>
+                const int D = a.heads * a.head_dim;
+                const int b = (a.row0 + row) / a.T, t = a.row0 + row - b * a.T;
+                const int plane = c8 / D, within = c8 - plane * D;
+                const int hh = within / a.head_dim, d = within - hh * a.head_dim;
+                const size_t bh = (size_t)b * a.heads + hh;
+                bf16x8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hi[e] = (__bf16)ve[e], hi[4 + e] = (__bf16)vo[e];
+                    lo[e] = (__bf16)(ve[e] - (float)hi[e]), lo[4 + e] = (__bf16)(vo[e] - (float)hi[4 + e]);
+                }
+                if (plane < 2) {
+                    __bf16* dst = reinterpret_cast<__bf16*>(plane ? a.k : a.q) + (bh * a.T + t) * a.head_dim + d;
+                    *reinterpret_cast<bf16x8*>(dst) = hi;
+                    *reinterpret_cast<bf16x8*>(dst + a.lo_off) = lo;
+                } else {
+                    __bf16* vp = reinterpret_cast<__bf16*>(a.vt) + (bh * a.head_dim + d) * a.T + t;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vp[(size_t)e * a.T] = hi[e], vp[(size_t)e * a.T + a.lo_off] = lo[e];
+                }
+            } else if constexpr (EPI == GM_EPI_RAW) {
                 float* prow = a.scratch + ((size_t)item_split(tile) * a.M + row) * a.N + c8;
                 *reinterpret_cast<f32x4*>(prow) = ve;
                 *reinterpret_cast<f32x4*>(prow + 4) = vo;
@@ -509,13 +569,13 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
     // ---- prologue: K-step 0 whole, the two early half-tiles of K-step 1 ------------------------------------------------
     Cur c1{0, 0, 0, 0}, c2{0, 0, 0, 0};
     cur_set(c1);                 // = K-step 0 for now
-    dma(rsA, 0, c1.sa);
-    dma(rsA, 16384, c1.sa + 128 * K2);
-    dma(rsW, 32768, c1.sw);
-    dma(rsW, 49152, c1.sw + 128 * K2);
+    dmaA(0, c1.sa);
+    dmaA(16384, c1.sa + 128 * KA2);
+    dmaW(32768, c1.sw);
+    dmaW(49152, c1.sw + 128 * KW2);
     if (S > 1) cur_next(c1);     // K-step 1
-    dma(rsW, 65536 + 32768, c1.sw);
-    dma(rsA, 65536, c1.sa);
+    dmaW(65536 + 32768, c1.sw);
+    dmaA(65536, c1.sa);
     c2 = c1;
     if (S > 2) cur_next(c2);     // K-step 2
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -529,7 +589,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         const int cb = t & 1, nb = cb ^ 1;
         // phase 0: quadrant (0,0)
         read_w(W0, cb, 0);
-        dma(rsA, nb * 65536 + 16384, c1.sa + 128 * K2);
+        dmaA(nb * 65536 + 16384, c1.sa + 128 * KA2);
         mem_done();
         __builtin_amdgcn_s_setprio(1);
         mma(0, 0, X0, W0);
@@ -537,7 +597,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         cmp_done();
         // phase 1: quadrant (0,1)
         read_w(W1, cb, 1);
-        dma(rsW, nb * 65536 + 49152, c1.sw + 128 * K2);
+        dmaW(nb * 65536 + 49152, c1.sw + 128 * KW2);
         mem_done();
         __builtin_amdgcn_s_setprio(1);
         mma(0, 1, X0, W1);
@@ -545,7 +605,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         cmp_done();
         // phase 2: quadrant (1,1)
         read_x(X1, cb, 1);
-        dma(rsW, cb * 65536 + 32768, c2.sw);
+        dmaW(cb * 65536 + 32768, c2.sw);
         mem_done();
         __builtin_amdgcn_s_setprio(1);
         mma(1, 1, X1, W1);
@@ -553,7 +613,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         cmp_done();
         // phase 3: quadrant (1,0)
         read_x(X0, nb, 0);
-        dma(rsA, cb * 65536, c2.sa);
+        dmaA(cb * 65536, c2.sa);
         mem_done();
         __builtin_amdgcn_s_setprio(1);
         mma(1, 0, X1, W0);
@@ -630,6 +690,31 @@ __global__ void gemm_splitk_finish_kernel(const GemmArgs a) {
 
 __global__ void cvt_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (__bf16)in[i];
+}
+
+// the split-bf16 flavour's operands: W' [N][3 K] = [hi | lo | hi] of the fp32 weight, planes [M][2 K] = [hi | lo] of an fp32 tensor
+__global__ void split3_weights_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int N, int K) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * K) return;
+    const int64_t n = i / K;
+    const int k = (int)(i - n * K);
+    const float v = w[i];
+    const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
+    __bf16* o = out + n * 3 * K;
+    o[k] = hi, o[K + k] = lo, o[2 * K + k] = hi;
+}
+__global__ void split_planes_kernel(const float* __restrict__ x, __bf16* __restrict__ out, int64_t M, int K) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (row, 4 columns)
+    const int K4 = K / 4;
+    if (i >= M * K4) return;
+    const int64_t r = i / K4;
+    const int c = (int)(i - r * K4) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * K + c);
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hi[e] = (__bf16)v[e], lo[e] = (__bf16)(v[e] - (float)hi[e]);
+    *reinterpret_cast<bf16x4*>(out + r * 2 * K + c) = hi;
+    *reinterpret_cast<bf16x4*>(out + r * 2 * K + K + c) = lo;
 }
 
 int g_gm_cus[16] = {};
@@ -763,7 +848,8 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only) {
         int rc;
         if ((rc = launch_gm<4, GM_EPI_TOK>(a, s, true)) || (rc = launch_gm<3, GM_EPI_TOK>(a, s, true)) ||
             (rc = launch_gm<4, GM_EPI_HEADS>(a, s, true)) || (rc = launch_gm<3, GM_EPI_HEADS>(a, s, true)) ||
-            (rc = launch_pp<GM_EPI_TOK>(a, s, true)) || (rc = launch_pp<GM_EPI_HEADS>(a, s, true)) || (rc = launch_pp<GM_EPI_RAW>(a, s, true)))
+            (rc = launch_pp<GM_EPI_TOK>(a, s, true)) || (rc = launch_pp<GM_EPI_HEADS>(a, s, true)) || (rc = launch_pp<GM_EPI_RAW>(a, s, true)) ||
+            (rc = launch_pp<GM_EPI_TOK32>(a, s, true)) || (rc = launch_pp<GM_EPI_SPLIT>(a, s, true)) || (rc = launch_pp<GM_EPI_HEADS32>(a, s, true)))
             return rc;
         return 0;
     }
@@ -797,5 +883,50 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only) {
 int launch_cvt_bf16(const float* in, void* out, size_t n, hipStream_t s) {
     const size_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, s, in, (__bf16*)out, n);
+    return (int)hipGetLastError();
+}
+
+// ---- split-bf16 ("bf16x3", the fp32-grade mode of common.h) on the same kernel -----------------------------------------------
+// sum_k a_k w_k with a = a_hi + a_lo, w = w_hi + w_lo evaluated as a_hi w_hi + a_hi w_lo + a_lo w_hi is ONE bf16 contraction of
+// length 3 K: A' = [a_hi | a_hi | a_lo], W' = [w_hi | w_lo | w_hi].  A is stored as [hi | lo] planes ([M][2 K] bf16, the same bytes
+// as the fp32 tensor; its hi plane is read twice: a_wrap) by the producing kernel (LayerNorm-modulate, the SPLIT epilogue of the
+// previous GEMM, split_planes_kernel), W' once per weight version; fp32 accumulation over all 3 K products, fp32 epilogue.
+// a: M, N, K = the real contraction length; A = planes, W = W'; out: fp32 [M][N] (out_mode 0, + fp32 resid / gate), [hi | lo]
+// planes [M][2 N] (out_mode 1), or head-split hi / lo planes (heads > 0, lo_off).
+int launch_gemm_x3(const GemmArgs& a, int out_mode, hipStream_t s) {
+    if (a.M < GM_TM || a.N < 256 || (a.N % 16) || (a.K % GM_KC) || 3 * a.K < 2 * GM_KC || !a.A || !a.W) return (int)hipErrorInvalidValue;
+    if ((size_t)a.N * 3 * a.K * 2 >= (1ull << 31)) return (int)hipErrorInvalidValue;
+    const int rows_max = (int)(((1ull << 31) - 1) / ((size_t)a.K * 4)) / GM_TM * GM_TM;
+    for (int r0 = 0; r0 < a.M; r0 += rows_max) {
+        GemmArgs b = a;
+        b.row0 = a.row0 + r0;
+        b.M = a.M - r0 < rows_max ? a.M - r0 : rows_max;
+        if (b.M < GM_TM) return (int)hipErrorInvalidValue;  // (a remainder below one tile: not met by the callers' shapes)
+        b.A = reinterpret_cast<const __bf16*>(a.A) + (size_t)r0 * 2 * a.K;
+        b.lda = 2 * a.K, b.ldw = 3 * a.K, b.a_wrap = a.K / GM_KC, b.K = 3 * a.K;
+        b.ksplit = 1, b.scratch = nullptr;
+        if (a.resid) b.resid = reinterpret_cast<const float*>(a.resid) + (size_t)r0 * a.N;
+        int rc;
+        if (a.heads > 0) {
+            rc = launch_pp<GM_EPI_HEADS32>(b, s, false);
+        } else if (out_mode == 1) {
+            b.out = reinterpret_cast<__bf16*>(a.out) + (size_t)r0 * 2 * a.N;
+            rc = launch_pp<GM_EPI_SPLIT>(b, s, false);
+        } else {
+            b.out = reinterpret_cast<float*>(a.out) + (size_t)r0 * a.N;
+            rc = launch_pp<GM_EPI_TOK32>(b, s, false);
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+int launch_split3_weights(const float* w, void* out, int N, int K, hipStream_t s) {
+    const int64_t n = (int64_t)N * K;
+    hipLaunchKernelGGL(split3_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, (__bf16*)out, N, K);
+    return (int)hipGetLastError();
+}
+int launch_split_planes(const float* x, void* out, int64_t M, int K, hipStream_t s) {
+    const int64_t n = M * (K / 4);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, (__bf16*)out, M, K);
     return (int)hipGetLastError();
 }

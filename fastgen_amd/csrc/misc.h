@@ -120,6 +120,9 @@ int launch_stem(int dtype, const float* x, const float* c_in, const void* wpack,
 // dit.hip: the non-GEMM pieces of a DiT forward (reference fastgen/networks/DiT/network.py); dtype = token-tensor storage (1 bf16, 0 fp32)
 int launch_dit_ln_modulate(int dtype, int D, const void* x, const float* mod, int mod_stride, int shift_off, int scale_off, void* y,
                            int ntok, int tokens_per_image, hipStream_t s);
+// fp32 tokens in, y as [hi | lo] bf16 planes [ntok][2 D] (the split-bf16 token GEMM's A operand)
+int launch_dit_ln_modulate_split(int D, const float* x, const float* mod, int mod_stride, int shift_off, int scale_off, void* y, int ntok,
+                                 int tokens_per_image, hipStream_t s);
 int launch_dit_final(int dtype, int D, const void* x, const float* mod, const float* w, const float* bias, float* out, int ntok, int grid,
                      int p, int C, hipStream_t s);
 int launch_dit_patch_embed(int dtype, const float* x, const float* w, const float* bias, const float* pos, void* out, int B, int C, int grid,
@@ -149,6 +152,9 @@ struct GemmArgs {
     void *q = nullptr, *k = nullptr, *vt = nullptr;
     int heads = 0, head_dim = 0, T = 0;
     int row0 = 0;  // global index of row 0 (set by the launcher when it cuts M into pieces below the 2 GiB buffer-offset range)
+    int lda = 0, ldw = 0;         // row pitches in elements when they differ from K (the split-bf16 flavour; set by launch_gemm_x3)
+    int a_wrap = 0;               // ... its A' = [hi | hi | lo] read out of [hi | lo]: K-steps >= a_wrap read a_wrap steps back
+    size_t lo_off = 0;            // ... head-split epilogue: elements from a hi plane to its lo plane
     float* scratch = nullptr;     // optional fp32 scratch for split-K partial sums (short grids; see gemm.hip gm_pick_ksplit)
     size_t scratch_bytes = 0;
     int ksplit = 1;               // set by the launcher
@@ -158,6 +164,12 @@ struct GemmArgs {
 bool gemm_bf16_supported(const GemmArgs& a);
 int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only = false);
 int launch_cvt_bf16(const float* in, void* out, size_t n, hipStream_t s);
+// the same kernel in the split-bf16 (fp32-grade) mode: see gemm.hip.  A = [hi | lo] planes [M][2 K] bf16, W = launch_split3_weights
+// of the fp32 weight ([N][3 K]), fp32 epilogue; out_mode 0: fp32 [M][N] (+ fp32 resid), 1: [hi | lo] planes [M][2 N]; heads > 0: head-split
+// hi / lo planes (q, k, vt + lo_off).  M >= 256, N >= 256, K % 64 == 0.
+int launch_gemm_x3(const GemmArgs& a, int out_mode, hipStream_t s);
+int launch_split3_weights(const float* w, void* out, int N, int K, hipStream_t s);
+int launch_split_planes(const float* x, void* out, int64_t M, int K, hipStream_t s);
 
 // wan.hip: the non-GEMM pieces of the causal video DiT (reference fastgen/networks/Wan/network_causal.py); bf16 token tensors
 int launch_wan_patch_embed(const float* x, const float* w, const float* bias, void* out, int B, int C, int Fr, int H, int W, int D, hipStream_t s);
