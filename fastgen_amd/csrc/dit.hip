@@ -136,10 +136,43 @@ __global__ __launch_bounds__(256) void final_kernel(const ST* __restrict__ x, co
 }
 
 // x0[n][t][d] = bias[d] + pos[t][d] + sum_{c,py,px} W[d][c][py][px] x[n][c][gy p + py][gx p + px]
-template <typename ST>
+// One thread = output dim d of FOUR neighbouring tokens (one patch row segment): its weight row (K = C p p floats, 16-byte loads,
+// consecutive threads = consecutive rows: coalesced) is read once for the four; the tokens' inputs are wave-uniform (broadcast) loads.
+template <typename ST, int K>
 __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                           const float* __restrict__ pos, ST* __restrict__ out, int B, int C, int grid, int p,
                                                           int D) {
+    const int tpi = grid * grid, res = grid * p;
+    const int64_t total = (int64_t)B * (tpi / 4) * D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int d = (int)(i % D);
+        const int64_t tg = i / D;
+        const int t0 = (int)(tg % (tpi / 4)) * 4, n = (int)(tg / (tpi / 4));
+        const int gy = t0 / grid, gx0 = t0 - gy * grid;  // grid % 4 == 0: the four tokens share a patch row
+        float wr[K];
+#pragma unroll
+        for (int k = 0; k < K; k += 4) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(w + (size_t)d * K + k);
+            wr[k] = q[0], wr[k + 1] = q[1], wr[k + 2] = q[2], wr[k + 3] = q[3];
+        }
+        const float bd = bias[d];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = bd + pos[(size_t)(t0 + j) * D + d];
+            int k = 0;
+            for (int c = 0; c < C; ++c)
+                for (int py = 0; py < p; ++py)
+                    for (int px = 0; px < p; ++px, ++k)
+                        a = fmaf(wr[k], x[(((size_t)n * C + c) * res + gy * p + py) * res + (gx0 + j) * p + px], a);
+            out[((size_t)n * tpi + t0 + j) * D + d] = (ST)a;
+        }
+    }
+}
+// (any other K: one thread per output element)
+template <typename ST>
+__global__ __launch_bounds__(256) void patch_embed_any_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                              const float* __restrict__ pos, ST* __restrict__ out, int B, int C, int grid, int p,
+                                                              int D) {
     const int tpi = grid * grid, res = grid * p, K = C * p * p;
     const int64_t total = (int64_t)B * tpi * D;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -439,13 +472,17 @@ int launch_dit_final(int dtype, int D, const void* x, const float* mod, const fl
 }
 int launch_dit_patch_embed(int dtype, const float* x, const float* w, const float* bias, const float* pos, void* out, int B, int C, int grid,
                            int p, int D, hipStream_t s) {
-    const int64_t total = (int64_t)B * grid * grid * D;
+    const bool k16 = C * p * p == 16 && p == 2 && (grid % 4) == 0;  // the reference's configs: 4 latent channels, patch 2
+    const int64_t total = k16 ? (int64_t)B * (grid * grid / 4) * D : (int64_t)B * grid * grid * D;
     const int64_t blocks = (total + 255) / 256;
     dim3 g((unsigned)(blocks > 262144 ? 262144 : blocks));
-    if (dtype)
-        hipLaunchKernelGGL(patch_embed_kernel<__bf16>, g, dim3(256), 0, s, x, w, bias, pos, (__bf16*)out, B, C, grid, p, D);
-    else
-        hipLaunchKernelGGL(patch_embed_kernel<float>, g, dim3(256), 0, s, x, w, bias, pos, (float*)out, B, C, grid, p, D);
+    if (k16) {
+        if (dtype) hipLaunchKernelGGL((patch_embed_kernel<__bf16, 16>), g, dim3(256), 0, s, x, w, bias, pos, (__bf16*)out, B, C, grid, p, D);
+        else hipLaunchKernelGGL((patch_embed_kernel<float, 16>), g, dim3(256), 0, s, x, w, bias, pos, (float*)out, B, C, grid, p, D);
+    } else {
+        if (dtype) hipLaunchKernelGGL(patch_embed_any_kernel<__bf16>, g, dim3(256), 0, s, x, w, bias, pos, (__bf16*)out, B, C, grid, p, D);
+        else hipLaunchKernelGGL(patch_embed_any_kernel<float>, g, dim3(256), 0, s, x, w, bias, pos, (float*)out, B, C, grid, p, D);
+    }
     DIT_RET();
 }
 int launch_dit_fourier(const float* t, float* f, int B, int dim, hipStream_t s) {

@@ -863,7 +863,7 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only) {
         if (a.out) b.out = reinterpret_cast<__bf16*>(a.out) + (size_t)r0 * a.N;
         if (a.resid) b.resid = reinterpret_cast<const __bf16*>(a.resid) + (size_t)r0 * a.N;
         const bool pp = (a.variant < 0 ? gm_variant() : a.variant) == 1 && b.M >= GM_TM && a.N >= 256 && a.K >= 2 * GM_KC;
-        if (pp && !heads && rows_max >= a.M) {
+        if (pp && !heads && !a.out_f32 && rows_max >= a.M) {
             const int dev = fg_device_slot();
             b.ksplit = gm_pick_ksplit(b, dev >= 0 && g_gm_cus[dev] ? g_gm_cus[dev] : 256);
             if (b.ksplit > 1) {
@@ -871,6 +871,12 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only) {
                 if (rc2) return rc2;
                 continue;
             }
+        }
+        if (a.out_f32) {
+            if (!pp || heads || rows_max < a.M) return (int)hipErrorInvalidValue;
+            const int rc3 = launch_pp<GM_EPI_TOK32>(b, s, false);
+            if (rc3) return rc3;
+            continue;
         }
         const int rc = pp ? (heads ? launch_pp<GM_EPI_HEADS>(b, s, false) : launch_pp<GM_EPI_TOK>(b, s, false))
                           : heads ? (n3 ? launch_gm<3, GM_EPI_HEADS>(b, s, false) : launch_gm<4, GM_EPI_HEADS>(b, s, false))

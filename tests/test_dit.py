@@ -100,6 +100,29 @@ def test_forward_against_reference_golden(golden_dir, tag, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag,mode", [("s", "bf16"), ("xl", "bf16"), ("s", "bf16x3")])
+def test_large_batch_paths_against_reference_golden(golden_dir, tag, mode):
+    """Batch 256 takes code the batch-2 fixtures do not reach (bf16: all blocks' conditioning linears as one stacked GEMM; whole
+    256-token tiles of the ping-pong GEMM; DiT-XL: the LDS-staged attention): the golden pair, repeated, must come back."""
+    from fastgen_amd.networks.DiT.network import DiT
+
+    fx = torch.load(os.path.join(golden_dir, "dit_forward_b2.pt"), weights_only=True)
+    dev = torch.device("cuda:0")
+    net = DiT(compute_dtype=mode, **KW[tag])
+    net.load_state_dict(R.random_state_dict(CFGS[tag], seed=77), strict=True)
+    net = net.to(dev).eval()
+    x, t, cond, r = _inputs(fx, tag)
+    rep = 128
+    with torch.inference_mode():
+        out = net(x.repeat(rep, 1, 1, 1).to(dev), t.repeat(rep).to(dev), condition=cond.repeat(rep, 1).to(dev)).cpu()
+    want = fx[f"{tag}/out"]
+    for i in (0, 1, 126, 127):
+        got = out[2 * i: 2 * i + 2]
+        err, rel = float((got - want).abs().max()), float((got - want).norm() / want.norm())
+        assert err <= TOL[mode][0] and rel <= TOL[mode][1], (tag, mode, i, err, rel)
+
+
+@pytest.mark.gpu
 def test_flow_sampler_against_oracle():
     """RF Euler sampler of the reference (`DiT._sample_flow`, :605-651) with classifier-free guidance, 4 steps, DiT-S/2: the module's
     `sample()` on the HIP network against the same loop run on the oracle network."""
