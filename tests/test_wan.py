@@ -122,6 +122,29 @@ def test_autoregressive_calls_against_oracle():
 
 
 @pytest.mark.gpu
+def test_width_of_the_1p3b_network_against_oracle():
+    """Inner dim 1536 (12 heads), MLP 8960: the widths the 1.3B network instantiates (RMSNorm / LayerNorm / output kernels at 12 x 128,
+    whole 256-token GEMM tiles, split-K on the short grids, key-split attention) - two layers, two chunks of two 16 x 16-token frames."""
+    from fastgen_amd.networks.Wan.network_causal import CausalWan
+
+    cfg = R.WanConfig(num_heads=12, head_dim=128, text_dim=256, ffn_dim=8960, num_layers=2, chunk_size=2, total_num_frames=4)
+    sd = R.random_state_dict(cfg, 21)
+    ref = R.CausalWanRef(sd, cfg)
+    net = CausalWan(num_attention_heads=12, attention_head_dim=128, text_dim=256, ffn_dim=8960, num_layers=2, chunk_size=2, total_num_frames=4)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(1, 16, 4, 32, 32, generator=g)
+    text = torch.randn(1, 64, 256, generator=g)
+    with torch.inference_mode():
+        for (lo, hi, t, store) in [(0, 2, 0.0, True), (2, 4, 0.5, False)]:
+            tt = torch.full((1,), t, dtype=torch.float64)
+            want = ref.forward(x[:, :, lo:hi], tt, text, cur_start_frame=lo, store_kv=store)
+            got = net(x[:, :, lo:hi].cuda(), tt.cuda(), condition=text.cuda(), fwd_pred_type="flow", cur_start_frame=lo, store_kv=store, is_ar=True)
+            assert _rel(got.cpu(), want) < 2e-2, (lo, _rel(got.cpu(), want))
+
+
+@pytest.mark.gpu
 def test_causvid_student_loop_against_oracle():
     from fastgen_amd.methods.distribution_matching.causvid import CausVidModel
 
