@@ -90,7 +90,7 @@ __device__ __forceinline__ Frag8<bf16x3> load_vop<bf16x3>(const float* row, int 
 }
 
 template <typename T, int NT>  // NT = T/32 key tiles; T = compute type (common.h), tensors in its storage type
-__global__ __launch_bounds__(256) void attention_kernel(const typename DT<T>::ST* __restrict__ q, const typename DT<T>::ST* __restrict__ k,
+__global__ __launch_bounds__(256, 2) void attention_kernel(const typename DT<T>::ST* __restrict__ q, const typename DT<T>::ST* __restrict__ k,
                                                         const typename DT<T>::ST* __restrict__ vt, typename DT<T>::ST* __restrict__ out, int B) {
     typedef typename DT<T>::ST ST;
     constexpr int Tn = NT * 32;
@@ -146,14 +146,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const typename DT<T>::ST
 #pragma unroll
         for (int i = 0; i < 16; ++i) st[kt][i] = FAST ? st[kt][i] * inv : st[kt][i] / sum;
 
-    // ---- O[query][dim] = sum_key P[query][key] V[key][dim], four 32-wide dim tiles at a time ---------------
+    // ---- O[query][dim] = sum_key P[query][key] V[key][dim], OG 32-wide dim tiles at a time --------------------------------------
+    // (two at a time for the 256-key form: with the 128 registers of S^T and four output tiles the kernel took 386 registers = one
+    // wave per SIMD, and these operand loads straight from global memory need the second wave to hide behind)
+    constexpr int OG = NT >= 8 ? 2 : 4;
     const ST* vbase = vt + ((size_t)n * D + r) * Tn + 4 * h;
     ST* obase = out + ((size_t)n * Tn + q0) * D + r;
 #pragma unroll 1
-    for (int dg = 0; dg < D / 128; ++dg) {
-        f32x16 o[4];
+    for (int dg = 0; dg < D / (32 * OG); ++dg) {
+        f32x16 o[OG];
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+        for (int d = 0; d < OG; ++d)
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
 #pragma unroll
@@ -162,16 +165,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const typename DT<T>::ST
             for (int s = 0; s < 2; ++s) {
                 const Frag8<T> pf = PFrag<T>::make(st[kt], s);
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const Frag8<T> vf = load_vop<T>(vbase + (size_t)(dg * 128 + d * 32) * Tn, kt * 32 + 16 * s);
+                for (int d = 0; d < OG; ++d) {
+                    const Frag8<T> vf = load_vop<T>(vbase + (size_t)(dg * 32 * OG + d * 32) * Tn, kt * 32 + 16 * s);
                     mma16(o[d], pf, vf);
                 }
             }
         }
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+        for (int d = 0; d < OG; ++d)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) obase[(size_t)acc_row(i, h) * D + dg * 128 + d * 32] = (ST)o[d][i];
+            for (int i = 0; i < 16; ++i) obase[(size_t)acc_row(i, h) * D + dg * 32 * OG + d * 32] = (ST)o[d][i];
     }
 }
 
