@@ -320,7 +320,7 @@ __device__ __forceinline__ Frag8<bf16x3> dload_v_planes(const __bf16* row, size_
 
 // QT: element type of q / k / v^T as stored (bf16x3: __bf16 planes; otherwise the storage type)
 template <typename T, int HD>
-__global__ __launch_bounds__(256) void dit_attention_kernel(const typename DT<T>::WT* __restrict__ q, const typename DT<T>::WT* __restrict__ k,
+__global__ __launch_bounds__(256, 2) void dit_attention_kernel(const typename DT<T>::WT* __restrict__ q, const typename DT<T>::WT* __restrict__ k,
                                                             const typename DT<T>::WT* __restrict__ vt, typename DT<T>::ST* __restrict__ out,
                                                             int BH, int heads, size_t lo_off) {
     typedef typename DT<T>::WT QT;
