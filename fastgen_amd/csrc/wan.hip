@@ -252,9 +252,10 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
         const float mn = fmaxf(m, mt);
         const float alpha = __builtin_amdgcn_exp2f((m - mn) * scale_log2e);  // m = -inf at the first tile: exp2(-inf) = 0
         float ps = 0.f;
+        const float mc = mn * scale_log2e;  // (one fma per logit instead of a subtraction and a multiplication)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            s[i] = __builtin_amdgcn_exp2f((s[i] - mn) * scale_log2e);
+            s[i] = __builtin_amdgcn_exp2f(fmaf(s[i], scale_log2e, -mc));
             ps += s[i];
         }
         ps += __shfl_xor(ps, 32);
