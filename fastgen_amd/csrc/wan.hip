@@ -150,8 +150,8 @@ __device__ __forceinline__ s16x4 fa_tr_read(const char* lds_addr) {
 }
 
 // HD = 128 (the video DiT) or 72 (DiT-XL/2, 256 tokens: timm Attention as DiTBlock uses it, fastgen/networks/DiT/network.py:168, 191).
-// HD = 72: LDS rows are 144 bytes apart (9 x 16 B: 16 consecutive rows at one chunk fall on 16 different 16-byte slots without
-// a swizzle); the fifth 16-deep step of the q k^T contraction is half empty (its upper half is zero on the q side, finite row
+// HD = 72: the K tile's LDS rows are 144 bytes apart (9 x 16 B: 16 consecutive rows at one chunk fall on 16 different 16-byte slots
+// without a swizzle), the V tile's 192; the fifth 16-deep step of the q k^T contraction is half empty (its upper half is zero on the q side, finite row
 // spill-over on the k side), the third 32-wide tile of output dims is computed from spill-over and only its first 8 dims stored.
 template <int HD, int MINW>
 __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict__ q, int ldq, int64_t q_bs, const __bf16* __restrict__ k,
@@ -160,12 +160,17 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
                                                        float* __restrict__ plse) {
     constexpr int KS = (HD + 15) / 16;   // 16-deep steps of q k^T
     constexpr int DT_ = (HD + 31) / 32;  // 32-wide tiles of output dims
-    constexpr int RP = HD * 2;           // LDS row pitch
-    constexpr int TILE = 32 * RP;        // bytes of one K or V tile
-    constexpr int BUF = 2 * TILE + (HD == 128 ? 0 : 256);  // a buffer = K tile | V tile (| slack for the reads past the last V row)
+    constexpr int RP = HD * 2;           // LDS row pitch of the K tile
+    // ... of the V tile: head dim 72 takes 192 bytes - the four rows of a transposed-read block (64 bytes each, two 16-lane groups)
+    // then tile the 256-byte bank window (0, 192, 128, 64); at the K tile's 144 they overlapped pairwise (profiles/r02_dit_attn_pmc:
+    // 1.1 conflict cycles per LDS instruction).  The third output tile's columns 72-95 read the row's padding: never stored.
+    constexpr int VP = HD == 128 ? RP : 192;
+    constexpr int TILE = 32 * RP;        // bytes of the K tile
+    constexpr int BUF = TILE + 32 * VP;  // a buffer = K tile | V tile
     constexpr int CPR = HD / 8;          // 16-byte chunks per row
     extern __shared__ __attribute__((aligned(16))) char smem[];
     auto off = [](int row, int ch) { return HD == 128 ? fa_off(row, ch) : row * RP + ch * 16; };
+    auto offv = [](int row, int ch) { return HD == 128 ? fa_off(row, ch) : row * VP + ch * 16; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
             const int p = tid + 256 * i;
             if (p < 32 * CPR) {
                 *reinterpret_cast<fg_u32x4*>(st + off(p / CPR, p % CPR)) = kreg[i];
-                *reinterpret_cast<fg_u32x4*>(st + TILE + off(p / CPR, p % CPR)) = vreg[i];
+                *reinterpret_cast<fg_u32x4*>(st + TILE + offv(p / CPR, p % CPR)) = vreg[i];
             }
         }
     };
@@ -220,10 +225,6 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
 
     const int ntiles = (Lkv + 31) / 32;
     const int t0 = (int)((long long)split * ntiles / nsplit), nt = (int)((long long)(split + 1) * ntiles / nsplit);
-    if (HD != 128 && tid < 32) {  // the slack behind both V tiles is read (never used): keep it finite
-        *reinterpret_cast<fg_u32x4*>(smem + 2 * TILE + tid * 8) = fg_u32x4{0, 0, 0, 0};
-        *reinterpret_cast<fg_u32x4*>(smem + BUF + 2 * TILE + tid * 8) = fg_u32x4{0, 0, 0, 0};
-    }
     issue(t0);
     park(smem + (t0 & 1) * BUF);
     __syncthreads();
@@ -276,8 +277,8 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
 #pragma unroll
             for (int d = 0; d < DT_; ++d) {
                 const int r0 = 16 * sx + 4 * h, c0 = 4 * d + 2 * gc;
-                const s16x4 lo = fa_tr_read(st + TILE + off(r0 + gq, c0 + (gp >> 1)) + 8 * (gp & 1));
-                const s16x4 hi = fa_tr_read(st + TILE + off(r0 + 8 + gq, c0 + (gp >> 1)) + 8 * (gp & 1));
+                const s16x4 lo = fa_tr_read(st + TILE + offv(r0 + gq, c0 + (gp >> 1)) + 8 * (gp & 1));
+                const s16x4 hi = fa_tr_read(st + TILE + offv(r0 + 8 + gq, c0 + (gp >> 1)) + 8 * (gp & 1));
                 typedef __attribute__((ext_vector_type(8))) short s16x8;
                 const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, ot[d], 0, 0, 0);
@@ -481,8 +482,8 @@ int launch_fa(int hd, const void* q, int ldq, int64_t q_bs, const void* k, const
         if (minw == 3) FA_GO(128, 3, 32768);
         else FA_GO(128, 2, 32768);
     } else {
-        if (minw == 3) FA_GO(72, 3, 2 * (2 * 32 * 144 + 256));
-        else FA_GO(72, 2, 2 * (2 * 32 * 144 + 256));
+        if (minw == 3) FA_GO(72, 3, 2 * (32 * 144 + 32 * 192));
+        else FA_GO(72, 2, 2 * (32 * 144 + 32 * 192));
     }
 #undef FA_GO
     if (nsplit > 1) {

@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $ROOT/bench.py --dtype $MODE --steps 2 --warmup 1 --no-cpu-baseline --no-secondary"
+CMD=${FG_PROFILE_CMD:-"python3 $ROOT/bench.py --dtype $MODE --steps 2 --warmup 1 --no-cpu-baseline --no-secondary"}   # FG_PROFILE_CMD: any other program of the repo (python3 <abs path> ...), e.g. scripts/dit_bench.py
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $CMD > $OUT/stats.log 2>&1
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" \

@@ -41,8 +41,10 @@ for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), r
 avg = {k: v[1] / v[0] for k, v in cnt.items() if v[0]}
 dom = [v for k, v in rows.items() if DOM in k]
 res = {
-    "kernel": DOM + f" (dominant kernel of bench.py, {MODE}, batch 512)",
-    "command": f"scripts/collect_profiles.sh: rocprofv3 --kernel-trace --pmc <group> --output-format csv -- python3 bench.py --dtype {MODE} --steps 2 --warmup 1 --no-cpu-baseline --no-secondary (one run per counter group)",
+    "kernel": DOM + (f" (dominant kernel of bench.py, {MODE}, batch 512)" if len(sys.argv) <= 5 else f" ({sys.argv[5]})"),
+    "command": "scripts/collect_profiles.sh: rocprofv3 --kernel-trace --pmc <group> --output-format csv -- " +
+               (f"python3 bench.py --dtype {MODE} --steps 2 --warmup 1 --no-cpu-baseline --no-secondary" if len(sys.argv) <= 5 else sys.argv[5]) +
+               " (one run per counter group)",
     "dispatches_per_pass": {k: v[0] for k, v in cnt.items()},
     "avg_launch_us_kernel_trace": (dom[0][1] / dom[0][0]) if dom else None,
     "counters_avg_per_dispatch": avg,
