@@ -360,9 +360,9 @@ __global__ __launch_bounds__(256, 2) void attention_x3_lds_kernel(const float* _
     auto stage_v = [&](int s, char* buf) {  // step s = 4 * dim half + key tile: 128 dims x 64 keys, written as 2 x 8 bytes (pitch % 16 = 8)
         const float* src = vt + ((size_t)n * D + (s >> 2) * 128) * Tn + (s & 3) * 64;
 #pragma unroll
-        for (int b2 = 0; b2 < 2; ++b2) {
+        for (int b2 = 0; b2 < 4; ++b2) {
 #pragma unroll
-            for (int i = b2 * 2; i < b2 * 2 + 2; ++i) {
+            for (int i = b2; i < b2 + 1; ++i) {
                 const int idx = tid + 256 * i, row = idx >> 3, c = idx & 7;
                 float x[8];
                 widen8(load_frag(src + (size_t)row * Tn + c * 8), x);
