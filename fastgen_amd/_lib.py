@@ -106,6 +106,7 @@ SIGNATURES = {
     "fg_wan_set_text": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "fg_wan_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                                c_void_p]),
+    "fg_wan_forward_block_causal": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "fg_disc_edm_num_params": (c_int, [c_int]),
     "fg_disc_edm_workspace_bytes": (c_size_t, [c_int, c_int]),
     "fg_disc_edm_run": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),

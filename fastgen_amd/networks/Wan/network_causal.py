@@ -8,8 +8,9 @@ weights and config, unavailable offline); here the fields of that config are con
 the parameters carry the same state-dict keys (`transformer.` + diffusers' names), so a converted checkpoint loads with
 `load_state_dict`.  PARITY UNPINNED (the arithmetic lives in un-vendored diffusers: oracle/wan_ref.py restates it).
 
-This round: autoregressive inference (`is_ar=True`, one cache tag).  Raises (never falls back): autograd, feature taps, r / image
-conditioning, teacher-forcing block masks (`is_ar=False` with all frames), any device but a HIP GPU.
+This round: autoregressive inference (`is_ar=True`, one cache tag) and the teacher- / diffusion-forcing forward over all
+total_num_frames frames (`is_ar=False`: block-wise causal mask, per-frame timesteps [B, F]).  Raises (never falls back): autograd,
+feature taps, r / image conditioning, `is_ar=False` on fewer frames, any device but a HIP GPU.
 """
 from __future__ import annotations
 
@@ -133,9 +134,10 @@ class CausalWan(FastGenNetwork):
             raise NotImplementedError("feature taps / logvar / skip_layers / r are not implemented for the causal video DiT path")
         if fwd_kwargs:
             raise TypeError(f"unexpected forward kwargs: {sorted(fwd_kwargs)}")
-        if not is_ar:
-            raise NotImplementedError("only the autoregressive call (is_ar=True: KV-cache attention) is implemented; the teacher-forcing "
-                                      "block-mask call is a training path")
+        if not is_ar and x_t.shape[2] != self.total_num_frames:
+            # (the reference builds its block mask only for a call over all total_num_frames frames, network_causal.py:673-680)
+            raise NotImplementedError(f"is_ar=False (block-wise causal mask) takes all total_num_frames = {self.total_num_frames} frames, got "
+                                      f"{x_t.shape[2]}; chunks go through the autoregressive call (is_ar=True)")
         if cache_tag != "pos":
             raise NotImplementedError("one cache tag ('pos') is implemented")
         if fwd_pred_type is None:
@@ -174,9 +176,14 @@ class CausalWan(FastGenNetwork):
         ts = (ts.view(-1, 1).expand(B, F) if ts.ndim == 1 else ts).to(torch.float32).contiguous()
         x32 = x_t.detach().to(torch.float32).contiguous()
         out = torch.empty_like(x32)
-        _lib.check(L.fg_wan_forward(self._h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(ts.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                                    B, F, H, W, int(cur_start_frame), int(bool(store_kv)), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
-                                    self._stream(dev)))
+        if is_ar:
+            _lib.check(L.fg_wan_forward(self._h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(ts.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                        B, F, H, W, int(cur_start_frame), int(bool(store_kv)), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                        self._stream(dev)))
+        else:  # teacher / diffusion forcing: all frames under the block-wise causal mask, caches untouched
+            _lib.check(L.fg_wan_forward_block_causal(self._h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(ts.data_ptr()),
+                                                     ctypes.c_void_p(out.data_ptr()), B, F, H, W, ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                                     self._stream(dev)))
         out = out.to(x_t.dtype)
         t_conv = t_in[:, None, :, None, None] if t_in.ndim == 2 else t_in
         return self.noise_scheduler.convert_model_output(x_t, out, t_conv, src_pred_type=self.net_pred_type, target_pred_type=fwd_pred_type)

@@ -356,6 +356,13 @@ FG_API int fg_wan_set_text(fg_wan* h, const float* text, int batch, int text_len
  * loop (causvid.py:150-172), where only that call moves the cache length. */
 FG_API int fg_wan_forward(fg_wan* h, const float* x_t, const float* t_frames, float* out, int batch, int frames, int height, int width,
                           int cur_start_frame, int store_kv, void* workspace, size_t workspace_bytes, void* stream);
+/* The teacher- / diffusion-forcing call over ALL frames: `CausalWan.forward(x_t, t, is_ar=False)` with frames == total_num_frames, where the
+ * reference attends through the block-wise causal mask of `_prepare_blockwise_causal_attn_mask` (network_causal.py:131-196, 673-680):
+ * a query sees the keys up to the end of its own chunk of chunk_size frames (the first chunk also holds frames % chunk_size).
+ * t_frames [B * frames] may differ per frame (diffusion forcing).  RoPE starts at frame 0; the self-attention caches are neither
+ * read nor written.  fg_wan_workspace_bytes(batch, total_num_frames, ...) covers this call's extra K / V buffers. */
+FG_API int fg_wan_forward_block_causal(fg_wan* h, const float* x_t, const float* t_frames, float* out, int batch, int frames, int height,
+                                       int width, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Samples to image bytes, the step after generator_fn in the reference's sample writer
  * (scripts/fid/compute_fid_from_ckpts.py:199): out[n,y,x,c] = uint8(clip(images[n,c,y,x] * 127.5 + 128, 0, 255)),

@@ -158,10 +158,27 @@ def layer_norm(x: torch.Tensor, eps: float, w=None, b=None) -> torch.Tensor:
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)
 
 
-def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
-    """`dispatch_attention_fn(q, k, v)` on [B, L, H, hd] tensors: softmax(q k^T / sqrt(hd)) v, flattened over heads."""
-    o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2))
+def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`dispatch_attention_fn(q, k, v)` on [B, L, H, hd] tensors: softmax(q k^T / sqrt(hd)) v, flattened over heads.  mask [Lq, Lk]
+    bool (True = attend): the flex_attention call under a block mask (network_causal.py:437)."""
+    o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=mask)
     return o.transpose(1, 2).flatten(2, 3)
+
+
+def blockwise_causal_mask(num_frames: int, frame_seqlen: int, chunk_size: int) -> torch.Tensor:
+    """`_prepare_blockwise_causal_attn_mask` (network_causal.py:131-196) as a dense [L, L] bool matrix: (kv < end of q's chunk) | (kv == q);
+    chunks of chunk_size frames, the first one front-loaded with num_frames % chunk_size.  (The reference's zero padding to a multiple
+    of 128 tokens adds rows / columns no real query sees and is dropped from its output, :418-443.)"""
+    nch, rem = num_frames // chunk_size, num_frames % chunk_size
+    counts = [rem] if nch == 0 else [chunk_size + rem] + [chunk_size] * (nch - 1)
+    ends = torch.zeros(num_frames * frame_seqlen, dtype=torch.long)
+    start = 0
+    for nf in counts:
+        n = nf * frame_seqlen
+        ends[start:start + n] = start + n
+        start += n
+    idx = torch.arange(num_frames * frame_seqlen)
+    return (idx[None, :] < ends[:, None]) | (idx[None, :] == idx[:, None])
 
 
 class CausalWanRef:
@@ -181,15 +198,21 @@ class CausalWanRef:
         return F.linear(x, self.p[name + ".weight"], self.p[name + ".bias"])
 
     def forward(self, x_t: torch.Tensor, t: torch.Tensor, text: torch.Tensor, cur_start_frame: int = 0, store_kv: bool = False,
-                trace: Optional[dict] = None) -> torch.Tensor:
+                trace: Optional[dict] = None, block_causal: bool = False) -> torch.Tensor:
         """The raw network output (net_pred_type: flow) of `CausalWan.forward(..., is_ar=True)`.  x_t [B, C, F, H, W]; t [B] in the
-        schedule's units (rescaled by 1000 here, `_compute_timestep_inputs` :1063-1075) - every frame of the chunk gets t."""
+        schedule's units (rescaled by 1000 here, `_compute_timestep_inputs` :1063-1075) - every frame of the chunk gets t - or [B, F]
+        (one per frame: diffusion forcing).
+        block_causal: the `is_ar=False` call over all total_num_frames frames - self-attention under the block-wise causal mask, no
+        self-attention cache read or written (the reference allocates none for a full-length call, :681-690)."""
         cfg, p = self.cfg, self.p
         B, C, Fr, H, W = x_t.shape
         gh, gw, D = H // 2, W // 2, cfg.dim
         fs = gh * gw  # frame_seqlen
         L = Fr * fs
-        ts = (1000.0 * t.float()).view(B, 1).expand(B, Fr).reshape(-1)  # [B * F]
+        ts = (1000.0 * t.float()).view(B, -1).expand(B, Fr).reshape(-1)  # [B * F]
+        if block_causal:
+            assert Fr == cfg.total_num_frames and cur_start_frame == 0 and not store_kv
+            mask = blockwise_causal_mask(Fr, fs, cfg.chunk_size)
         cos, sin = rope_for_chunk(cfg, Fr, gh, gw, cur_start_frame)
         # patch embedding: Conv3d kernel = stride = (1, 2, 2); tokens ordered (f, h, w)
         hs = F.conv3d(x_t.float(), p["patch_embedding.weight"], p["patch_embedding.bias"], stride=(1, 2, 2)).flatten(2).transpose(1, 2)
@@ -217,15 +240,18 @@ class CausalWanRef:
             k = rms_norm(self._lin(y, b + "attn1.to_k"), p[b + "attn1.norm_k.weight"], cfg.eps).view(B, L, cfg.num_heads, -1)
             v = self._lin(y, b + "attn1.to_v").view(B, L, cfg.num_heads, -1)
             q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
-            if self.self_kv[i] is None:
-                self.self_kv[i] = {"k": torch.zeros(B, cap, cfg.num_heads, cfg.head_dim), "v": torch.zeros(B, cap, cfg.num_heads, cfg.head_dim)}
-            kv = self.self_kv[i]
-            if store_kv:
-                kv["k"][:, cache_start:cache_start + L] = k
-                kv["v"][:, cache_start:cache_start + L] = v
-            k_full = torch.cat([kv["k"][:, :cache_start], k], dim=1)
-            v_full = torch.cat([kv["v"][:, :cache_start], v], dim=1)
-            att = self._lin(sdpa(q, k_full, v_full), b + "attn1.to_out.0")
+            if block_causal:
+                att = self._lin(sdpa(q, k, v, mask), b + "attn1.to_out.0")
+            else:
+                if self.self_kv[i] is None:
+                    self.self_kv[i] = {"k": torch.zeros(B, cap, cfg.num_heads, cfg.head_dim), "v": torch.zeros(B, cap, cfg.num_heads, cfg.head_dim)}
+                kv = self.self_kv[i]
+                if store_kv:
+                    kv["k"][:, cache_start:cache_start + L] = k
+                    kv["v"][:, cache_start:cache_start + L] = v
+                k_full = torch.cat([kv["k"][:, :cache_start], k], dim=1)
+                v_full = torch.cat([kv["v"][:, :cache_start], v], dim=1)
+                att = self._lin(sdpa(q, k_full, v_full), b + "attn1.to_out.0")
             hs = hs + (att.view(B, Fr, fs, D) * gate[:, :, None]).reshape(B, L, D)
             # 2. cross-attention to the text (static cache, :331-360)
             y = layer_norm(hs, cfg.eps, p[b + "norm2.weight"], p[b + "norm2.bias"])
@@ -285,3 +311,34 @@ def student_sample_loop(net: CausalWanRef, x: torch.Tensor, t_list: torch.Tensor
         net.forward(x_next, t_list[-1].expand(B), text, cur_start_frame=start, store_kv=True)
     net.clear_caches()
     return x
+
+
+def self_forcing_rollout(net: CausalWanRef, noise: torch.Tensor, t_list: torch.Tensor, text: torch.Tensor, end_steps: list,
+                         same_step_across_blocks: bool = True, eps_list: Optional[list] = None, sample_type: str = "sde") -> torch.Tensor:
+    """`SelfForcingModel.rollout_with_gradient` (self_forcing.py:92-241) without autograd, context_noise = 0, RF schedule: per chunk,
+    denoise down to the chunk's exit step (end_steps[0] for all chunks when same_step_across_blocks), keep that step's x0, then one
+    forward on it at t = 0 that fills the KV cache.  A frame remainder is not a chunk of its own: it rides with the first chunk.
+    eps_list: the injected noise draws of the 'sde' branch, in call order."""
+    net.clear_caches()
+    B, Fr = noise.shape[0], noise.shape[2]
+    cs = net.cfg.chunk_size
+    nblocks, rem = Fr // cs, Fr % cs
+    draws = iter(eps_list or [])
+    outs = []
+    for b in range(nblocks):
+        start = 0 if b == 0 else cs * b + rem
+        end = cs * (b + 1) + rem
+        x = noise[:, :, start:end]
+        exit_step = end_steps[0] if same_step_across_blocks else end_steps[b]
+        for step in range(len(t_list)):
+            tc = float(t_list[step])
+            x0 = x - tc * net.forward(x, t_list[step].expand(B), text, cur_start_frame=start, store_kv=False)
+            if step == exit_step:
+                break
+            tn = float(t_list[step + 1])
+            eps = next(draws) if sample_type == "sde" else (x - (1 - tc) * x0) / tc
+            x = (1 - tn) * x0 + tn * eps
+        outs.append(x0)
+        net.forward(x0, torch.zeros(B, dtype=torch.float64), text, cur_start_frame=start, store_kv=True)
+    net.clear_caches()
+    return torch.cat(outs, dim=2) if outs else torch.empty_like(noise)
