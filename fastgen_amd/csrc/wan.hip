@@ -157,7 +157,7 @@ template <int HD, int MINW>
 __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict__ q, int ldq, int64_t q_bs, const __bf16* __restrict__ k,
                                                        const __bf16* __restrict__ v, int ldk, int64_t kv_bs, __bf16* __restrict__ out, int ldo,
                                                        int64_t o_bs, int Lq, int Lkv, float scale_log2e, int nsplit, float* __restrict__ po,
-                                                       float* __restrict__ plse) {
+                                                       float* __restrict__ plse, int heads, int batch) {
     constexpr int KS = (HD + 15) / 16;   // 16-deep steps of q k^T
     constexpr int DT_ = (HD + 31) / 32;  // 32-wide tiles of output dims
     constexpr int RP = HD * 2;           // LDS row pitch of the K tile
@@ -173,10 +173,17 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
     auto offv = [](int row, int ch) { return HD == 128 ? fa_off(row, ch) : row * VP + ch * 16; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    // blockIdx.x = query tile * nsplit + split: with nsplit > 1 the workgroup covers the key tiles [t0, t1) of its split and leaves a
-    // normalised partial output + the log2-domain log-sum-exp of its keys; fa128_combine_kernel merges the splits
-    const int qt = (int)blockIdx.x / nsplit, split = (int)blockIdx.x - qt * nsplit;
+    // Workgroup -> (unit, query tile), unit = (sample, head, key split): the query tiles of a unit read the same K / V rows, so a unit
+    // lives on ONE XCD (workgroup w of a 1-D grid runs on XCD w % 8) and its tiles take neighbouring dispatch slots there - they walk
+    // the keys together and all but the first read of a K / V tile hit that XCD's L2.  (With the query tile on blockIdx.x every head
+    // was streamed through all eight L2s: 1.2 GB fetched per launch for 0.2 GB of K / V at the video DiT's chunk 6.)
+    // With nsplit > 1 the workgroup covers the key tiles [t0, t1) of its split and leaves a normalised partial output + the
+    // log2-domain log-sum-exp of its keys; fa128_combine_kernel merges the splits.
+    const int qtiles = (Lq + 127) / 128, units = batch * heads * nsplit;
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int unit = (slot / qtiles) * 8 + xcd, qt = slot % qtiles;
+    if (unit >= units) return;  // (the grid is padded to a multiple of 8 units; uniform per workgroup, before any barrier)
+    const int split = unit % nsplit, bh = unit / nsplit, head = bh % heads, b = bh / heads;
     const int q0 = qt * 128 + wave * 32;
     // this lane's query row (clamped: rows past Lq compute on the last row and are not stored)
     const __bf16* qrow = q + (size_t)b * q_bs + (size_t)min(q0 + r, Lq - 1) * ldq + head * HD + 8 * h;
@@ -212,6 +219,35 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
         }
     };
 
+    // HD = 128: the tiles go global -> LDS by LDS-DMA (no VGPR round trip) into a ring of NST buffers, three tiles ahead of the one
+    // being computed: with one tile of prefetch (registers, as HD = 72 below keeps it) an iteration lasted as long as a loaded
+    // L2 / HBM round trip - 2800 cycles for 512 cycles of MFMA work.  A wave instruction fills 1 KiB = 4 rows of a tile; the
+    // swizzle is applied on the lane's SOURCE address (LDS slot (row, pos) holds chunk pos ^ swizzle(row)).  Rows past Lkv are out of
+    // the buffer resource's range and read as zeros.
+    constexpr bool DMA = HD == 128;
+    constexpr int NST = DMA ? 4 : 2;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    __amdgpu_buffer_rsrc_t rsK, rsV;
+    unsigned dvo[2] = {0, 0};
+    if constexpr (DMA) {
+        const unsigned bytes = (unsigned)(((size_t)(Lkv - 1) * ldk + HD) * 2);
+        rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(kb), 0, bytes, 0x00020000);
+        rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(vb), 0, bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (wave * 2 + j) * 4 + (lane >> 4), pos = lane & 15;
+            dvo[j] = (unsigned)row * (unsigned)ldk * 2u + 16u * (unsigned)(pos ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+        }
+    }
+    auto dma = [&](int t, int stage) {  // tile t -> ring buffer `stage`; 4 instructions per wave
+        const int soff = t * 32 * ldk * 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr)(smem + stage * BUF + (wave * 2 + j) * 1024), 16, dvo[j], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr)(smem + stage * BUF + TILE + (wave * 2 + j) * 1024), 16, dvo[j], soff, 0, 0);
+        }
+    };
+
     f32x16 ot[DT_];
 #pragma unroll
     for (int d = 0; d < DT_; ++d)
@@ -225,21 +261,58 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
 
     const int ntiles = (Lkv + 31) / 32;
     const int t0 = (int)((long long)split * ntiles / nsplit), nt = (int)((long long)(split + 1) * ntiles / nsplit);
-    issue(t0);
-    park(smem + (t0 & 1) * BUF);
-    __syncthreads();
-    for (int t = t0; t < nt; ++t) {
-        const char* st = smem + (t & 1) * BUF;
-        if (t + 1 < nt) issue(t + 1);
+    if constexpr (DMA) {
+        // (tile indices past the split's end re-load its last tile into a buffer nobody reads: the waits below stay uniform)
+        dma(t0, 0);
+        dma(min(t0 + 1, nt - 1), 1);
+        dma(min(t0 + 2, nt - 1), 2);
+        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");  // tile t0 has landed, in every wave's part
+    } else {
+        issue(t0);
+        park(smem);
+        __syncthreads();
+    }
+    // fragment addresses of this lane inside buffer 0 (the buffer, the K | V split and the 16-key half go into the instruction's
+    // immediate offset: the tile loop below is unrolled over the two buffers, so no address arithmetic is left in it)
+    const uint32_t s0 = (uint32_t)(uintptr_t)smem;
+    uint32_t ka[KS], va[DT_][2];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) ka[kk] = s0 + (uint32_t)off(r, 2 * kk + h);
+#pragma unroll
+    for (int d = 0; d < DT_; ++d)
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) va[d][hi] = s0 + (uint32_t)(offv(4 * h + 8 * hi + gq, 4 * d + 2 * gc + (gp >> 1)) + 8 * (gp & 1));
+    auto step = [&](int t, auto BI_) {
+        constexpr int BI = decltype(BI_)::value;  // tile t sits in buffer BI
+        if constexpr (DMA) dma(min(t + 3, nt - 1), (BI + 3) % NST);  // into tile t - 1's buffer: its readers passed the last barrier
+        else if (t + 1 < nt) issue(t + 1);
+        // every fragment read of the tile goes out first: this lane's K row (the q k^T chain then runs MFMA behind MFMA instead of one
+        // LDS round trip per MFMA) and the transposed V blocks, which land behind the softmax arithmetic
+        // (inline asm + a hand-counted wait: left to itself hipcc sinks each read to just before the MFMA that uses it)
+        bf16x8 kf[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[kk]) : "v"(ka[kk]), "n"(BI * BUF));
+        s16x4 vl[2][DT_], vh[2][DT_];
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+            for (int d = 0; d < DT_; ++d) {
+                // rows 16 sx + 4 h + gq (+ 8): the swizzle of a row depends on row & 15 only, so sx is a plain row offset
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vl[sx][d]) : "v"(va[d][0]), "n"(BI * BUF + TILE + 16 * VP * sx));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vh[sx][d]) : "v"(va[d][1]), "n"(BI * BUF + TILE + 16 * VP * sx));
+            }
+        // LDS returns in order: at most 15 reads outstanding = the K fragments (issued first) have landed
+        if constexpr (4 * DT_ >= 15) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(4 * DT_) : "memory");
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) asm volatile("" : "+v"(kf[kk]));  // (the MFMAs below depend on the wait, not only on the reads)
+        __builtin_amdgcn_sched_barrier(0);
         // S^T[key][query]
         f32x16 s;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(st + off(r, 2 * kk + h));
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
-        }
+        for (int kk = 0; kk < KS; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], s, 0, 0, 0);
         // online softmax; keys past Lkv (last tile) are masked
         float mt = -INFINITY;
         if (t == ntiles - 1) {  // (wave-uniform) only the last key tile can be ragged
@@ -249,17 +322,30 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) mt = fmaxf(mt, s[i]);
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        {  // the other half of the query's keys sits in lane ^ 32: v_permlane32_swap instead of a trip through LDS
+            float a_ = mt, b_ = mt;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a_), "+v"(b_));
+            mt = fmaxf(a_, b_);
+        }
         const float mn = fmaxf(m, mt);
         const float alpha = __builtin_amdgcn_exp2f((m - mn) * scale_log2e);  // m = -inf at the first tile: exp2(-inf) = 0
-        float ps = 0.f;
         const float mc = mn * scale_log2e;  // (one fma per logit instead of a subtraction and a multiplication)
+        // two logits per instruction (v_pk_fma_f32, v_pk_add_f32); the exponentials themselves are scalar quarter-rate instructions
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 sc2 = {scale_log2e, scale_log2e}, mc2 = {mc, mc};
+        f32x2 e2[8];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            s[i] = __builtin_amdgcn_exp2f(fmaf(s[i], scale_log2e, -mc));
-            ps += s[i];
+        for (int i = 0; i < 8; ++i) {
+            const f32x2 z = __builtin_elementwise_fma(f32x2{s[2 * i], s[2 * i + 1]}, sc2, -mc2);
+            e2[i] = f32x2{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
         }
-        ps += __shfl_xor(ps, 32);
+        const f32x2 p2 = ((e2[0] + e2[1]) + (e2[2] + e2[3])) + ((e2[4] + e2[5]) + (e2[6] + e2[7]));
+        float ps = p2[0] + p2[1];
+        {
+            float a_ = ps, b_ = ps;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a_), "+v"(b_));
+            ps = a_ + b_;
+        }
         lsum = lsum * alpha + ps;
         m = mn;
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {  // wave-uniform: the running maximum of some query of this wave moved
@@ -269,30 +355,52 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
                 for (int i = 0; i < 16; ++i) ot[d][i] *= alpha;
         }
         // O^T[dim][query] += V^T[dim][key] P^T[key][query]
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+            for (int d = 0; d < DT_; ++d) asm volatile("" : "+v"(vl[sx][d]), "+v"(vh[sx][d]));
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx) {
             bf16x8 pf;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[8 * sx + j];
+            for (int j = 0; j < 4; ++j) pf[2 * j] = (__bf16)e2[4 * sx + j][0], pf[2 * j + 1] = (__bf16)e2[4 * sx + j][1];
 #pragma unroll
             for (int d = 0; d < DT_; ++d) {
-                const int r0 = 16 * sx + 4 * h, c0 = 4 * d + 2 * gc;
-                const s16x4 lo = fa_tr_read(st + TILE + offv(r0 + gq, c0 + (gp >> 1)) + 8 * (gp & 1));
-                const s16x4 hi = fa_tr_read(st + TILE + offv(r0 + 8 + gq, c0 + (gp >> 1)) + 8 * (gp & 1));
                 typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x4 lo = vl[sx][d], hi = vh[sx][d];
                 const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, ot[d], 0, 0, 0);
             }
         }
-        if (t + 1 < nt) park(smem + ((t + 1) & 1) * BUF);
-        __syncthreads();
+        if constexpr (DMA) {
+            // two younger tiles (8 instructions) may stay in flight: tile t + 1 has landed; then the hand-over barrier
+            asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        } else {
+            if (t + 1 < nt) park(smem + (1 - BI) * BUF);
+            __syncthreads();
+        }
+    };
+    if constexpr (DMA) {
+        for (int t = t0; t < nt; t += 4) {
+            step(t, std::integral_constant<int, 0>{});
+            if (t + 1 < nt) step(t + 1, std::integral_constant<int, 1>{});
+            if (t + 2 < nt) step(t + 2, std::integral_constant<int, 2>{});
+            if (t + 3 < nt) step(t + 3, std::integral_constant<int, 3>{});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may land in an LDS allocation this workgroup has given up
+    } else {
+        for (int t = t0; t < nt; t += 2) {
+            step(t, std::integral_constant<int, 0>{});
+            if (t + 1 < nt) step(t + 1, std::integral_constant<int, 1>{});
+        }
     }
     // out[query][head * HD + dim]: this lane holds dims 32 d + acc_row(i, h) = 32 d + 8 i4 + 4 h + e of its query
     if (nsplit > 1) {
         if (q0 + r < Lq) {
             const float inv = 1.0f / lsum;
-            const size_t row = (size_t)b * Lq + q0 + r, rows = (size_t)gridDim.z * Lq;
-            float* orow = po + ((size_t)split * rows + row) * (gridDim.y * HD) + head * HD;
+            const size_t row = (size_t)b * Lq + q0 + r, rows = (size_t)batch * Lq;
+            float* orow = po + ((size_t)split * rows + row) * (heads * HD) + head * HD;
 #pragma unroll
             for (int d = 0; d < DT_; ++d)
 #pragma unroll
@@ -300,7 +408,7 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
                     if (32 * d + 8 * i4 + 4 * h < HD)
                         *reinterpret_cast<f32x4*>(orow + 32 * d + 8 * i4 + 4 * h) =
                             f32x4{ot[d][4 * i4] * inv, ot[d][4 * i4 + 1] * inv, ot[d][4 * i4 + 2] * inv, ot[d][4 * i4 + 3] * inv};
-            if (h == 0) plse[((size_t)split * rows + row) * gridDim.y + head] = m * scale_log2e + __builtin_amdgcn_logf(lsum);
+            if (h == 0) plse[((size_t)split * rows + row) * heads + head] = m * scale_log2e + __builtin_amdgcn_logf(lsum);
         }
         return;
     }
@@ -448,7 +556,7 @@ int launch_rms_rope(int D, const void* src, int ld_src, const float* w, float ep
     WAN_RET();
 }
 // Key splits: how many workgroups share one query tile's keys, so that short grids (one sample: ceil(Lq / 128) x heads workgroups)
-// still fill 256 CUs x 3 resident workgroups; every split keeps >= 8 key tiles.  scratch (nullable -> no split) holds the splits'
+// still fill 256 CUs x 2 resident workgroups.  scratch (nullable -> no split) holds the splits'
 // partial outputs and log-sum-exps: fa128_scratch_bytes(B, heads, Lq).
 constexpr int FA_MAX_SPLIT = 8;
 size_t fa128_scratch_bytes(int B, int heads, int Lq) { return (size_t)FA_MAX_SPLIT * B * Lq * ((size_t)heads * 128 + heads) * 4 + 256; }
@@ -456,31 +564,35 @@ int launch_fa(int hd, const void* q, int ldq, int64_t q_bs, const void* k, const
               int B, int heads, int Lq, int Lkv, hipStream_t s, void* scratch) {
     if ((hd != 128 && hd != 72) || Lq <= 0 || Lkv <= 0 || (ldq % 8) || (ldk % 8) || (ldo % 4)) return (int)hipErrorInvalidValue;
     const int qtiles = (Lq + 127) / 128, ktiles = (Lkv + 31) / 32;
-    const long long base = (long long)qtiles * heads * B, slots = 256 * 3;
+    // key splits: units (sample, head, split) are dealt to the 8 XCDs (fa_kernel's mapping: 32 CUs each, two workgroups resident per CU at
+    // half speed each).  Cost in tile iterations (~1.2 us) = workgroups on the fullest CU / 2 x (key tiles per split + ~6 of prologue
+    // and epilogue) + the merge pass (fp32 partial outputs read back at ~5 TB/s); every split keeps >= 8 key tiles.
     int nsplit = 1;
-    if (scratch && base < 2 * slots) {
-        double best = 0.0;
-        for (int c = 1; c <= FA_MAX_SPLIT && ktiles / c >= 8; ++c) {
-            const long long tot = base * c;
-            const double eff = (double)tot / (double)(((tot + slots - 1) / slots) * slots);
-            if (eff > best + 0.02) best = eff, nsplit = c;
+    if (scratch) {
+        double best = -1.0;
+        for (int c = 1; c <= FA_MAX_SPLIT && (c == 1 || ktiles / c >= 8); ++c) {
+            const long long ux = ((long long)B * heads * c + 7) / 8, per_cu = (ux * qtiles + 31) / 32;
+            const double cost = 0.5 * (double)per_cu * ((ktiles + c - 1) / c + 6) + (c > 1 ? 3.0 + 6.7e-7 * c * B * (double)Lq * heads * hd : 0.0);
+            if (best < 0.0 || cost < best) best = cost, nsplit = c;
         }
     }
     float* po = (float*)scratch;
     float* plse = po ? po + (size_t)FA_MAX_SPLIT * B * Lq * heads * hd : nullptr;
-    dim3 g(qtiles * nsplit, heads, B);
-    static int minw = -1;  // waves per SIMD the kernel is compiled for (register budget 168 | 256): FASTGEN_AMD_FA_WAVES = 3 (default) | 2
+    const long long units = (long long)B * heads * nsplit;
+    dim3 g((unsigned)(((units + 7) / 8) * 8 * qtiles));
+    static int minw = -1;  // waves per SIMD the kernel is compiled for (register budget 256 | 168): FASTGEN_AMD_FA_WAVES = 2 (default: room for the tile's fragments) | 3
     if (minw < 0) {
         const char* e = getenv("FASTGEN_AMD_FA_WAVES");
-        minw = (e && e[0] == '2') ? 2 : 3;
+        minw = (e && e[0] == '3') ? 3 : 2;
     }
     const float sc = 1.44269504088896341f / sqrtf((float)hd);
 #define FA_GO(HD, MW, LDS)                                                                                                                  \
     hipLaunchKernelGGL((fa_kernel<HD, MW>), g, dim3(256), LDS, s, (const __bf16*)q, ldq, q_bs, (const __bf16*)k, (const __bf16*)v, ldk, kv_bs, \
-                       (__bf16*)out, ldo, o_bs, Lq, Lkv, sc, nsplit, po, plse)
+                       (__bf16*)out, ldo, o_bs, Lq, Lkv, sc, nsplit, po, plse, heads, B)
     if (hd == 128) {
-        if (minw == 3) FA_GO(128, 3, 32768);
-        else FA_GO(128, 2, 32768);
+        if ((size_t)Lkv * ldk * 2 >= ((size_t)1 << 31)) return (int)hipErrorInvalidValue;  // (buffer-resource offsets are 32-bit)
+        if (minw == 3) FA_GO(128, 3, 65536);
+        else FA_GO(128, 2, 65536);
     } else {
         if (minw == 3) FA_GO(72, 3, 2 * (32 * 144 + 32 * 192));
         else FA_GO(72, 2, 2 * (32 * 144 + 32 * 192));
