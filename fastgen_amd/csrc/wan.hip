@@ -153,11 +153,11 @@ __device__ __forceinline__ s16x4 fa_tr_read(const char* lds_addr) {
 // HD = 72: the K tile's LDS rows are 144 bytes apart (9 x 16 B: 16 consecutive rows at one chunk fall on 16 different 16-byte slots
 // without a swizzle), the V tile's 192; the fifth 16-deep step of the q k^T contraction is half empty (its upper half is zero on the q side, finite row
 // spill-over on the k side), the third 32-wide tile of output dims is computed from spill-over and only its first 8 dims stored.
-template <int HD, int MINW>
+template <int HD, int MINW, bool FA_DMA>
 __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict__ q, int ldq, int64_t q_bs, const __bf16* __restrict__ k,
                                                        const __bf16* __restrict__ v, int ldk, int64_t kv_bs, __bf16* __restrict__ out, int ldo,
                                                        int64_t o_bs, int Lq, int Lkv, float scale_log2e, int nsplit, float* __restrict__ po,
-                                                       float* __restrict__ plse, int heads, int batch) {
+                                                       float* __restrict__ plse, int heads, int batch, int abl) {
     constexpr int KS = (HD + 15) / 16;   // 16-deep steps of q k^T
     constexpr int DT_ = (HD + 31) / 32;  // 32-wide tiles of output dims
     constexpr int RP = HD * 2;           // LDS row pitch of the K tile
@@ -198,33 +198,37 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
 
     // staging: 32 rows x CPR chunks of both tiles over 256 threads
     constexpr int NPC = (32 * CPR + 255) / 256;
-    fg_u32x4 kreg[NPC], vreg[NPC];
-    auto issue = [&](int t) {
+    // two register sets: the loads of tile t + 2 are issued while tile t is computed and tile t + 1 (issued an iteration earlier) waits
+    // for its turn to be written to LDS - one tile of prefetch left an iteration as long as a loaded L2 / HBM round trip
+    constexpr int PD = HD == 128 ? 2 : 1;  // tiles of prefetch (head dim 72: 256 keys = 8 tiles per query tile, one is enough)
+    fg_u32x4 kreg[PD][NPC], vreg[PD][NPC];
+    auto issue = [&](int t, auto SET_) {
+        constexpr int SET = decltype(SET_)::value % PD;
 #pragma unroll
         for (int i = 0; i < NPC; ++i) {
             const int p = min(tid + 256 * i, 32 * CPR - 1);
             const size_t key = (size_t)min(t * 32 + p / CPR, Lkv - 1);
-            kreg[i] = *reinterpret_cast<const fg_u32x4*>(kb + key * ldk + (p % CPR) * 8);
-            vreg[i] = *reinterpret_cast<const fg_u32x4*>(vb + key * ldk + (p % CPR) * 8);
+            kreg[SET][i] = *reinterpret_cast<const fg_u32x4*>(kb + key * ldk + (p % CPR) * 8);
+            vreg[SET][i] = *reinterpret_cast<const fg_u32x4*>(vb + key * ldk + (p % CPR) * 8);
         }
     };
-    auto park = [&](char* st) {
+    auto park = [&](char* st, auto SET_) {
+        constexpr int SET = decltype(SET_)::value % PD;
 #pragma unroll
         for (int i = 0; i < NPC; ++i) {
             const int p = tid + 256 * i;
             if (p < 32 * CPR) {
-                *reinterpret_cast<fg_u32x4*>(st + off(p / CPR, p % CPR)) = kreg[i];
-                *reinterpret_cast<fg_u32x4*>(st + TILE + offv(p / CPR, p % CPR)) = vreg[i];
+                *reinterpret_cast<fg_u32x4*>(st + off(p / CPR, p % CPR)) = kreg[SET][i];
+                *reinterpret_cast<fg_u32x4*>(st + TILE + offv(p / CPR, p % CPR)) = vreg[SET][i];
             }
         }
     };
-
     // HD = 128: the tiles go global -> LDS by LDS-DMA (no VGPR round trip) into a ring of NST buffers, three tiles ahead of the one
     // being computed: with one tile of prefetch (registers, as HD = 72 below keeps it) an iteration lasted as long as a loaded
     // L2 / HBM round trip - 2800 cycles for 512 cycles of MFMA work.  A wave instruction fills 1 KiB = 4 rows of a tile; the
     // swizzle is applied on the lane's SOURCE address (LDS slot (row, pos) holds chunk pos ^ swizzle(row)).  Rows past Lkv are out of
     // the buffer resource's range and read as zeros.
-    constexpr bool DMA = HD == 128;
+    constexpr bool DMA = HD == 128 && FA_DMA;
     constexpr int NST = DMA ? 4 : 2;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     __amdgpu_buffer_rsrc_t rsK, rsV;
@@ -266,10 +270,11 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
         dma(t0, 0);
         dma(min(t0 + 1, nt - 1), 1);
         dma(min(t0 + 2, nt - 1), 2);
-        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");  // tile t0 has landed, in every wave's part
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");  // tiles t0 and t0 + 1 have landed, in every wave's part
     } else {
-        issue(t0);
-        park(smem);
+        issue(t0, std::integral_constant<int, 0>{});
+        if (PD == 2 && t0 + 1 < nt) issue(t0 + 1, std::integral_constant<int, 1>{});
+        park(smem, std::integral_constant<int, 0>{});
         __syncthreads();
     }
     // fragment addresses of this lane inside buffer 0 (the buffer, the K | V split and the 16-key half go into the instruction's
@@ -284,29 +289,43 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
         for (int hi = 0; hi < 2; ++hi) va[d][hi] = s0 + (uint32_t)(offv(4 * h + 8 * hi + gq, 4 * d + 2 * gc + (gp >> 1)) + 8 * (gp & 1));
     auto step = [&](int t, auto BI_) {
         constexpr int BI = decltype(BI_)::value;  // tile t sits in buffer BI
-        if constexpr (DMA) dma(min(t + 3, nt - 1), (BI + 3) % NST);  // into tile t - 1's buffer: its readers passed the last barrier
-        else if (t + 1 < nt) issue(t + 1);
-        // every fragment read of the tile goes out first: this lane's K row (the q k^T chain then runs MFMA behind MFMA instead of one
-        // LDS round trip per MFMA) and the transposed V blocks, which land behind the softmax arithmetic
-        // (inline asm + a hand-counted wait: left to itself hipcc sinks each read to just before the MFMA that uses it)
+        if (t + PD < nt) issue(t + PD, std::integral_constant<int, BI + PD>{});  // (two sets: set BI held tile t, in LDS since the last iteration)
         bf16x8 kf[KS];
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[kk]) : "v"(ka[kk]), "n"(BI * BUF));
         s16x4 vl[2][DT_], vh[2][DT_];
+        if constexpr (HD == 128) {
+            // every fragment read of the tile goes out first: this lane's K row (the q k^T chain then runs MFMA behind MFMA instead of
+            // one LDS round trip per MFMA) and the transposed V blocks, which land behind the softmax arithmetic
+            // (inline asm + a hand-counted wait: left to itself hipcc sinks each read to just before the MFMA that uses it)
 #pragma unroll
-        for (int sx = 0; sx < 2; ++sx)
+            for (int kk = 0; kk < KS; ++kk) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[kk]) : "v"(ka[kk]), "n"(BI * BUF));
 #pragma unroll
-            for (int d = 0; d < DT_; ++d) {
-                // rows 16 sx + 4 h + gq (+ 8): the swizzle of a row depends on row & 15 only, so sx is a plain row offset
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vl[sx][d]) : "v"(va[d][0]), "n"(BI * BUF + TILE + 16 * VP * sx));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vh[sx][d]) : "v"(va[d][1]), "n"(BI * BUF + TILE + 16 * VP * sx));
-            }
-        // LDS returns in order: at most 15 reads outstanding = the K fragments (issued first) have landed
-        if constexpr (4 * DT_ >= 15) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(4 * DT_) : "memory");
+            for (int sx = 0; sx < 2; ++sx)
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) asm volatile("" : "+v"(kf[kk]));  // (the MFMAs below depend on the wait, not only on the reads)
-        __builtin_amdgcn_sched_barrier(0);
+                for (int d = 0; d < DT_; ++d) {
+                    // rows 16 sx + 4 h + gq (+ 8): the swizzle of a row depends on row & 15 only, so sx is a plain row offset
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vl[sx][d]) : "v"(va[d][0]), "n"(BI * BUF + TILE + 16 * VP * sx));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vh[sx][d]) : "v"(va[d][1]), "n"(BI * BUF + TILE + 16 * VP * sx));
+                }
+            // LDS returns in order: at most 15 reads outstanding = the K fragments (issued first) have landed
+            asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) asm volatile("" : "+v"(kf[kk]));  // (the MFMAs below depend on the wait, not only on the reads)
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // head dim 72 (256 keys = 8 tiles per query tile): the reads stay compiler-visible (hipcc places each next to its MFMA);
+            // fragments in flight bought nothing at this length (DiT-XL/2 forward 75.6 ms either way)
+            const char* st = smem + BI * BUF;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) kf[kk] = *reinterpret_cast<const bf16x8*>(st + off(r, 2 * kk + h));
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                for (int d = 0; d < DT_; ++d) {
+                    const int r0 = 16 * sx + 4 * h, c0 = 4 * d + 2 * gc;
+                    vl[sx][d] = fa_tr_read(st + TILE + offv(r0 + gq, c0 + (gp >> 1)) + 8 * (gp & 1));
+                    vh[sx][d] = fa_tr_read(st + TILE + offv(r0 + 8 + gq, c0 + (gp >> 1)) + 8 * (gp & 1));
+                }
+        }
         // S^T[key][query]
         f32x16 s;
 #pragma unroll
@@ -355,11 +374,13 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
                 for (int i = 0; i < 16; ++i) ot[d][i] *= alpha;
         }
         // O^T[dim][query] += V^T[dim][key] P^T[key][query]
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (HD == 128) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int sx = 0; sx < 2; ++sx)
+            for (int sx = 0; sx < 2; ++sx)
 #pragma unroll
-            for (int d = 0; d < DT_; ++d) asm volatile("" : "+v"(vl[sx][d]), "+v"(vh[sx][d]));
+                for (int d = 0; d < DT_; ++d) asm volatile("" : "+v"(vl[sx][d]), "+v"(vh[sx][d]));
+        }
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx) {
             bf16x8 pf;
@@ -373,20 +394,142 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
                 ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, ot[d], 0, 0, 0);
             }
         }
-        if constexpr (DMA) {
-            // two younger tiles (8 instructions) may stay in flight: tile t + 1 has landed; then the hand-over barrier
-            asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-        } else {
-            if (t + 1 < nt) park(smem + (1 - BI) * BUF);
-            __syncthreads();
-        }
+        if (t + 1 < nt) park(smem + (1 - BI) * BUF, std::integral_constant<int, 1 - BI>{});
+        __syncthreads();
     };
     if constexpr (DMA) {
+        // ---- software-pipelined form: S^T of tile t + 1 (eight chained MFMAs) is issued in between the pieces of tile t's softmax
+        // arithmetic - a wave issues in order, so the chain only overlaps the VALU work if the two are interleaved in program
+        // order (one MFMA per ~40-60 cycles of VALU: never a stall on the chain) - then O += V P of tile t.  Tile t + 1 must have
+        // landed when iteration t starts: one younger tile (4 DMA instructions) stays in flight over the hand-over barrier.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x16 sc;  // S^T of the tile whose softmax comes next
+        {
+            bf16x8 kf[KS];
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) asm volatile("ds_read_b128 %0, %1" : "=v"(kf[kk]) : "v"(ka[kk]));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) asm volatile("" : "+v"(kf[kk]));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc[i] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], sc, 0, 0, 0);
+        }
+        auto pstep = [&](int t, auto BI_) {
+            constexpr int BI = decltype(BI_)::value, BN = (BI + 1) % NST;  // tile t sits in buffer BI, tile t + 1 in BN
+            if (!(abl & 4)) dma(min(t + 3, nt - 1), (BI + 3) % NST);  // into tile t - 1's buffer: its readers passed the last barrier
+            // K rows of tile t + 1 (past the split's end: a re-loaded last tile, result unused), then the V blocks of tile t
+            bf16x8 kf[KS];
+            s16x4 vl[2][DT_], vh[2][DT_];
+            if (!(abl & 2)) {
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[kk]) : "v"(ka[kk]), "n"(BN * BUF));
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                for (int d = 0; d < DT_; ++d) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vl[sx][d]) : "v"(va[d][0]), "n"(BI * BUF + TILE + 16 * VP * sx));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vh[sx][d]) : "v"(va[d][1]), "n"(BI * BUF + TILE + 16 * VP * sx));
+                }
+            }
+            f32x16 sn;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sn[i] = 0.f;
+            // piece 0: mask of a ragged last tile, this lane's maximum
+            float mt = -INFINITY;
+            if (t == ntiles - 1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (t * 32 + acc_row(i, h) >= Lkv) sc[i] = -INFINITY;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mt = fmaxf(mt, sc[i]);
+            asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");  // in-order returns: the 8 K fragments (issued first) have landed
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) asm volatile("" : "+v"(kf[kk]));
+            __builtin_amdgcn_sched_barrier(0);
+            sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], sn, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // piece 1: the other half of the query's keys (lane ^ 32), running maximum, rescale factor
+            {
+                float a_ = mt, b_ = mt;
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a_), "+v"(b_));
+                mt = fmaxf(a_, b_);
+            }
+            const float mn = fmaxf(m, mt);
+            const float alpha = __builtin_amdgcn_exp2f((m - mn) * scale_log2e);
+            const float mc = mn * scale_log2e;
+            const f32x2 sc2 = {scale_log2e, scale_log2e}, mc2 = {mc, mc};
+            __builtin_amdgcn_sched_barrier(0);
+            sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[1], sn, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // pieces 2-5: four exponentials each
+            f32x2 e2[8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int i = 2 * c; i < 2 * c + 2; ++i) {
+                    const f32x2 z = __builtin_elementwise_fma(f32x2{sc[2 * i], sc[2 * i + 1]}, sc2, -mc2);
+                    e2[i] = (abl & 1) ? z : f32x2{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2 + c], qf[2 + c], sn, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // piece 6: row sums
+            const f32x2 p2 = ((e2[0] + e2[1]) + (e2[2] + e2[3])) + ((e2[4] + e2[5]) + (e2[6] + e2[7]));
+            float ps = p2[0] + p2[1];
+            {
+                float a_ = ps, b_ = ps;
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a_), "+v"(b_));
+                ps = a_ + b_;
+            }
+            lsum = lsum * alpha + ps;
+            m = mn;
+            __builtin_amdgcn_sched_barrier(0);
+            sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[6], qf[6], sn, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // piece 7: P^T fragments; the (rare) rescale of O
+            bf16x8 pf[2];
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pf[sx][2 * j] = (__bf16)e2[4 * sx + j][0], pf[sx][2 * j + 1] = (__bf16)e2[4 * sx + j][1];
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+#pragma unroll
+                for (int d = 0; d < DT_; ++d)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) ot[d][i] *= alpha;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[7], qf[7], sn, 0, 0, 0);
+            // O^T[dim][query] += V^T[dim][key] P^T[key][query]
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                for (int d = 0; d < DT_; ++d) asm volatile("" : "+v"(vl[sx][d]), "+v"(vh[sx][d]));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                for (int d = 0; d < DT_; ++d) {
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    const s16x4 lo = vl[sx][d], hi = vh[sx][d];
+                    const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if (!(abl & 16)) ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[sx], ot[d], 0, 0, 0);
+                }
+            sc = sn;
+            // one younger tile (4 instructions) may stay in flight: tile t + 2 has landed; then the hand-over barrier
+            if (!(abl & 8)) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        };
+        static_assert(!DMA || KS == 8, "the interleave above is written for eight contraction steps");
         for (int t = t0; t < nt; t += 4) {
-            step(t, std::integral_constant<int, 0>{});
-            if (t + 1 < nt) step(t + 1, std::integral_constant<int, 1>{});
-            if (t + 2 < nt) step(t + 2, std::integral_constant<int, 2>{});
-            if (t + 3 < nt) step(t + 3, std::integral_constant<int, 3>{});
+            pstep(t, std::integral_constant<int, 0>{});
+            if (t + 1 < nt) pstep(t + 1, std::integral_constant<int, 1>{});
+            if (t + 2 < nt) pstep(t + 2, std::integral_constant<int, 2>{});
+            if (t + 3 < nt) pstep(t + 3, std::integral_constant<int, 3>{});
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may land in an LDS allocation this workgroup has given up
     } else {
@@ -580,22 +723,33 @@ int launch_fa(int hd, const void* q, int ldq, int64_t q_bs, const void* k, const
     float* plse = po ? po + (size_t)FA_MAX_SPLIT * B * Lq * heads * hd : nullptr;
     const long long units = (long long)B * heads * nsplit;
     dim3 g((unsigned)(((units + 7) / 8) * 8 * qtiles));
+    static int use_dma = -1;  // head dim 128: LDS-DMA ring (1, default) | two-deep register prefetch (0): FASTGEN_AMD_FA_DMA
+    if (use_dma < 0) {
+        const char* e = getenv("FASTGEN_AMD_FA_DMA");
+        use_dma = (e && e[0] == '0') ? 0 : 1;
+    }
+    static int abl = -1;  // (timing experiments only: FASTGEN_AMD_FA_ABL bit mask, see fa_kernel's pipelined step)
+    if (abl < 0) {
+        const char* e = getenv("FASTGEN_AMD_FA_ABL");
+        abl = e ? atoi(e) : 0;
+    }
     static int minw = -1;  // waves per SIMD the kernel is compiled for (register budget 256 | 168): FASTGEN_AMD_FA_WAVES = 2 (default: room for the tile's fragments) | 3
     if (minw < 0) {
         const char* e = getenv("FASTGEN_AMD_FA_WAVES");
         minw = (e && e[0] == '3') ? 3 : 2;
     }
     const float sc = 1.44269504088896341f / sqrtf((float)hd);
-#define FA_GO(HD, MW, LDS)                                                                                                                  \
-    hipLaunchKernelGGL((fa_kernel<HD, MW>), g, dim3(256), LDS, s, (const __bf16*)q, ldq, q_bs, (const __bf16*)k, (const __bf16*)v, ldk, kv_bs, \
-                       (__bf16*)out, ldo, o_bs, Lq, Lkv, sc, nsplit, po, plse, heads, B)
+#define FA_GO(HD, MW, LDS, DM)                                                                                                              \
+    hipLaunchKernelGGL((fa_kernel<HD, MW, DM>), g, dim3(256), LDS, s, (const __bf16*)q, ldq, q_bs, (const __bf16*)k, (const __bf16*)v, ldk, kv_bs, \
+                       (__bf16*)out, ldo, o_bs, Lq, Lkv, sc, nsplit, po, plse, heads, B, abl)
     if (hd == 128) {
         if ((size_t)Lkv * ldk * 2 >= ((size_t)1 << 31)) return (int)hipErrorInvalidValue;  // (buffer-resource offsets are 32-bit)
-        if (minw == 3) FA_GO(128, 3, 65536);
-        else FA_GO(128, 2, 65536);
+        if (!use_dma) FA_GO(128, 2, 32768, false);
+        else if (minw == 3) FA_GO(128, 3, 65536, true);
+        else FA_GO(128, 2, 65536, true);
     } else {
-        if (minw == 3) FA_GO(72, 3, 2 * (32 * 144 + 32 * 192));
-        else FA_GO(72, 2, 2 * (32 * 144 + 32 * 192));
+        if (minw == 3) FA_GO(72, 3, 2 * (32 * 144 + 32 * 192), false);
+        else FA_GO(72, 2, 2 * (32 * 144 + 32 * 192), false);
     }
 #undef FA_GO
     if (nsplit > 1) {
