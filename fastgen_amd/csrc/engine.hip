@@ -1267,9 +1267,29 @@ int fg_op_gemm_bf16(const void* a, const void* w, const float* bias, void* out, 
         HIP_TRY(hipMalloc(&scratch, g.scratch_bytes));
         g.scratch = (float*)scratch;
     }
+    if (tile_order & 128) {  // (timing experiments) cycle stamps of workgroup 0: printed per tile, see gemm_bf16_pp_kernel's `stamp`
+        HIP_TRY(hipMalloc(&scratch, 65536));
+        HIP_TRY(hipMemsetAsync(scratch, 0, 65536, (hipStream_t)stream));
+        g.scratch = (float*)scratch;
+        g.scratch_bytes = 0;
+        g.act |= 16;
+    }
     const int rc = launch_gemm_bf16(g, (hipStream_t)stream);
     if (scratch) {
         (void)hipStreamSynchronize((hipStream_t)stream);
+        if (tile_order & 128) {
+            static unsigned long long st[8192];
+            (void)hipMemcpy(st, scratch, 65536, hipMemcpyDeviceToHost);
+            for (int ti = 0; ti < 16 && st[ti * 16]; ++ti) {
+                fprintf(stderr, "tile %2d:", ti);
+                for (int gq = 0; gq < 2; ++gq) {
+                    const unsigned long long* q = st + ti * 16 + gq;  // slot s at q[2 s]
+                    fprintf(stderr, "  group %d: k-loop %6llu  last k-step %5llu  epilogue %6llu = quadrants %5llu %5llu %5llu %5llu  -> next tile %5llu |", gq,
+                            q[2] - q[0], q[4] - q[2], q[6] - q[4], q[8] - q[4], q[10] - q[8], q[12] - q[10], q[6] - q[12], st[(ti + 1) * 16 + gq] ? st[(ti + 1) * 16 + gq] - q[6] : 0ull);
+                }
+                fprintf(stderr, "\n");
+            }
+        }
         (void)hipFree(scratch);
     }
     HIP_TRY(rc);

@@ -432,8 +432,78 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
     // between the token-tile groups of an XCD (-3...-8 %).  What the epilogue costs is measured with act bits 4 / 8: at K = 1152
     // the K-loop alone runs at 1450-1530 TFLOP/s, the epilogue arithmetic takes it to 1210, the stores (HBM write rate, exposed
     // by the in-order vmcnt) to 900-980.
+    // token epilogue (GM_EPI_TOK): every address is buffer-resource arithmetic - a lane-constant byte offset (its row inside the
+    // wave's half, its 8-output column group), everything that depends on the tile, the 16-row block or the quadrant in the scalar
+    // offset.  (As 64-bit pointer arithmetic per row and quadrant the epilogue was ~1000 vector instructions per tile and wave -
+    // 5 us per tile at two waves per SIMD, a quarter of a K = 1152 tile's time - mostly address computation.)
+    int ep_m0 = 0, ep_n0 = 0, ep_mk = 0, ep_nk = 0;
+    const int lane_c8 = wc * 64 + 16 * (g & 1) + 8 * (g >> 1);
+    const int vo_out = ((wr * 128 + col) * a.N + lane_c8) * 2;
+    const __amdgpu_buffer_rsrc_t rsO = make_rsrc(a.out), rsR = make_rsrc(a.resid), rsG = make_rsrc(a.gate);
+    // (gate periods >= the tile height: a tile then spans at most two gate rows; launch_gemm_bf16 sends shorter ones to gemm_bf16_kernel)
     auto slice = [&](auto MH_, auto NH_, int tile, f32x4 be, f32x4 bo) {
         constexpr int MH = decltype(MH_)::value, NH = decltype(NH_)::value;
+        if constexpr (EPI == GM_EPI_TOK) {
+            if (!(a.act & 8)) {
+                const int m0 = ep_m0, n0 = ep_n0, mk = ep_mk, nk_ = ep_nk;  // (tile_origin / tile_keep_from of `tile`, computed once per tile)
+                const bool edge = (mk != m0) || (nk_ != n0);  // a shifted last tile: part of it is its neighbour's (uniform)
+                const int c8 = n0 + lane_c8 + 32 * NH;
+                // gate x value: the gate rows of the tile's first token and of the next gate period (if the tile reaches into it)
+                f32x4 g0e = {1.f, 1.f, 1.f, 1.f}, g0o = g0e, g1e = g0e, g1o = g0e;
+                int bnd = 0x7fffffff;
+                if (a.gate) {
+                    const int gi0 = (a.row0 + m0) / a.gate_rows;
+                    bnd = (gi0 + 1) * a.gate_rows - a.row0;  // first token (in this launch's rows) of the next gate period
+                    const int gso = (gi0 * a.gate_stride + n0 + 32 * NH) * 4;
+                    g0e = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4, gso, 0));
+                    g0o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4 + 16, gso, 0));
+                    g1e = g0e, g1o = g0o;
+                    if (bnd < m0 + GM_TM) {
+                        g1e = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4, gso + a.gate_stride * 4, 0));
+                        g1o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4 + 16, gso + a.gate_stride * 4, 0));
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int rb = (MH * 4 + m) * 16;  // 16-row block inside the wave's token half
+                    const int row = m0 + wr * 128 + rb + col;
+                    f32x4 ve = acc[MH * 4 + m][NH * 2] + be, vo = acc[MH * 4 + m][NH * 2 + 1] + bo;
+                    acc[MH * 4 + m][NH * 2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc[MH * 4 + m][NH * 2 + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (a.act & 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ve[e] = gm_gelu_tanh(ve[e]), vo[e] = gm_gelu_tanh(vo[e]);
+                    }
+                    {
+                        float e0 = ve[0], e1 = ve[1], e2 = ve[2], e3 = ve[3], o0 = vo[0], o1 = vo[1], o2 = vo[2], o3 = vo[3];
+                        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %6\n\t"
+                                     "v_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                                     : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));
+                        ve = f32x4{e0, e1, e2, e3};
+                        vo = f32x4{o0, o1, o2, o3};
+                    }
+                    if (edge && !(row >= mk && c8 >= nk_)) continue;
+                    if (a.gate) {
+                        const bool nx_ = row >= bnd;
+                        ve *= nx_ ? g1e : g0e;
+                        vo *= nx_ ? g1o : g0o;
+                    }
+                    const int so = ((m0 + rb) * a.N + n0 + 32 * NH) * 2;  // (scalar; < 2 GiB: launch_gemm_bf16 chunks the rows)
+                    if (a.resid) {
+                        const bf16x8 r8 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsR, vo_out, so, 0));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ve[e] += (float)r8[e], vo[e] += (float)r8[4 + e];
+                    }
+                    bf16x8 o8;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o8[e] = (__bf16)ve[e], o8[4 + e] = (__bf16)vo[e];
+                    if (a.act & 4) asm volatile("" ::"v"(o8));  // (timing experiments: everything but the store)
+                    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fg_u32x4, o8), rsO, vo_out, so, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                return;
+            }
+        }
         if (a.act & 8) {  // (timing experiments: no epilogue at all)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -527,22 +597,6 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
                 float* prow = a.scratch + ((size_t)item_split(tile) * a.M + row) * a.N + c8;
                 *reinterpret_cast<f32x4*>(prow) = ve;
                 *reinterpret_cast<f32x4*>(prow + 4) = vo;
-            } else if constexpr (EPI == GM_EPI_TOK) {
-                if (a.gate) {
-                    const float* grow = a.gate + (size_t)((a.row0 + row) / a.gate_rows) * a.gate_stride + c8;
-                    ve *= *reinterpret_cast<const f32x4*>(grow);
-                    vo *= *reinterpret_cast<const f32x4*>(grow + 4);
-                }
-                if (a.resid) {
-                    const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.resid) + (size_t)row * a.N + c8);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ve[e] += (float)r8[e], vo[e] += (float)r8[4 + e];
-                }
-                bf16x8 o8;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o8[e] = (__bf16)ve[e], o8[4 + e] = (__bf16)vo[e];
-                if (a.act & 4) asm volatile("" ::"v"(o8));  // (timing experiments: everything but the store)
-                else *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(a.out) + (size_t)row * a.N + c8) = o8;
             } else {
                 const int D = a.heads * a.head_dim;  // % 8 == 0: the 8 outputs lie in one plane and one head
                 const int b = (a.row0 + row) / a.T, t = a.row0 + row - b * a.T;
@@ -621,6 +675,12 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         cmp_done();
     };
     // (the loop nest keeps the K-steps inside a tile - the hot loop - a loop of its own for the register allocator)
+    // (timing experiments: act bit 16 = cycle stamps of workgroup 0, waves 0 and 4, into a.scratch: [tile][slot][group])
+    int stamp_tile = 0;
+    auto stamp = [&](int slot) {
+        if (EPI == GM_EPI_TOK && (a.act & 16) && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0)
+            reinterpret_cast<unsigned long long*>(a.scratch)[(stamp_tile * 8 + slot) * 2 + wr] = __builtin_readcyclecounter();
+    };
     int t = 0;
     auto advance = [&]() {
         c1 = c2;
@@ -628,15 +688,20 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         ++t;
     };
     for (int ti = 0; ti < my_tiles; ++ti) {
+        stamp_tile = ti;
+        stamp(0);
+        if (ti > 0 && wr == 1) asm volatile("s_barrier" ::: "memory");  // the second group falls one barrier behind again
         for (int kk = 0; kk + 1 < nk; ++kk) {
             kstep(t);
             advance();
         }
+        stamp(1);
         // the tile's bias, one K-step ahead of its use: this lane's quads of the four output pairs (own layout, before the swap)
         f32x4 b00 = {0.f, 0.f, 0.f, 0.f}, b01 = b00, b10 = b00, b11 = b00;
+        tile_origin(ti, ep_m0, ep_n0);
+        tile_keep_from(ti, ep_mk, ep_nk);
         if (a.bias && EPI != GM_EPI_RAW) {
-            int m0, n0;
-            tile_origin(ti, m0, n0);
+            const int n0 = ep_n0;
             const float* bp = a.bias + n0 + wc * 64 + 4 * g;
             b00 = *reinterpret_cast<const f32x4*>(bp);
             b01 = *reinterpret_cast<const f32x4*>(bp + 16);
@@ -644,14 +709,22 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
             b11 = *reinterpret_cast<const f32x4*>(bp + 48);
         }
         kstep(t);
+        // the groups meet before the epilogue (the first one waits out the second's last compute part) and run it side by side:
+        // one barrier apart, each group's 7 000-cycle epilogue stalled the other at its next barrier (cycle stamps,
+        // scripts/gemm_stamps.py: 14 800 of a K = 1152 tile's 70 000 cycles)
+        if (wr == 0) asm volatile("s_barrier" ::: "memory");
+        stamp(2);
         slice(I0{}, I0{}, ti, b00, b01);
+        stamp(4);
         slice(I0{}, I1{}, ti, b10, b11);
+        stamp(5);
         slice(I1{}, I1{}, ti, b10, b11);
+        stamp(6);
         slice(I1{}, I0{}, ti, b00, b01);
+        stamp(3);
         advance();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may land in an LDS allocation this workgroup has given up
-    if (wr == 0) asm volatile("s_barrier" ::: "memory");
 }
 
 // out[row][c .. c + 7] = epilogue(sum over the K splits of their fp32 partial sums): bias, tanh-GELU, gate x value + residual as in the
@@ -854,7 +927,8 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only) {
         return 0;
     }
     // rows per launch: staging offsets into A stay below the buffer resource's 2 GiB
-    const int rows_max = (int)(((1ull << 31) - 1) / ((size_t)a.K * 2)) / GM_TM * GM_TM;
+    // (... and the epilogue's offsets into out / resid: N instead of K)
+    const int rows_max = (int)(((1ull << 31) - 1) / ((size_t)(a.K > a.N ? a.K : a.N) * 2)) / GM_TM * GM_TM;
     for (int r0 = 0; r0 < a.M; r0 += rows_max) {
         GemmArgs b = a;
         b.row0 = a.row0 + r0;
@@ -862,7 +936,8 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only) {
         b.A = reinterpret_cast<const __bf16*>(a.A) + (size_t)r0 * a.K;
         if (a.out) b.out = reinterpret_cast<__bf16*>(a.out) + (size_t)r0 * a.N;
         if (a.resid) b.resid = reinterpret_cast<const __bf16*>(a.resid) + (size_t)r0 * a.N;
-        const bool pp = (a.variant < 0 ? gm_variant() : a.variant) == 1 && b.M >= GM_TM && a.N >= 256 && a.K >= 2 * GM_KC;
+        const bool pp = (a.variant < 0 ? gm_variant() : a.variant) == 1 && b.M >= GM_TM && a.N >= 256 && a.K >= 2 * GM_KC &&
+                        (!a.gate || a.gate_rows >= GM_TM);  // (the ping-pong kernel's token epilogue: a tile spans at most two gate rows)
         if (pp && !heads && !a.out_f32 && rows_max >= a.M) {
             const int dev = fg_device_slot();
             b.ksplit = gm_pick_ksplit(b, dev >= 0 && g_gm_cus[dev] ? g_gm_cus[dev] : 256);
