@@ -225,22 +225,83 @@ __global__ __launch_bounds__(WG_THREADS, X3 ? 1 : 2) void conv_wgrad_kernel(cons
         // ---- k-steps x taps MFMAs ------------------------------------------------------------------------------------
         if constexpr (ROLL) {
             // Tap (ky, kx) of tile row s reads halo row s + ky shifted by kx: the same fragment serves (s, ky), (s+1, ky-1) and
-            // (s+2, ky-2).  Keep three halo rows x three shifts in registers (slot = halo row % 3); each k-step fetches only
-            // the row that enters (s + 2), early enough that the six MFMAs of rows s and s + 1 cover the LDS latency:
-            // 8 transposed reads per 9 MFMAs instead of 20 - the LDS read port was the bottleneck of the plain form.
-            WFrag<X3> F[3][3];
-            auto load_row = [&](int hr) __attribute__((always_inline)) {
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) F[hr % 3][kx] = frag2(a_lane + (hr * HW_ + kx) * WG_AP, a_lane + (hr * HW_ + kx + 4) * WG_AP);
+            // (s+2, ky-2).  A ring of FOUR halo rows x three shifts stays in registers (slot = halo row % 4): step s computes on
+            // rows s .. s+2 while row s+3 and the next step's dY fragment are on their way - 8 transposed reads per 9 MFMAs
+            // instead of 20, issued a whole step (27 or 9 MFMAs) before their use.  (Inline asm + one hand-placed wait per step:
+            // hipcc sank every compiler-visible read to just before its MFMA, an LDS round trip every two or three MFMAs -
+            // 54 full waits per 216 MFMAs with one wave per SIMD and nothing else to issue.)
+            struct FR {
+                s16x4 h[2], l[2];  // hi image: pixels k .. k+3 | k+4 .. k+7; lo image (split-bf16 mode only)
             };
-            load_row(0);
-            load_row(1);
+            const uint32_t a_u = (uint32_t)(uintptr_t)a_lane, d_u = (uint32_t)(uintptr_t)dy_lane;
+            const uint32_t a_ul = a_u + LO, d_ul = d_u + LO;
+            FR F[4][3], fa[2];
+            auto rd = [&](FR& f, uint32_t base, uint32_t base_lo, auto OFF0_, auto OFF1_) __attribute__((always_inline)) {
+                constexpr int O0 = decltype(OFF0_)::value, O1 = decltype(OFF1_)::value;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.h[0]) : "v"(base), "n"(O0));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.h[1]) : "v"(base), "n"(O1));
+                if constexpr (X3) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.l[0]) : "v"(base_lo), "n"(O0));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.l[1]) : "v"(base_lo), "n"(O1));
+                }
+            };
+            auto landed = [&](FR& f) __attribute__((always_inline)) {  // (ties the fragment to the wait that precedes this call)
+                asm volatile("" : "+v"(f.h[0]), "+v"(f.h[1]));
+                if constexpr (X3) asm volatile("" : "+v"(f.l[0]), "+v"(f.l[1]));
+            };
+            auto as_frag = [&](const FR& f) __attribute__((always_inline)) -> WFrag<X3> {
+                WFrag<X3> w;
+                const s16x8 hv = {f.h[0][0], f.h[0][1], f.h[0][2], f.h[0][3], f.h[1][0], f.h[1][1], f.h[1][2], f.h[1][3]};
+                w.hi.v = __builtin_bit_cast(bf16x8, hv);
+                if constexpr (X3) {
+                    const s16x8 lv = {f.l[0][0], f.l[0][1], f.l[0][2], f.l[0][3], f.l[1][0], f.l[1][1], f.l[1][2], f.l[1][3]};
+                    w.lo.v = __builtin_bit_cast(bf16x8, lv);
+                }
+                return w;
+            };
+            auto load_row = [&](auto HR_) __attribute__((always_inline)) {
+                constexpr int hr = decltype(HR_)::value;
+                rd(F[hr % 4][0], a_u, a_ul, std::integral_constant<int, (hr * HW_ + 0) * WG_AP>{}, std::integral_constant<int, (hr * HW_ + 4) * WG_AP>{});
+                rd(F[hr % 4][1], a_u, a_ul, std::integral_constant<int, (hr * HW_ + 1) * WG_AP>{}, std::integral_constant<int, (hr * HW_ + 5) * WG_AP>{});
+                rd(F[hr % 4][2], a_u, a_ul, std::integral_constant<int, (hr * HW_ + 2) * WG_AP>{}, std::integral_constant<int, (hr * HW_ + 6) * WG_AP>{});
+            };
+            auto load_dy = [&](auto S_) __attribute__((always_inline)) {
+                constexpr int s_ = decltype(S_)::value;
+                rd(fa[s_ & 1], d_u, d_ul, std::integral_constant<int, (16 * s_) * WG_DYP>{}, std::integral_constant<int, (16 * s_ + 4) * WG_DYP>{});
+            };
+            static_assert((9 * HW_ + 6) * WG_AP < 65536 && (16 * 7 + 4) * WG_DYP < 65536, "ds_read offsets are 16-bit");
+            load_row(std::integral_constant<int, 0>{});
+            load_row(std::integral_constant<int, 1>{});
+            load_row(std::integral_constant<int, 2>{});
+            load_dy(std::integral_constant<int, 0>{});
+            auto step = [&](auto S_) __attribute__((always_inline)) {
+                constexpr int s_ = decltype(S_)::value;
+                // what this step computes on was issued a step ago (or in the prologue): one wait, covered by the last step's MFMAs
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int s = 0; s < TH; ++s) {
-                load_row(s + 2);
-                const WFrag<X3> fa = frag2(dy_lane + (16 * s) * WG_DYP, dy_lane + (16 * s + 4) * WG_DYP);
+                for (int r3 = 0; r3 < 3; ++r3)
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) wg_mma<X3>(acc[tap], fa, F[(s + tap / 3) % 3][tap % 3]);
+                    for (int kx = 0; kx < 3; ++kx) landed(F[(s_ + r3) % 4][kx]);
+                landed(fa[s_ & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (s_ + 1 < TH) {
+                    load_row(std::integral_constant<int, s_ + 3>{});
+                    load_dy(std::integral_constant<int, s_ + 1>{});
+                }
+                const WFrag<X3> fd = as_frag(fa[s_ & 1]);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) wg_mma<X3>(acc[tap], fd, as_frag(F[(s_ + tap / 3) % 4][tap % 3]));
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            step(std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{});
+            step(std::integral_constant<int, 3>{});
+            if constexpr (TH > 4) {
+                step(std::integral_constant<int, 4>{});
+                step(std::integral_constant<int, 5>{});
+                step(std::integral_constant<int, 6>{});
+                step(std::integral_constant<int, 7>{});
             }
         } else
 #pragma unroll
