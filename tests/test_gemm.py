@@ -101,3 +101,27 @@ def test_unsupported_shapes_are_refused():
     w = torch.zeros(64, 96, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(_lib.FastGenAMDError):
         _run(a, w)  # k % 64 != 0
+
+
+@pytest.mark.parametrize("m,n,k,rows", [(4680, 3072, 1536, 1560), (2900, 1152, 1152, 300), (1024, 512, 256, 256)])
+def test_gate_periods_that_straddle_a_tile(m, n, k, rows):
+    """The ping-pong kernel's token epilogue reads the gate rows of a tile's first token and of the next gate period: periods that are
+    no multiple of the 256-token tile (the video DiT's 1 560 tokens per frame), a ragged last token tile, in-place residual."""
+    g = torch.Generator().manual_seed(m + rows)
+    a = torch.randn(m, k, generator=g).bfloat16().cuda()
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).bfloat16().cuda()
+    bias = torch.randn(n, generator=g).cuda()
+    gate = torch.randn((m + rows - 1) // rows, n, generator=g).cuda()
+    resid = torch.randn(m, n, generator=g).bfloat16().cuda()
+    want = _ref(a, w, bias, gate=gate, gate_rows=rows, resid=resid)
+    got = _run(a, w, bias, gate=gate, gate_rows=rows, resid=resid, order=32 + 1)
+    assert (got.float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-3
+    # in place: out aliases the residual (rows / columns a shifted edge tile shares with its neighbour are stored once)
+    from fastgen_amd import _lib
+
+    x = resid.clone()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(_lib.lib().fg_op_gemm_bf16(p(a), p(w), p(bias), p(x), m, n, k, 0, p(gate), n, rows, p(x), 32 + 1,
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert (x.float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-3
