@@ -127,6 +127,66 @@ def cpu_baseline(budget_s: float = 20.0):
             "sample": f"{n} batches of 16 images, 4-step sde, fp32 torch-CPU oracle ({dt:.1f} s)"}
 
 
+def transformer_rows(dev):
+    """Secondary measurements (not the headline metric): wall time of one forward, max-synchronised, after warm-up."""
+    import time
+
+    from fastgen_amd.networks.DiT.network import DiT
+    from fastgen_amd.networks.Wan.network_causal import CausalWan
+
+    out = {}
+
+    def timeit(fn, n):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n
+
+    # DiT-XL/2 (fastgen/configs/net.py:124-127): hidden 1152, 28 blocks, 16 heads x 72, 256 tokens; 237 GFLOP / image / forward
+    D, depth, T, Hd, B = 1152, 28, 256, 4608, 256
+    gf = depth * (2 * T * D * 3 * D + 4 * T * T * D + 2 * T * D * D + 4 * T * D * Hd + 2 * D * 6 * D) / 1e9
+    net = DiT(compute_dtype="bf16").to(dev).eval()
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for _, p in net.named_parameters():  # O(1) signal in every branch (the reference zero-initialises the adaLN layers)
+            p.copy_((torch.randn(p.shape, generator=g) * (0.1 if p.dim() == 1 else p.shape[-1] ** -0.5)).to(dev))
+    x = torch.randn(B, 4, 32, 32, device=dev)
+    t = torch.rand(B, dtype=torch.float64, device=dev) * 0.99
+    c = torch.randint(0, 1000, (B,), device=dev)
+    with torch.inference_mode():
+        for _ in range(3):
+            net(x, t, condition=c)
+        dt = timeit(lambda: net(x, t, condition=c), 5)
+    out["dit_xl2_forward"] = {"batch": B, "dtype": "bf16", "ms": round(dt * 1e3, 2), "img_per_s": round(B / dt, 1),
+                              "algorithmic_tflops": round(B * gf / dt / 1e3, 1), "frac_of_2.5PF": round(B * gf / dt / 1e3 / 2500.0, 4)}
+    del net
+    torch.cuda.empty_cache()
+    # causal video DiT 1.3B at 480p (fastgen/configs/experiments/WanT2V/config_sf.py: latents [16, 21, 60, 104], chunks of 3 frames):
+    # one network call of the student loop on chunk k = 4 680 query tokens over (k + 1) * 4 680 cached + own keys
+    Dw, Fd, fs, Lt, layers = 1536, 8960, 1560, 512, 30
+    net = CausalWan(num_layers=layers).to(dev).eval()
+    xv = torch.randn(1, 16, 21, 60, 104, device=dev)
+    text = torch.randn(1, Lt, 4096, device=dev)
+    tv = torch.tensor([0.7], dtype=torch.float64, device=dev)
+    calls = {}
+    with torch.inference_mode():
+        for k in range(7):
+            xs = xv[:, :, 3 * k: 3 * k + 3]
+            call = lambda: net(xs, tv, condition=text, cur_start_frame=3 * k, store_kv=True, is_ar=True)
+            call()
+            if k in (0, 6):
+                dtk = timeit(call, 3)
+                L, Lkv = 3 * fs, (3 * k + 3) * fs
+                gfk = layers * (2 * L * Dw * (4 * Dw + 2 * Fd + 2 * Dw) + 4 * L * Lkv * Dw + 4 * L * Lt * Dw) / 1e9
+                calls[f"chunk{k}"] = {"ms": round(dtk * 1e3, 2), "algorithmic_tflops": round(gfk / dtk / 1e3, 1)}
+    out["causal_video_dit_1p3b_480p_call"] = dict(dtype="bf16", batch=1, **calls)
+    del net
+    torch.cuda.empty_cache()
+    return out
+
+
 def result_line(value, world, steps, warmup, dt, dtype, batch, sample_steps, graph, roofline, cpu):
     """The ONE JSON line of the driver contract (fields and meanings: the task brief, 'Measurement')."""
     return {
@@ -150,7 +210,7 @@ def main():
     ap.add_argument("--dtype", choices=["bf16x3", "fp32", "bf16"], default="bf16x3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the bf16 line reported beside the headline")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the bf16 line and the transformer-row timings reported beside the headline")
     args = ap.parse_args()
 
     rank, local_rank, world = dist_env()
@@ -233,6 +293,14 @@ def main():
         secondary = {"bf16": {"value": round(v2, 2), "unit": "img/s", "ms_per_step": round(dt2 / args.steps * 1e3, 3),
                               "note": "bf16 MFMA operands AND bf16 activation storage: narrower than the reference's fp32 "
                                       "config, not the headline", "roofline": roof2}}
+    # the rows next to the headline path, one GPU only: DiT-XL/2 forward and the causal video DiT's network call,
+    # both at the precision their reference configs run (bf16), random-init weights of the named architectures
+    if world == 1 and not args.no_secondary:
+        try:
+            secondary = dict(secondary or {})
+            secondary["transformer_rows"] = transformer_rows(dev)
+        except Exception as e:  # (never lose the headline line to a secondary measurement)
+            secondary["transformer_rows"] = {"error": f"{type(e).__name__}: {e}"}
     if world > 1:
         dist.barrier()
 
