@@ -342,3 +342,53 @@ def self_forcing_rollout(net: CausalWanRef, noise: torch.Tensor, t_list: torch.T
         net.forward(x0, torch.zeros(B, dtype=torch.float64), text, cur_start_frame=start, store_kv=True)
     net.clear_caches()
     return torch.cat(outs, dim=2) if outs else torch.empty_like(noise)
+
+
+def extrapolate(net: CausalWanRef, noise: torch.Tensor, t_list: torch.Tensor, text: torch.Tensor, num_segments: int, overlap_frames: int,
+                vae_roundtrip, fresh_noise: list) -> torch.Tensor:
+    """`CausVidModel.generator_fn_extrapolation` (causvid.py:188-397), 'ode' re-noising, context_noise = 0, RF schedule.
+    vae_roundtrip(latents) -> latents: encode(decode(.)) of the caller's VAE on the overlapped tail; fresh_noise: the tensors the
+    reference draws with randn_like for the segments after the first, in order."""
+    B, _, T = noise.shape[:3]
+    cs = net.cfg.chunk_size
+    draws = iter(fresh_noise)
+    t0 = float(t_list[0])
+
+    def run_segment(lat, prefill):
+        x = lat.clone()
+        net.clear_caches()
+        for start in range(0, prefill, cs):
+            net.forward(x[:, :, start:min(start + cs, prefill)], torch.zeros(B, dtype=torch.float64), text, cur_start_frame=start, store_kv=True)
+        x[:, :, prefill:] = x[:, :, prefill:] * t0  # latents = noise * sigma(t_list[0])
+        for start in range(prefill, T, cs):
+            end = min(start + cs, T)
+            x_next = x[:, :, start:end]
+            for step in range(len(t_list) - 1):
+                tc = float(t_list[step])
+                x_cur = x_next
+                x_next = x_cur - tc * net.forward(x_cur, t_list[step].expand(B), text, cur_start_frame=start, store_kv=False)
+                tn = float(t_list[step + 1])
+                if tn > 0:
+                    eps = (x_cur - (1 - tc) * x_next) / tc
+                    x_next = (1 - tn) * x_next + tn * eps
+            x[:, :, start:end] = x_next
+            net.forward(x_next, torch.zeros(B, dtype=torch.float64), text, cur_start_frame=start, store_kv=True)
+        net.clear_caches()
+        return x
+
+    segs, cur, prefill = [], noise, 0
+    for i in range(num_segments):
+        seg = run_segment(cur, prefill)
+        segs.append(seg if i == 0 or overlap_frames == 0 else seg[:, :, overlap_frames:])
+        if i == num_segments - 1:
+            break
+        if overlap_frames == 0:
+            cur, prefill = next(draws), 0
+            continue
+        tail = vae_roundtrip(seg)[:, :, -overlap_frames:]
+        if overlap_frames > 1:
+            tail = torch.cat([tail[:, :, :1], seg[:, :, -(overlap_frames - 1):]], dim=2)
+        cur = next(draws).clone()
+        cur[:, :, :overlap_frames] = tail
+        prefill = overlap_frames
+    return torch.cat(segs, dim=2)

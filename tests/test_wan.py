@@ -267,3 +267,41 @@ def test_block_causal_call_against_oracle():
     assert _rel(a0.cpu(), w0) < 2e-2 and _rel(a1.cpu(), w1) < 2e-2
     with pytest.raises(NotImplementedError):
         net(x[:, :, :4].cuda(), t[:, :4].cuda(), condition=text.cuda(), is_ar=False)
+
+
+class _ToyVAE:
+    """decode / encode pair for the segment bridge (any pair works for the call sequence: pixels = 2 x latents + 1)."""
+
+    @staticmethod
+    def decode(z):
+        return 2.0 * z + 1.0
+
+    @staticmethod
+    def encode(px):
+        return 0.5 * (px - 1.0) * 0.9  # (not an exact inverse: the bridged first latent differs from the reused ones)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [0, 2])
+def test_causvid_extrapolation_against_oracle(overlap, monkeypatch):
+    from fastgen_amd.methods.distribution_matching.causvid import CausVidModel
+
+    ref, net = _nets(16)
+    net.vae = _ToyVAE()
+    g = torch.Generator().manual_seed(17)
+    B, T, H, W = 1, 4, 16, 16  # two chunks of 2 frames per segment
+    noise = torch.randn(B, 16, T, H, W, generator=g)
+    text = torch.randn(B, 16, 128, generator=g)
+    fresh = [torch.randn(B, 16, T, H, W, generator=g) for _ in range(2)]
+    t_list = [0.999, 0.6, 0.0]
+    pending = [f.clone() for f in fresh]
+    monkeypatch.setattr(torch, "randn_like", lambda x, **kw: pending.pop(0).to(x.device, x.dtype))  # 'ode': the only draws are the new segments' latents
+    got = CausVidModel.generator_fn_extrapolation(net, noise.cuda(), condition=text.cuda(), num_segments=3, overlap_frames=overlap,
+                                                  student_sample_steps=2, student_sample_type="ode", t_list=t_list)
+    want = R.extrapolate(ref, noise, torch.tensor(t_list, dtype=torch.float64), text, 3, overlap,
+                         lambda z: _ToyVAE.encode(_ToyVAE.decode(z)), fresh)
+    assert got.shape == want.shape == (B, 16, 3 * T - 2 * overlap, H, W)
+    assert _rel(got.cpu(), want) < 4e-2, _rel(got.cpu(), want)
+    with pytest.raises(ValueError):
+        CausVidModel.generator_fn_extrapolation(net, noise.cuda(), condition=text.cuda(), num_segments=2, overlap_frames=1, t_list=t_list,
+                                                student_sample_steps=2)
