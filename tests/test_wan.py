@@ -305,3 +305,36 @@ def test_causvid_extrapolation_against_oracle(overlap, monkeypatch):
     with pytest.raises(ValueError):
         CausVidModel.generator_fn_extrapolation(net, noise.cuda(), condition=text.cuda(), num_segments=2, overlap_frames=1, t_list=t_list,
                                                 student_sample_steps=2)
+
+
+@pytest.mark.gpu
+def test_block_causal_call_with_a_frame_remainder():
+    """5 frames at chunk_size 2: the mask's first chunk holds 3 frames (network_causal.py:163-174); odd token counts per frame
+    (10 x 6 latents = 15 tokens: query tiles and key tiles end inside a chunk)."""
+    import dataclasses
+
+    from fastgen_amd.networks.Wan.network_causal import CausalWan
+
+    cfg = dataclasses.replace(R.TINY, total_num_frames=5)
+    sd = R.random_state_dict(cfg, 21)
+    ref = R.CausalWanRef(sd, cfg)
+    net = CausalWan(**dict(KW, total_num_frames=5))
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    g = torch.Generator().manual_seed(22)
+    B = 2
+    x = torch.randn(B, 16, 5, 10, 6, generator=g)
+    text = torch.randn(B, 9, 128, generator=g)
+    t = torch.rand(B, 5, generator=g, dtype=torch.float64) * 0.9 + 0.05
+    with torch.inference_mode():
+        got = net(x.cuda(), t.cuda(), condition=text.cuda(), fwd_pred_type="flow", is_ar=False)
+    want = ref.forward(x, t, text, block_causal=True)
+    assert _rel(got.cpu(), want) < 2e-2, _rel(got.cpu(), want)
+    # the chunked loop over the same 5 frames: chunks of 3 + 2
+    from fastgen_amd.methods.distribution_matching.causvid import CausVidModel
+
+    tl = [0.999, 0.5, 0.0]
+    noise = torch.randn(B, 16, 5, 10, 6, generator=g)
+    got = CausVidModel.generator_fn(net, noise.cuda(), student_sample_steps=2, t_list=tl, condition=text.cuda(), student_sample_type="ode")
+    want = R.student_sample_loop(ref, noise * 0.999, torch.tensor(tl, dtype=torch.float64), text, sample_type="ode")
+    assert _rel(got.cpu(), want) < 3e-2, _rel(got.cpu(), want)
