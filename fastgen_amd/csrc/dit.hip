@@ -55,22 +55,73 @@ __device__ __forceinline__ void ln_token(const ST* __restrict__ xrow, int lane, 
     for (int e = 0; e < D / 64; ++e) v[e] *= rstd;
 }
 
-// y[tok][c] = LN(x[tok])[c] * (1 + scale[n][c]) + shift[n][c];  mod [B][mod_stride] holds shift at shift_off, scale at scale_off
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4(const __bf16* p) {
+    const bf16x4 q = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
+}
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4(__bf16* p, f32x4 v) { *reinterpret_cast<bf16x4*>(p) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; }
+
+// y[tok][c] = LN(x[tok])[c] * (1 + scale[n][c]) + shift[n][c];  mod [B][mod_stride] holds shift at shift_off, scale at scale_off.
+// One wave walks FOUR consecutive tokens; lane l holds the channel quads 4 l + 256 j.  The kernel is bound by the NUMBER of its
+// vector-memory instructions, not by their bytes (a wave issues one per ~65-150 cycles whatever its width, MI355X_MICROARCH.md /
+// the cycle stamps of wgrad.hip and gemm.hip): 4-channel pieces (8 / 16 bytes per lane) instead of pairs, and the modulation
+// vectors - the same for every token of an image or frame - loaded once per wave instead of once per token: 36 -> 12.5 instructions
+// per token at D = 1152 (DiT-XL/2, B = 256: 72 -> 62 us = 4.9 TB/s).
 template <typename ST, int D>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const ST* __restrict__ x, const float* __restrict__ mod, int mod_stride,
                                                           int shift_off, int scale_off, ST* __restrict__ y, int ntok, int tpi) {
+    constexpr int NJ = (D + 255) / 256, TPW = 4;
     const int lane = threadIdx.x & 63;
-    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tok >= ntok) return;
-    const int n = tok / tpi;
-    float v[D / 64];
-    ln_token<ST, D>(x + (size_t)tok * D, lane, v);
-    const float* mrow = mod + (size_t)n * mod_stride;
+    const int tok0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW;
+    if (tok0 >= ntok) return;
+    // (the last quad column is ragged when D % 256 != 0: 1152 = 4.5 x 256)
+    auto has = [&](int j) { return j < NJ - 1 || D % 256 == 0 || lane < (D % 256) / 4; };
+    f32x4 sc[NJ], sh[NJ];
+    int n_have = -1;
 #pragma unroll
-    for (int j = 0; j < D / 128; ++j) {
-        const int c = 2 * lane + 128 * j;
-        const f32x2 sc = ld2(mrow + scale_off + c), sh = ld2(mrow + shift_off + c);
-        st2(y + (size_t)tok * D + c, f32x2{fmaf(v[2 * j], 1.0f + sc[0], sh[0]), fmaf(v[2 * j + 1], 1.0f + sc[1], sh[1])});
+    for (int i = 0; i < TPW; ++i) {
+        const int tok = tok0 + i;
+        if (tok >= ntok) break;
+        const int n = tok / tpi;
+        if (n != n_have) {  // (wave-uniform)
+            const float* mrow = mod + (size_t)n * mod_stride;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if (has(j)) {
+                    sc[j] = ld4(mrow + scale_off + 4 * lane + 256 * j) + 1.0f;
+                    sh[j] = ld4(mrow + shift_off + 4 * lane + 256 * j);
+                }
+            n_have = n;
+        }
+        const ST* xrow = x + (size_t)tok * D;
+        f32x4 v[NJ];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (has(j)) v[j] = ld4(xrow + 4 * lane + 256 * j);
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+        const float mean = wave_sum(s) * (1.0f / D);
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (has(j)) {
+                v[j] -= mean;
+                ss = fmaf(v[j][0], v[j][0], ss), ss = fmaf(v[j][1], v[j][1], ss), ss = fmaf(v[j][2], v[j][2], ss), ss = fmaf(v[j][3], v[j][3], ss);
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(ss) * (1.0f / D) + 1e-6f);
+        ST* yrow = y + (size_t)tok * D;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (has(j)) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaf(v[j][e] * rstd, sc[j][e], sh[j][e]);
+                st4(yrow + 4 * lane + 256 * j, o);
+            }
     }
 }
 
@@ -416,7 +467,8 @@ __global__ __launch_bounds__(256, 2) void dit_attention_kernel(const typename DT
 
 template <typename ST>
 int ln_mod_d(int D, const void* x, const float* mod, int ms, int so, int co, void* y, int ntok, int tpi, hipStream_t s) {
-    dim3 g((ntok + 3) / 4), b(256);
+    if ((ms % 4) || (so % 4) || (co % 4)) return (int)hipErrorInvalidValue;  // (16-byte loads of the modulation vectors)
+    dim3 g((ntok + 15) / 16), b(256);  // 4 waves x 4 tokens
     switch (D) {
         case 384: hipLaunchKernelGGL((ln_modulate_kernel<ST, 384>), g, b, 0, s, (const ST*)x, mod, ms, so, co, (ST*)y, ntok, tpi); break;
         case 768: hipLaunchKernelGGL((ln_modulate_kernel<ST, 768>), g, b, 0, s, (const ST*)x, mod, ms, so, co, (ST*)y, ntok, tpi); break;
