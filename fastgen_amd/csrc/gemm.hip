@@ -344,15 +344,19 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         voffW[j] = (unsigned)row * (unsigned)KW2 + sw;
     }
     // regions of buffer b: A half h at b * 65536 + h * 16384, W half h at b * 65536 + 32768 + h * 16384
+    // (the scalar offset through v_readfirstlane: the cursors are uniform by construction, but hipcc kept the A cursor in a VGPR and
+    // wrapped each of its DMA instructions in a waterfall loop - readfirstlane, compare, exec mask, branch - inside the K-loop)
     auto dmaA = [&](int region, int soff) {
+        const int so = __builtin_amdgcn_readfirstlane(soff);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(smem + region + (wave * 2 + j) * 1024), 16, voffA[j], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(smem + region + (wave * 2 + j) * 1024), 16, voffA[j], so, 0, 0);
     };
     auto dmaW = [&](int region, int soff) {
+        const int so = __builtin_amdgcn_readfirstlane(soff);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(smem + region + (wave * 2 + j) * 1024), 16, voffW[j], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(smem + region + (wave * 2 + j) * 1024), 16, voffW[j], so, 0, 0);
     };
     // cursors over the flat K-steps t + 1 and t + 2: scalar byte offsets of their A / W tiles' first row at their k
     struct Cur {
@@ -363,8 +367,8 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         tile_origin(c.ti, m0, n0);
         const int ks_ = item_split(c.ti) * nk + c.kk;                       // K-step of the (virtual) contraction
         const int ka = (a.a_wrap && ks_ >= a.a_wrap) ? ks_ - a.a_wrap : ks_;  // split-bf16: A' = [hi | hi | lo] read out of [hi | lo]
-        c.sa = m0 * KA2 + ka * (GM_KC * 2);
-        c.sw = n0 * KW2 + ks_ * (GM_KC * 2);
+        c.sa = __builtin_amdgcn_readfirstlane(m0 * KA2 + ka * (GM_KC * 2));  // (uniform by construction; keeps the cursor arithmetic on the scalar unit)
+        c.sw = __builtin_amdgcn_readfirstlane(n0 * KW2 + ks_ * (GM_KC * 2));
     };
     auto cur_next = [&](Cur& c) {
         if (++c.kk == nk) c.kk = 0, ++c.ti;
