@@ -112,7 +112,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_kernel(const GemmArgs a) {
         for (int j = 0; j < NT; ++j) offW[j] = (unsigned)min(n0 + srow + 64 * j, a.N - 1) * (unsigned)(a.K * 2) + soct * 16;
     };
     auto issue = [&](int kidx) {
-        const int so = kidx * (GM_KC * 2);
+        const int so = __builtin_amdgcn_readfirstlane(kidx * (GM_KC * 2));  // (uniform; kept off the vector unit: no waterfall loop per load)
 #pragma unroll
         for (int j = 0; j < 4; ++j) pa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, offA[j], so, 0);
 #pragma unroll
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
                 if (a.gate) {
                     const int gi0 = (a.row0 + m0) / a.gate_rows;
                     bnd = (gi0 + 1) * a.gate_rows - a.row0;  // first token (in this launch's rows) of the next gate period
-                    const int gso = (gi0 * a.gate_stride + n0 + 32 * NH) * 4;
+                    const int gso = __builtin_amdgcn_readfirstlane((gi0 * a.gate_stride + n0 + 32 * NH) * 4);
                     g0e = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4, gso, 0));
                     g0o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4 + 16, gso, 0));
                     g1e = g0e, g1o = g0o;
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
                         ve *= nx_ ? g1e : g0e;
                         vo *= nx_ ? g1o : g0o;
                     }
-                    const int so = ((m0 + rb) * a.N + n0 + 32 * NH) * 2;  // (scalar; < 2 GiB: launch_gemm_bf16 chunks the rows)
+                    const int so = __builtin_amdgcn_readfirstlane(((m0 + rb) * a.N + n0 + 32 * NH) * 2);  // (scalar; < 2 GiB: launch_gemm_bf16 chunks the rows)
                     if (a.resid) {
                         const bf16x8 r8 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsR, vo_out, so, 0));
 #pragma unroll
