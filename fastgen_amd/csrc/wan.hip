@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
         // order (one MFMA per ~40-60 cycles of VALU: never a stall on the chain) - then O += V P of tile t.  Tile t + 1 must have
         // landed when iteration t starts: one younger tile (4 DMA instructions) stays in flight over the hand-over barrier.
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x16 sc;  // S^T of the tile whose softmax comes next
+        f32x16 s_a, s_b;  // S^T of the tile whose softmax comes next / of the tile after it: the two swap roles from step to step (no copy)
         {
             bf16x8 kf[KS];
 #pragma unroll
@@ -412,11 +412,11 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) asm volatile("" : "+v"(kf[kk]));
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sc[i] = 0.f;
+            for (int i = 0; i < 16; ++i) s_a[i] = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], sc, 0, 0, 0);
+            for (int kk = 0; kk < KS; ++kk) s_a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], s_a, 0, 0, 0);
         }
-        auto pstep = [&](int t, auto BI_) {
+        auto pstep = [&](int t, auto BI_, f32x16& sc, f32x16& sn) {
             constexpr int BI = decltype(BI_)::value, BN = (BI + 1) % NST;  // tile t sits in buffer BI, tile t + 1 in BN
             if (!(abl & 4)) dma(min(t + 3, nt - 1), (BI + 3) % NST);  // into tile t - 1's buffer: its readers passed the last barrier
             // K rows of tile t + 1 (past the split's end: a re-loaded last tile, result unused), then the V blocks of tile t
@@ -433,9 +433,6 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
                     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vh[sx][d]) : "v"(va[d][1]), "n"(BI * BUF + TILE + 16 * VP * sx));
                 }
             }
-            f32x16 sn;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sn[i] = 0.f;
             // piece 0: mask of a ragged last tile, this lane's maximum
             float mt = -INFINITY;
             if (t == ntiles - 1) {
@@ -449,7 +446,12 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) asm volatile("" : "+v"(kf[kk]));
             __builtin_amdgcn_sched_barrier(0);
-            sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], sn, 0, 0, 0);
+            {  // (C = the inline constant 0: no sixteen v_mov to clear the accumulator)
+                f32x16 z;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) z[i] = 0.f;
+                sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], z, 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             // piece 1: the other half of the query's keys (lane ^ 32), running maximum, rescale factor
             {
@@ -506,30 +508,33 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
             sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[7], qf[7], sn, 0, 0, 0);
             // O^T[dim][query] += V^T[dim][key] P^T[key][query]
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-                for (int d = 0; d < DT_; ++d) asm volatile("" : "+v"(vl[sx][d]), "+v"(vh[sx][d]));
-            __builtin_amdgcn_sched_barrier(0);
+            // (the two halves of an operand are joined BEFORE the tie to the wait: the register allocator can then give the two reads
+            // the halves of one 4-register tuple instead of copying them together in front of every MFMA)
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            s16x8 vv[2][DT_];
 #pragma unroll
             for (int sx = 0; sx < 2; ++sx)
 #pragma unroll
                 for (int d = 0; d < DT_; ++d) {
-                    typedef __attribute__((ext_vector_type(8))) short s16x8;
                     const s16x4 lo = vl[sx][d], hi = vh[sx][d];
-                    const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    if (!(abl & 16)) ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[sx], ot[d], 0, 0, 0);
+                    vv[sx][d] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    asm volatile("" : "+v"(vv[sx][d]));
                 }
-            sc = sn;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                for (int d = 0; d < DT_; ++d)
+                    if (!(abl & 16)) ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv[sx][d]), pf[sx], ot[d], 0, 0, 0);
             // one younger tile (4 instructions) may stay in flight: tile t + 2 has landed; then the hand-over barrier
             if (!(abl & 8)) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
         };
         static_assert(!DMA || KS == 8, "the interleave above is written for eight contraction steps");
         for (int t = t0; t < nt; t += 4) {
-            pstep(t, std::integral_constant<int, 0>{});
-            if (t + 1 < nt) pstep(t + 1, std::integral_constant<int, 1>{});
-            if (t + 2 < nt) pstep(t + 2, std::integral_constant<int, 2>{});
-            if (t + 3 < nt) pstep(t + 3, std::integral_constant<int, 3>{});
+            pstep(t, std::integral_constant<int, 0>{}, s_a, s_b);
+            if (t + 1 < nt) pstep(t + 1, std::integral_constant<int, 1>{}, s_b, s_a);
+            if (t + 2 < nt) pstep(t + 2, std::integral_constant<int, 2>{}, s_a, s_b);
+            if (t + 3 < nt) pstep(t + 3, std::integral_constant<int, 3>{}, s_b, s_a);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may land in an LDS allocation this workgroup has given up
     } else {
