@@ -231,32 +231,34 @@ __global__ __launch_bounds__(WG_THREADS, X3 ? 1 : 2) void conv_wgrad_kernel(cons
             // hipcc sank every compiler-visible read to just before its MFMA, an LDS round trip every two or three MFMAs -
             // 54 full waits per 216 MFMAs with one wave per SIMD and nothing else to issue.)
             struct FR {
-                s16x4 h[2], l[2];  // hi image: pixels k .. k+3 | k+4 .. k+7; lo image (split-bf16 mode only)
+                s16x8 h, l;  // hi image: pixels k .. k+7 (two transposed reads of 4); lo image (split-bf16 mode only)
             };
             const uint32_t a_u = (uint32_t)(uintptr_t)a_lane, d_u = (uint32_t)(uintptr_t)dy_lane;
             const uint32_t a_ul = a_u + LO, d_ul = d_u + LO;
             FR F[4][3], fa[2];
+            // (the two 4-pixel halves of an operand are joined right at the read: the register allocator gives the two reads the halves
+            // of one 4-register tuple - joined only in front of the MFMA they cost two to four v_mov per fragment)
             auto rd = [&](FR& f, uint32_t base, uint32_t base_lo, auto OFF0_, auto OFF1_) __attribute__((always_inline)) {
                 constexpr int O0 = decltype(OFF0_)::value, O1 = decltype(OFF1_)::value;
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.h[0]) : "v"(base), "n"(O0));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.h[1]) : "v"(base), "n"(O1));
+                s16x4 p0, p1;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(p0) : "v"(base), "n"(O0));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(p1) : "v"(base), "n"(O1));
+                f.h = s16x8{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
                 if constexpr (X3) {
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.l[0]) : "v"(base_lo), "n"(O0));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.l[1]) : "v"(base_lo), "n"(O1));
+                    s16x4 q0, q1;
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(q0) : "v"(base_lo), "n"(O0));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(q1) : "v"(base_lo), "n"(O1));
+                    f.l = s16x8{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
                 }
             };
             auto landed = [&](FR& f) __attribute__((always_inline)) {  // (ties the fragment to the wait that precedes this call)
-                asm volatile("" : "+v"(f.h[0]), "+v"(f.h[1]));
-                if constexpr (X3) asm volatile("" : "+v"(f.l[0]), "+v"(f.l[1]));
+                asm volatile("" : "+v"(f.h));
+                if constexpr (X3) asm volatile("" : "+v"(f.l));
             };
             auto as_frag = [&](const FR& f) __attribute__((always_inline)) -> WFrag<X3> {
                 WFrag<X3> w;
-                const s16x8 hv = {f.h[0][0], f.h[0][1], f.h[0][2], f.h[0][3], f.h[1][0], f.h[1][1], f.h[1][2], f.h[1][3]};
-                w.hi.v = __builtin_bit_cast(bf16x8, hv);
-                if constexpr (X3) {
-                    const s16x8 lv = {f.l[0][0], f.l[0][1], f.l[0][2], f.l[0][3], f.l[1][0], f.l[1][1], f.l[1][2], f.l[1][3]};
-                    w.lo.v = __builtin_bit_cast(bf16x8, lv);
-                }
+                w.hi.v = __builtin_bit_cast(bf16x8, f.h);
+                if constexpr (X3) w.lo.v = __builtin_bit_cast(bf16x8, f.l);
                 return w;
             };
             auto load_row = [&](auto HR_) __attribute__((always_inline)) {
