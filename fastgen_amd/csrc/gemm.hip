@@ -508,6 +508,38 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
                 return;
             }
         }
+        if constexpr (EPI == GM_EPI_RAW) {
+            if (!(a.act & 8)) {  // split-K partial sums: fp32 [split][M][N], the same buffer-resource addressing as the token epilogue
+                const int m0 = ep_m0, n0 = ep_n0, mk = ep_mk, nk_ = ep_nk;
+                const bool edge = (mk != m0) || (nk_ != n0);
+                const int c8 = n0 + lane_c8 + 32 * NH;
+                const int sp = item_split(tile);
+                const __amdgpu_buffer_rsrc_t rsS = make_rsrc(a.scratch);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int rb = (MH * 4 + m) * 16;
+                    const int row = m0 + wr * 128 + rb + col;
+                    f32x4 ve = acc[MH * 4 + m][NH * 2], vo = acc[MH * 4 + m][NH * 2 + 1];
+                    acc[MH * 4 + m][NH * 2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc[MH * 4 + m][NH * 2 + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    {
+                        float e0 = ve[0], e1 = ve[1], e2 = ve[2], e3 = ve[3], o0 = vo[0], o1 = vo[1], o2 = vo[2], o3 = vo[3];
+                        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %6\n\t"
+                                     "v_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                                     : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));
+                        ve = f32x4{e0, e1, e2, e3};
+                        vo = f32x4{o0, o1, o2, o3};
+                    }
+                    if (edge && !(row >= mk && c8 >= nk_)) continue;
+                    // (the launcher gives split-K only to grids of < 128 tiles: 4 splits x 128 tiles x 256 KiB of fp32 stay far below 2 GiB)
+                    const int so = __builtin_amdgcn_readfirstlane((((sp * a.M + m0 + rb) * a.N) + n0 + 32 * NH) * 4);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fg_u32x4, ve), rsS, 2 * vo_out, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fg_u32x4, vo), rsS, 2 * vo_out + 16, so, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                return;
+            }
+        }
         if (a.act & 8) {  // (timing experiments: no epilogue at all)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -597,10 +629,6 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) vp[(size_t)e * a.T] = hi[e], vp[(size_t)e * a.T + a.lo_off] = lo[e];
                 }
-            } else if constexpr (EPI == GM_EPI_RAW) {
-                float* prow = a.scratch + ((size_t)item_split(tile) * a.M + row) * a.N + c8;
-                *reinterpret_cast<f32x4*>(prow) = ve;
-                *reinterpret_cast<f32x4*>(prow + 4) = vo;
             } else {
                 const int D = a.heads * a.head_dim;  // % 8 == 0: the 8 outputs lie in one plane and one head
                 const int b = (a.row0 + row) / a.T, t = a.row0 + row - b * a.T;
