@@ -119,6 +119,7 @@ SIGNATURES = {
     "fg_op_images_to_u8": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "fg_op_randn": (c_int, [c_void_p, c_int64, c_uint64, c_uint64, c_void_p]),
     "fg_op_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fg_op_attention_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fg_op_gemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
                                 c_int, c_void_p]),
 }

@@ -251,13 +251,19 @@ __global__ void fourier_kernel(const float* __restrict__ t, float* __restrict__ 
     f[i] = j < half ? cosf(ang) : sinf(ang);
 }
 
-// c = t_emb + table[cls] + r_emb (r_emb nullable);  sc = silu(c)
+// c = t_emb + table[cls] + r_emb (r_emb nullable);  sc = silu(c).  A class index outside the table's `rows` rows (the reference's
+// nn.Embedding device-asserts there) reads nothing: the sample's conditioning becomes NaN and *err (host-visible) is raised - the
+// handle's next call returns FG_EINVAL.
 __global__ void cond_kernel(const float* __restrict__ t_emb, const float* __restrict__ r_emb, const float* __restrict__ table,
-                            const int64_t* __restrict__ cls, float* __restrict__ c, float* __restrict__ sc, int B, int D) {
+                            const int64_t* __restrict__ cls, float* __restrict__ c, float* __restrict__ sc, int B, int D, int rows,
+                            int* __restrict__ err) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * D) return;
     const int b = i / D, d = i - b * D;
-    float v = t_emb[i] + table[(size_t)cls[b] * D + d];
+    const int64_t id = cls[b];
+    const bool ok = id >= 0 && id < rows;
+    if (!ok && d == 0 && err) *err = 1;
+    float v = ok ? t_emb[i] + table[(size_t)id * D + d] : __builtin_nanf("");
     if (r_emb) v += r_emb[i];
     c[i] = v;
     sc[i] = v / (1.0f + expf(-v));
@@ -542,8 +548,8 @@ int launch_dit_fourier(const float* t, float* f, int B, int dim, hipStream_t s) 
     DIT_RET();
 }
 int launch_dit_cond(const float* t_emb, const float* r_emb, const float* table, const int64_t* cls, float* c, float* sc, int B, int D,
-                    hipStream_t s) {
-    hipLaunchKernelGGL(cond_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, t_emb, r_emb, table, cls, c, sc, B, D);
+                    int rows, int* err, hipStream_t s) {
+    hipLaunchKernelGGL(cond_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, t_emb, r_emb, table, cls, c, sc, B, D, rows, err);
     DIT_RET();
 }
 // mode: FG_DTYPE_* (0 exact fp32, 1 bf16, 2 split-bf16 on fp32 tensors).  256 tokens; head_dim 64 or 72.

@@ -1239,57 +1239,77 @@ int fg_op_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, void*
     HIP_TRY(launch_randn(out, total, seed, offset, nullptr, (hipStream_t)stream));
     return FG_OK;
 }
-int fg_op_attention(const void* q, const void* k, const void* v, void* out, int batch, int heads, int head_dim, int lq, int lkv, void* stream) {
+int fg_op_attention_split(const void* q, const void* k, const void* v, void* out, int batch, int heads, int head_dim, int lq, int lkv, int nsplit,
+                          void* stream) {
     if (!q || !k || !v || !out || batch <= 0 || heads <= 0 || lq <= 0 || lkv <= 0 || (head_dim != 128 && head_dim != 72))
         return fail(FG_EINVAL, "fg_op_attention: bad argument (head_dim 128 or 72)");
+    if (nsplit < 0 || nsplit > 8) return fail(FG_EINVAL, "fg_op_attention_split: nsplit must be in [0, 8]");
     const int D = heads * head_dim;
     // key-split scratch for short grids (freed after the stream has drained: a test entry point, not a hot path)
     void* scratch = nullptr;
     HIP_TRY(hipMalloc(&scratch, fa128_scratch_bytes(batch, heads, lq)));
     const int rc = launch_fa(head_dim, q, D, (int64_t)lq * D, k, v, D, (int64_t)lkv * D, out, D, (int64_t)lq * D, batch, heads, lq, lkv,
-                             (hipStream_t)stream, scratch);
+                             (hipStream_t)stream, scratch, nsplit);
     (void)hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(scratch);
     HIP_TRY(rc);
     return FG_OK;
 }
+int fg_op_attention(const void* q, const void* k, const void* v, void* out, int batch, int heads, int head_dim, int lq, int lkv, void* stream) {
+    return fg_op_attention_split(q, k, v, out, batch, heads, head_dim, lq, lkv, 0, stream);
+}
 int fg_op_gemm_bf16(const void* a, const void* w, const float* bias, void* out, int m, int n, int k, int act, const float* gate,
                     int gate_stride, int gate_rows, const void* resid, int tile_order, void* stream) {
+#ifdef FG_TIMING_BUILD
+    const int act_ok = 1 | 4 | 8, order_ok = 255;  // + act 4 / 8: no stores / no epilogue; tile_order 128: cycle stamps (gemm.hip, GM_TIMING)
+#else
+    const int act_ok = 1, order_ok = 127;
+#endif
+    if (act < 0 || (act & ~act_ok)) return fail(FG_EINVAL, "fg_op_gemm_bf16: act must be 0 (none) or 1 (GELU tanh), got %d", act);
+    if (tile_order < 0 || (tile_order & ~order_ok)) return fail(FG_EINVAL, "fg_op_gemm_bf16: bad tile_order %d", tile_order);
+    if ((tile_order & 16) && (tile_order & 32)) return fail(FG_EINVAL, "fg_op_gemm_bf16: tile_order bits 16 and 32 exclude each other");
     GemmArgs g;
     g.A = a; g.W = w; g.bias = bias; g.out = out; g.M = m; g.N = n; g.K = k; g.act = act;
     g.gate = gate; g.gate_stride = gate_stride; g.gate_rows = gate_rows > 0 ? gate_rows : 1; g.resid = resid; g.xn = tile_order & 15;
     g.variant = (tile_order & 16) ? 0 : (tile_order & 32) ? 1 : -1;
     if (!gemm_bf16_supported(g)) return fail(FG_EINVAL, "fg_op_gemm_bf16: unsupported shape (k %% 64, n %% 16, pointers)");
     HIP_TRY(launch_gemm_bf16(g, (hipStream_t)stream, true));
+    // one scratch allocation, released on every path once the stream has drained (a test entry point, not a hot path)
     void* scratch = nullptr;
-    if (tile_order & 64) {  // let short grids split K (scratch freed after the stream has drained: a test entry point)
-        g.scratch_bytes = (size_t)4 * m * n * 4;
-        HIP_TRY(hipMalloc(&scratch, g.scratch_bytes));
-        g.scratch = (float*)scratch;
-    }
-    if (tile_order & 128) {  // (timing experiments) cycle stamps of workgroup 0: printed per tile, see gemm_bf16_pp_kernel's `stamp`
-        HIP_TRY(hipMalloc(&scratch, 65536));
-        HIP_TRY(hipMemsetAsync(scratch, 0, 65536, (hipStream_t)stream));
+    hipError_t herr = hipSuccess;
+#ifdef FG_TIMING_BUILD
+    const bool stamps = (tile_order & 128) != 0;
+    if (stamps && (tile_order & 64)) return fail(FG_EINVAL, "fg_op_gemm_bf16: tile_order bits 64 and 128 exclude each other");
+    if (stamps) {  // cycle stamps of workgroup 0: printed per tile, see gemm_bf16_pp_kernel's `stamp`
+        if ((herr = hipMalloc(&scratch, 65536)) == hipSuccess) herr = hipMemsetAsync(scratch, 0, 65536, (hipStream_t)stream);
         g.scratch = (float*)scratch;
         g.scratch_bytes = 0;
         g.act |= 16;
     }
-    const int rc = launch_gemm_bf16(g, (hipStream_t)stream);
+#endif
+    if (tile_order & 64) {  // let short grids split K
+        g.scratch_bytes = (size_t)4 * m * n * 4;
+        herr = hipMalloc(&scratch, g.scratch_bytes);
+        g.scratch = (float*)scratch;
+    }
+    int rc = herr == hipSuccess ? launch_gemm_bf16(g, (hipStream_t)stream) : (int)herr;
     if (scratch) {
         (void)hipStreamSynchronize((hipStream_t)stream);
-        if (tile_order & 128) {
-            static unsigned long long st[8192];
-            (void)hipMemcpy(st, scratch, 65536, hipMemcpyDeviceToHost);
+#ifdef FG_TIMING_BUILD
+        if (stamps && rc == 0) {
+            std::vector<unsigned long long> st(8192);
+            (void)hipMemcpy(st.data(), scratch, 65536, hipMemcpyDeviceToHost);
             for (int ti = 0; ti < 16 && st[ti * 16]; ++ti) {
                 fprintf(stderr, "tile %2d:", ti);
                 for (int gq = 0; gq < 2; ++gq) {
-                    const unsigned long long* q = st + ti * 16 + gq;  // slot s at q[2 s]
+                    const unsigned long long* q = st.data() + ti * 16 + gq;  // slot s at q[2 s]
                     fprintf(stderr, "  group %d: k-loop %6llu  last k-step %5llu  epilogue %6llu = quadrants %5llu %5llu %5llu %5llu  -> next tile %5llu |", gq,
                             q[2] - q[0], q[4] - q[2], q[6] - q[4], q[8] - q[4], q[10] - q[8], q[12] - q[10], q[6] - q[12], st[(ti + 1) * 16 + gq] ? st[(ti + 1) * 16 + gq] - q[6] : 0ull);
                 }
                 fprintf(stderr, "\n");
             }
         }
+#endif
         (void)hipFree(scratch);
     }
     HIP_TRY(rc);

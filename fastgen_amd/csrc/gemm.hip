@@ -277,6 +277,13 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_kernel(const GemmArgs a) {
 // would serialise the pipeline; the waits here are counted by hand (vmcnt(4) = two half-tiles in flight).
 // Ragged edges: the last token tile / output tile is shifted back to end at M / N (M, N >= 256); what it recomputes of its neighbour
 // tile is not stored again.
+// act bits 4 / 8 / 16 (no stores / no epilogue / cycle stamps) are timing experiments with wrong results: compiled only into
+// libfastgen_amd_timing.so (`make timing`, -DFG_TIMING_BUILD); in the product build the tests fold to false and act is 0 or 1.
+#ifdef FG_TIMING_BUILD
+#define GM_TIMING(x) (x)
+#else
+#define GM_TIMING(x) false
+#endif
 #define GM_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
 template <int EPI>
@@ -448,7 +455,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
     auto slice = [&](auto MH_, auto NH_, int tile, f32x4 be, f32x4 bo) {
         constexpr int MH = decltype(MH_)::value, NH = decltype(NH_)::value;
         if constexpr (EPI == GM_EPI_TOK) {
-            if (!(a.act & 8)) {
+            if (!GM_TIMING(a.act & 8)) {
                 const int m0 = ep_m0, n0 = ep_n0, mk = ep_mk, nk_ = ep_nk;  // (tile_origin / tile_keep_from of `tile`, computed once per tile)
                 const bool edge = (mk != m0) || (nk_ != n0);  // a shifted last tile: part of it is its neighbour's (uniform)
                 const int c8 = n0 + lane_c8 + 32 * NH;
@@ -501,7 +508,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
                     bf16x8 o8;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o8[e] = (__bf16)ve[e], o8[4 + e] = (__bf16)vo[e];
-                    if (a.act & 4) asm volatile("" ::"v"(o8));  // (timing experiments: everything but the store)
+                    if (GM_TIMING(a.act & 4)) asm volatile("" ::"v"(o8));  // (timing build: everything but the store)
                     else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fg_u32x4, o8), rsO, vo_out, so, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -509,7 +516,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
             }
         }
         if constexpr (EPI == GM_EPI_RAW) {
-            if (!(a.act & 8)) {  // split-K partial sums: fp32 [split][M][N], the same buffer-resource addressing as the token epilogue
+            if (!GM_TIMING(a.act & 8)) {  // split-K partial sums: fp32 [split][M][N], the same buffer-resource addressing as the token epilogue
                 const int m0 = ep_m0, n0 = ep_n0, mk = ep_mk, nk_ = ep_nk;
                 const bool edge = (mk != m0) || (nk_ != n0);
                 const int c8 = n0 + lane_c8 + 32 * NH;
@@ -540,7 +547,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
                 return;
             }
         }
-        if (a.act & 8) {  // (timing experiments: no epilogue at all)
+        if (GM_TIMING(a.act & 8)) {  // (timing build: no epilogue at all)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 asm volatile("" ::"v"(acc[MH * 4 + m][NH * 2]), "v"(acc[MH * 4 + m][NH * 2 + 1]));
@@ -710,7 +717,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
     // (timing experiments: act bit 16 = cycle stamps of workgroup 0, waves 0 and 4, into a.scratch: [tile][slot][group])
     int stamp_tile = 0;
     auto stamp = [&](int slot) {
-        if (EPI == GM_EPI_TOK && (a.act & 16) && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0)
+        if (EPI == GM_EPI_TOK && GM_TIMING(a.act & 16) && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0)
             reinterpret_cast<unsigned long long*>(a.scratch)[(stamp_tile * 8 + slot) * 2 + wr] = __builtin_readcyclecounter();
     };
     int t = 0;

@@ -129,7 +129,7 @@ int launch_dit_patch_embed(int dtype, const float* x, const float* w, const floa
                            int p, int D, hipStream_t s);
 int launch_dit_fourier(const float* t, float* f, int B, int dim, hipStream_t s);
 int launch_dit_cond(const float* t_emb, const float* r_emb, const float* table, const int64_t* cls, float* c, float* sc, int B, int D,
-                    hipStream_t s);
+                    int rows, int* err, hipStream_t s);
 // mode 2 (bf16x3): q, k, vt are hi / lo bf16 planes, lo_off elements apart (conv.hip OUT_HEADS writes them so); else lo_off unused
 int launch_dit_attention(int mode, const void* q, const void* k, const void* vt, void* out, int B, int heads, int head_dim, size_t lo_off,
                          hipStream_t s);
@@ -190,7 +190,7 @@ int launch_rms_rope(int D, const void* src, int ld_src, const float* w, float ep
 size_t fa128_scratch_bytes(int B, int heads, int Lq);
 // the same kernel for head dim hd = 128 | 72 (DiT-XL/2's 16 x 72)
 int launch_fa(int hd, const void* q, int ldq, int64_t q_bs, const void* k, const void* v, int ldk, int64_t kv_bs, void* out, int ldo, int64_t o_bs,
-              int B, int heads, int Lq, int Lkv, hipStream_t s, void* scratch = nullptr);
+              int B, int heads, int Lq, int Lkv, hipStream_t s, void* scratch = nullptr, int force_split = 0);
 int launch_fa128(const void* q, int ldq, int64_t q_bs, const void* k, const void* v, int ldk, int64_t kv_bs, void* out, int ldo, int64_t o_bs,
                  int B, int heads, int Lq, int Lkv, hipStream_t s, void* scratch = nullptr);
 int launch_wan_final(int D, const void* x, const float* mod, const float* w, const float* bias, float* out, int ntok, int Fr, int gh, int gw, int C,

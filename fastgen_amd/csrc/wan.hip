@@ -191,6 +191,18 @@ __device__ __forceinline__ s16x4 fa_tr_read(const char* lds_addr) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(uint32_t)(uintptr_t)lds_addr);
 }
 
+// Timing experiments (scripts/fa_ablate.sh) skip one ingredient of the pipelined step each and compute garbage: they exist only in the
+// separately built libfastgen_amd_timing.so (`make timing`, -DFG_TIMING_BUILD); the product kernel has neither the argument nor the tests.
+#ifdef FG_TIMING_BUILD
+#define FA_ABL_PARAM , int abl
+#define FA_ABL_ARG , abl
+#define FA_ABL(bit) (abl & (bit))
+#else
+#define FA_ABL_PARAM
+#define FA_ABL_ARG
+#define FA_ABL(bit) false
+#endif
+
 // HD = 128 (the video DiT) or 72 (DiT-XL/2, 256 tokens: timm Attention as DiTBlock uses it, fastgen/networks/DiT/network.py:168, 191).
 // HD = 72: the K tile's LDS rows are 144 bytes apart (9 x 16 B: 16 consecutive rows at one chunk fall on 16 different 16-byte slots
 // without a swizzle), the V tile's 192; the fifth 16-deep step of the q k^T contraction is half empty (its upper half is zero on the q side, finite row
@@ -199,7 +211,7 @@ template <int HD, int MINW, bool FA_DMA>
 __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict__ q, int ldq, int64_t q_bs, const __bf16* __restrict__ k,
                                                        const __bf16* __restrict__ v, int ldk, int64_t kv_bs, __bf16* __restrict__ out, int ldo,
                                                        int64_t o_bs, int Lq, int Lkv, float scale_log2e, int nsplit, float* __restrict__ po,
-                                                       float* __restrict__ plse, int heads, int batch, int abl) {
+                                                       float* __restrict__ plse, int heads, int batch FA_ABL_PARAM) {
     constexpr int KS = (HD + 15) / 16;   // 16-deep steps of q k^T
     constexpr int DT_ = (HD + 31) / 32;  // 32-wide tiles of output dims
     constexpr int RP = HD * 2;           // LDS row pitch of the K tile
@@ -460,11 +472,11 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
         }
         auto pstep = [&](int t, auto BI_, f32x16& sc, f32x16& sn) {
             constexpr int BI = decltype(BI_)::value, BN = (BI + 1) % NST;  // tile t sits in buffer BI, tile t + 1 in BN
-            if (!(abl & 4)) dma(min(t + 3, nt - 1), (BI + 3) % NST);  // into tile t - 1's buffer: its readers passed the last barrier
+            if (!FA_ABL(4)) dma(min(t + 3, nt - 1), (BI + 3) % NST);  // into tile t - 1's buffer: its readers passed the last barrier
             // K rows of tile t + 1 (past the split's end: a re-loaded last tile, result unused), then the V blocks of tile t
             bf16x8 kf[KS];
             s16x4 vl[2][DT_], vh[2][DT_];
-            if (!(abl & 2)) {
+            if (!FA_ABL(2)) {
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[kk]) : "v"(ka[kk]), "n"(BN * BUF));
 #pragma unroll
@@ -515,7 +527,7 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
 #pragma unroll
                 for (int i = 2 * c; i < 2 * c + 2; ++i) {
                     const f32x2 z = __builtin_elementwise_fma(f32x2{sc[2 * i], sc[2 * i + 1]}, sc2, -mc2);
-                    e2[i] = (abl & 1) ? z : f32x2{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
+                    e2[i] = FA_ABL(1) ? z : f32x2{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2 + c], qf[2 + c], sn, 0, 0, 0);
@@ -567,9 +579,9 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
             for (int sx = 0; sx < 2; ++sx)
 #pragma unroll
                 for (int d = 0; d < DT_; ++d)
-                    if (!(abl & 16)) ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv[sx][d]), pf[sx], ot[d], 0, 0, 0);
+                    if (!FA_ABL(16)) ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv[sx][d]), pf[sx], ot[d], 0, 0, 0);
             // one younger tile (4 instructions) may stay in flight: tile t + 2 has landed; then the hand-over barrier
-            if (!(abl & 8)) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+            if (!FA_ABL(8)) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
         };
         static_assert(!DMA || KS == 8, "the interleave above is written for eight contraction steps");
         for (int t = t0; t < nt; t += 4) {
@@ -756,14 +768,17 @@ int launch_rms_rope(int D, const void* src, int ld_src, const float* w, float ep
 constexpr int FA_MAX_SPLIT = 8;
 size_t fa128_scratch_bytes(int B, int heads, int Lq) { return (size_t)FA_MAX_SPLIT * B * Lq * ((size_t)heads * 128 + heads) * 4 + 256; }
 int launch_fa(int hd, const void* q, int ldq, int64_t q_bs, const void* k, const void* v, int ldk, int64_t kv_bs, void* out, int ldo, int64_t o_bs,
-              int B, int heads, int Lq, int Lkv, hipStream_t s, void* scratch) {
+              int B, int heads, int Lq, int Lkv, hipStream_t s, void* scratch, int force_split) {
     if ((hd != 128 && hd != 72) || Lq <= 0 || Lkv <= 0 || (ldq % 8) || (ldk % 8) || (ldo % 4)) return (int)hipErrorInvalidValue;
+    if (force_split < 0 || force_split > FA_MAX_SPLIT || (force_split > 1 && !scratch)) return (int)hipErrorInvalidValue;
     const int qtiles = (Lq + 127) / 128, ktiles = (Lkv + 31) / 32;
     // key splits: units (sample, head, split) are dealt to the 8 XCDs (fa_kernel's mapping: 32 CUs each, two workgroups resident per CU at
     // half speed each).  Cost in tile iterations (~1.2 us) = workgroups on the fullest CU / 2 x (key tiles per split + ~6 of prologue
     // and epilogue) + the merge pass (fp32 partial outputs read back at ~5 TB/s); every split keeps >= 8 key tiles.
     int nsplit = 1;
-    if (scratch) {
+    if (force_split > 0) {  // (parity tests: the splits of one launch against another's)
+        nsplit = force_split < ktiles ? force_split : ktiles;
+    } else if (scratch) {
         double best = -1.0;
         for (int c = 1; c <= FA_MAX_SPLIT && (c == 1 || ktiles / c >= 8); ++c) {
             const long long ux = ((long long)B * heads * c + 7) / 8, per_cu = (ux * qtiles + 31) / 32;
@@ -780,11 +795,13 @@ int launch_fa(int hd, const void* q, int ldq, int64_t q_bs, const void* k, const
         const char* e = getenv("FASTGEN_AMD_FA_DMA");
         use_dma = (e && e[0] == '0') ? 0 : 1;
     }
-    static int abl = -1;  // (timing experiments only: FASTGEN_AMD_FA_ABL bit mask, see fa_kernel's pipelined step)
+#ifdef FG_TIMING_BUILD
+    static int abl = -1;  // FASTGEN_AMD_FA_ABL bit mask, see fa_kernel's pipelined step (libfastgen_amd_timing.so only)
     if (abl < 0) {
         const char* e = getenv("FASTGEN_AMD_FA_ABL");
         abl = e ? atoi(e) : 0;
     }
+#endif
     static int minw = -1;  // waves per SIMD the kernel is compiled for (register budget 256 | 168): FASTGEN_AMD_FA_WAVES = 2 (default: room for the tile's fragments) | 3
     if (minw < 0) {
         const char* e = getenv("FASTGEN_AMD_FA_WAVES");
@@ -793,7 +810,7 @@ int launch_fa(int hd, const void* q, int ldq, int64_t q_bs, const void* k, const
     const float sc = 1.44269504088896341f / sqrtf((float)hd);
 #define FA_GO(HD, MW, LDS, DM)                                                                                                              \
     hipLaunchKernelGGL((fa_kernel<HD, MW, DM>), g, dim3(256), LDS, s, (const __bf16*)q, ldq, q_bs, (const __bf16*)k, (const __bf16*)v, ldk, kv_bs, \
-                       (__bf16*)out, ldo, o_bs, Lq, Lkv, sc, nsplit, po, plse, heads, B, abl)
+                       (__bf16*)out, ldo, o_bs, Lq, Lkv, sc, nsplit, po, plse, heads, B FA_ABL_ARG)
     if (hd == 128) {
         if ((size_t)Lkv * ldk * 2 >= ((size_t)1 << 31)) return (int)hipErrorInvalidValue;  // (buffer-resource offsets are 32-bit)
         if (!use_dma) FA_GO(128, 2, 32768, false);
@@ -813,7 +830,7 @@ int launch_fa(int hd, const void* q, int ldq, int64_t q_bs, const void* k, const
 }
 int launch_fa128(const void* q, int ldq, int64_t q_bs, const void* k, const void* v, int ldk, int64_t kv_bs, void* out, int ldo, int64_t o_bs,
                  int B, int heads, int Lq, int Lkv, hipStream_t s, void* scratch) {
-    return launch_fa(128, q, ldq, q_bs, k, v, ldk, kv_bs, out, ldo, o_bs, B, heads, Lq, Lkv, s, scratch);
+    return launch_fa(128, q, ldq, q_bs, k, v, ldk, kv_bs, out, ldo, o_bs, B, heads, Lq, Lkv, s, scratch, 0);
 }
 int launch_wan_final(int D, const void* x, const float* mod, const float* w, const float* bias, float* out, int ntok, int Fr, int gh, int gw, int C,
                      float eps, hipStream_t s) {

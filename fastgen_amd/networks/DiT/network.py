@@ -187,6 +187,10 @@ class DiT(FastGenNetwork):
         # one-hot -> class index, an all-zero row -> the extra "unconditional" row (:493-498); training-time label dropout (:120-149)
         if condition.ndim == 2:
             mask = torch.any(condition != 0, dim=1)
+            if self._cfg.embedding_rows == self.num_classes and not bool(mask.all()):
+                # (the table has the extra row only for class_dropout_prob > 0, :116-118; the reference's nn.Embedding device-asserts here)
+                raise ValueError("an all-zero (unconditional) condition row needs the extra row of y_embedder.class_embeddings, "
+                                 "which exists only for class_dropout_prob > 0")
             condition = torch.where(~mask, self.num_classes, condition.argmax(dim=1))
         cls = condition.to(device=dev, dtype=torch.int64)
         if self.training and self.class_dropout_prob > 0:

@@ -127,8 +127,16 @@ class _TrainCall:
         ws = net._train_workspace(h, B, dev)
         if part == _lib.FG_BWD_DECODER:
             self.have_forward = int(getattr(net, "_train_token", None) is self.token and ws.data_ptr() == self.ws_ptr)
+            # from here on the workspace holds THIS call's backward state (its own kept forward, or the one the decoder part re-runs);
+            # any training forward of the module in between takes the ownership away again (`_bwd_owner = None`)
+            net._bwd_owner = self
+            if not self.have_forward:
+                net._train_token = object()  # the re-run forward overwrites whichever call's kept state the workspace held
         elif ws.data_ptr() != self.ws_ptr_bwd:
             raise RuntimeError("the training workspace was replaced between two parts of one backward pass")
+        elif getattr(net, "_bwd_owner", None) is not self:
+            raise RuntimeError("another differentiable forward (or backward) of this module ran between two parts of one backward pass: "
+                               "the encoder / embedding gradients would be computed from its workspace state")
         self.ws_ptr_bwd = ws.data_ptr()
         if self.drop is not None:
             _lib.check(L.fg_edm_set_dropout(h, self.drop[0], self.drop[1]))
@@ -205,6 +213,7 @@ class _EDMForwardFn(torch.autograd.Function):
         # the training workspace now holds this call's state; any later training forward of the module replaces the token, and
         # the backward of this call then recomputes its forward
         call.token = net._train_token = object()
+        net._bwd_owner = None
         call.ws_ptr, call.ntap = ws.data_ptr(), ntap
         call.saved = (x32, t64, r64, labels)  # plain inputs (no graph): held by the call object
         call.want_dx = bool(x32.requires_grad)
@@ -765,6 +774,7 @@ class EDMPrecond(FastGenNetwork):
         try:
             ws = self._train_workspace(h, B, dev)
             self._train_token = object()  # the kept state of an earlier training forward is overwritten
+            self._bwd_owner = None
             out, jv = torch.empty_like(x32), torch.empty_like(x32)
             p = lambda a: ctypes.c_void_p(a.data_ptr() if a is not None else None)
             with self._AugmentScope(h, aug):

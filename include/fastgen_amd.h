@@ -305,7 +305,9 @@ FG_API size_t fg_dit_workspace_bytes(const fg_dit* h, int batch);
 /* The network part of DiT.forward (:511-547): patch embedding + positional table, conditioning vector, the transformer blocks,
  * output projection, unpatchify.  x_t, out: [B,C,H,W] fp32; t, r: [B] fp32 AS THE EMBEDDERS SEE THEM (after prepare_t's rescaling,
  * :457-462, the SiT flip :503-504 and, for time_cond_type 'diff', the t - r difference :520-521: scalar host-side plumbing);
- * r NULL = no r embedding; class_ids: [B] int64 row of the class table (num_classes = the unconditional row, :493-498);
+ * r NULL = no r embedding; class_ids: [B] int64 row of the class table (num_classes = the unconditional row, :493-498); an id outside
+ * [0, embedding_rows) makes that sample's output NaN and the NEXT call on the handle return FG_EINVAL (the reference's nn.Embedding
+ * device-asserts; the check cannot surface in the asynchronous call itself);
  * cond_out (nullable): [B, hidden_size] conditioning vector c.  Prediction-type conversion and the SiT sign stay with the caller. */
 FG_API int fg_dit_forward(fg_dit* h, const float* x_t, const float* t, const float* r, const int64_t* class_ids, float* out,
                           float* cond_out, int batch, void* workspace, size_t workspace_bytes, void* stream);
@@ -353,7 +355,8 @@ FG_API int fg_wan_set_text(fg_wan* h, const float* text, int batch, int text_len
  * t_frames: [B * frames] fp32 AS THE EMBEDDER SEES THEM (rescale_t: 1000 t, `_compute_timestep_inputs` :1063-1075).  The chunk's
  * keys / values are written to cache rows [cur_start_frame * frame_seqlen, +frames * frame_seqlen) in every call and attention runs
  * over rows [0, that end): with store_kv = 0 the rows are rewritten by the chunk's later store_kv = 1 call, as in the reference's
- * loop (causvid.py:150-172), where only that call moves the cache length. */
+ * loop (causvid.py:150-172), where only that call moves the cache length.  Restriction: a store_kv = 0 call whose rows were filled by
+ * an earlier store_kv = 1 call (re-evaluating a stored chunk; the reference leaves its cache untouched there) returns FG_EINVAL. */
 FG_API int fg_wan_forward(fg_wan* h, const float* x_t, const float* t_frames, float* out, int batch, int frames, int height, int width,
                           int cur_start_frame, int store_kv, void* workspace, size_t workspace_bytes, void* stream);
 /* The teacher- / diffusion-forcing call over ALL frames: `CausalWan.forward(x_t, t, is_ar=False)` with frames == total_num_frames, where the
@@ -377,10 +380,15 @@ FG_API int fg_op_randn(float* out, int64_t total, uint64_t seed, uint64_t offset
  * Exposed for the parity tests. */
 FG_API int fg_op_attention(const void* q, const void* k, const void* v, void* out, int batch, int heads, int head_dim, int lq, int lkv,
                            void* stream);
+/* The same with the number of key splits fixed: nsplit 0 = the launcher's cost model (what the networks run), 1 = one workgroup walks
+ * all keys of its query tile, 2 .. 8 = that many workgroups share them and a merge pass combines their partial outputs by
+ * log-sum-exp.  For the parity tests: the split paths against each other at the video DiT's full sequence lengths. */
+FG_API int fg_op_attention_split(const void* q, const void* k, const void* v, void* out, int batch, int heads, int head_dim, int lq, int lkv,
+                                 int nsplit, void* stream);
 /* The transformer blocks' token GEMM in the bf16 compute mode (gemm.hip; reference: the nn.Linear calls of DiTBlock,
  * fastgen/networks/DiT/network.py:168-198, under bf16 autocast): out[m][n] = resid[m][n] + gate[(m / gate_rows) * gate_stride + n] *
  * act(sum_k a[m][k] w[n][k] + bias[n]) with a [m][k], w [n][k], resid / out [m][n] in bf16, fp32 accumulation, bias / gate fp32;
- * act 0 none, 1 GELU(tanh); bias, gate, resid nullable.  k % 64 == 0, n % 16 == 0.  tile_order: 0 linear, 1 XCD-aware (launcher's
+ * act 0 none, 1 GELU(tanh) (anything else: FG_EINVAL); bias, gate, resid nullable.  k % 64 == 0, n % 16 == 0.  tile_order: 0 linear, 1 XCD-aware (launcher's
  * choice), 2 / 4 / 8 XCD columns over n; + 16 forces the register-staged kernel, + 32 the LDS-DMA ping-pong kernel (default: the
  * latter where m, n >= 256), + 64 lets grids of fewer tiles than half the CUs split K (fp32 partial sums + a finishing pass).  Exposed for the parity tests and scripts/gemm_bench.py. */
 FG_API int fg_op_gemm_bf16(const void* a, const void* w, const float* bias, void* out, int m, int n, int k, int act, const float* gate,

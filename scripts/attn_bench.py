@@ -6,6 +6,7 @@ around the launch: host-side timers would measure that):
 Shapes: video DiT 1.3B self-attention of chunk k (4680 queries over 1560 * 3 (k + 1) keys, 12 heads x 128), its cross-attention (512 text
 keys), DiT-XL/2 (B = 256, 16 heads x 72, 256 tokens)."""
 import ctypes
+import os
 import glob
 import sys
 
@@ -45,6 +46,8 @@ if "--parse" in sys.argv:
 import torch
 
 from fastgen_amd import _lib
+if os.environ.get("FA_TIMING_LIB") == "1":  # scripts/fa_ablate.sh: the FASTGEN_AMD_FA_ABL switches exist only in the timing library
+    _lib.LIB_PATH = _lib.LIB_PATH.replace("libfastgen_amd.so", "libfastgen_amd_timing.so")
 
 L = _lib.lib()
 p = lambda t: ctypes.c_void_p(t.data_ptr())

@@ -2,6 +2,8 @@
 # Timing builds of fa_kernel<128> that skip one ingredient of the loop each (FASTGEN_AMD_FA_ABL bit mask: 1 exponentials, 2 fragment
 # reads, 4 LDS-DMA, 8 hand-over barrier, 16 the O += V P MFMAs), and the register-prefetch variant.  Run on the GPU box from the repo root.
 export PYTHONPATH=$PWD
+# the switches exist only in the timing library: build it first (`make -C fastgen_amd/csrc timing`); attn_bench.py loads it when FA_TIMING_LIB=1
+export FA_TIMING_LIB=1
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 run() {
   rm -rf gpurun_out/attn

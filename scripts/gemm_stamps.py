@@ -2,6 +2,7 @@
 import ctypes, sys
 import torch
 from fastgen_amd import _lib
+_lib.LIB_PATH = _lib.LIB_PATH.replace("libfastgen_amd.so", "libfastgen_amd_timing.so")  # `make -C fastgen_amd/csrc timing` (act bits 4 / 8 / 16 exist only there)
 L = _lib.lib()
 p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -146,3 +146,33 @@ def test_flow_sampler_against_oracle():
         vu, vc = v.chunk(2)
         x = x + (tn - t).to(x.dtype) * (vu + 2.0 * (vc - vu))
     assert float((got - x).abs().max()) <= 5e-4 and float((got - x).norm() / x.norm()) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_class_index_outside_the_embedding_table_is_reported():
+    """`y_embedder.class_embeddings` has the extra "unconditional" row only for class_dropout_prob > 0 (DiT/network.py:116-118).  Without
+    it an all-zero one-hot row (-> index num_classes) or any out-of-range id would read past the table; the reference's nn.Embedding
+    device-asserts.  Here: the one-hot form is refused up front; an id tensor poisons that sample (NaN, nothing is clamped or read) and
+    the handle's next call reports it."""
+    from fastgen_amd import _lib
+    from fastgen_amd.networks.DiT.network import DiT
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = DiT(class_dropout_prob=0.0, compute_dtype="bf16x3", **KW["s"]).to(dev).eval()
+    assert net.state_dict()["y_embedder.class_embeddings.weight"].shape[0] == 1000
+    x = torch.randn(2, 4, 32, 32, device=dev)
+    t = torch.tensor([0.7, 0.3], dtype=torch.float64, device=dev)
+    cond = torch.zeros(2, 1000, device=dev)
+    cond[0, 5] = 1.0
+    with torch.inference_mode():
+        with pytest.raises(ValueError, match="class_dropout_prob"):
+            net(x, t, condition=cond)
+        good = net(x, t, condition=torch.tensor([5, 999], device=dev))
+        assert torch.isfinite(good).all()
+        bad = net(x, t, condition=torch.tensor([5, 1000], device=dev))
+        torch.cuda.synchronize()
+        assert torch.equal(bad[0], good[0]) and torch.isnan(bad[1]).all()
+        with pytest.raises(_lib.FastGenAMDError, match="class index"):
+            net(x, t, condition=torch.tensor([5, 999], device=dev))
+        assert torch.equal(net(x, t, condition=torch.tensor([5, 999], device=dev)), good)  # reported once, then back to normal

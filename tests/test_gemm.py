@@ -37,10 +37,16 @@ def _ref(a, w, bias=None, act=0, gate=None, gate_rows=1, resid=None):
     return v
 
 
-@pytest.mark.parametrize("m,n,k", [(256, 256, 64), (512, 192, 128), (1000, 1152, 1152), (4680, 1536, 1536), (77, 3456, 1152),
-                                    (2048, 4608, 1152), (2048, 1152, 4608), (300, 64, 256), (513, 384, 384)])
-@pytest.mark.parametrize("order", [0, 1, 16 + 1, 32 + 0, 32 + 1])
-def test_plain_gemm_matches_fp32_matmul_of_the_same_operands(m, n, k, order):
+_SHAPES = [(256, 256, 64), (512, 192, 128), (1000, 1152, 1152), (4680, 1536, 1536), (77, 3456, 1152), (2048, 4608, 1152), (2048, 1152, 4608),
+           (300, 64, 256), (513, 384, 384)]
+# every shape in the launcher's own choice of kernel and tile order (1) and forced onto each kernel (16 + 1 register-staged, 32 + 1 LDS-DMA
+# ping-pong); the linear tile orders (0, 32 + 0) on the shapes with the most tiles
+_CASES = [(s, o) for s in _SHAPES for o in (1, 16 + 1, 32 + 1)] + [(s, o) for s in _SHAPES[2:7:2] for o in (0, 32 + 0)]
+
+
+@pytest.mark.parametrize("shape,order", _CASES)
+def test_plain_gemm_matches_fp32_matmul_of_the_same_operands(shape, order):
+    m, n, k = shape
     g = torch.Generator().manual_seed(m * 7 + n * 3 + k)
     a = torch.randn(m, k, generator=g).bfloat16().cuda()
     w = (torch.randn(n, k, generator=g) * k ** -0.5).bfloat16().cuda()
@@ -101,6 +107,17 @@ def test_unsupported_shapes_are_refused():
     w = torch.zeros(64, 96, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(_lib.FastGenAMDError):
         _run(a, w)  # k % 64 != 0
+    # the timing experiments (no stores / no epilogue / cycle stamps: act bits 4 / 8 / 16, tile_order bit 128) are not in the product
+    # library: anything but act 0 / 1 is refused instead of silently computing garbage
+    a = torch.zeros(256, 128, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(256, 128, dtype=torch.bfloat16, device="cuda")
+    for act in (2, 4, 8, 16, 5, -1):
+        with pytest.raises(_lib.FastGenAMDError, match="act must be"):
+            _run(a, w, act=act)
+    for order in (128, 128 + 33, 16 + 32, 256):
+        with pytest.raises(_lib.FastGenAMDError, match="tile_order"):
+            _run(a, w, order=order)
+    assert torch.equal(_run(a, w, act=1), torch.zeros(256, 256, dtype=torch.bfloat16, device="cuda"))
 
 
 @pytest.mark.parametrize("m,n,k,rows", [(4680, 3072, 1536, 1560), (2900, 1152, 1152, 300), (1024, 512, 256, 256)])

@@ -366,14 +366,14 @@ def mf_sd():
 @pytest.fixture(scope="module")
 def mf_nets(mf_sd):
     out = {}
-    for mode in ("fp32", "bf16"):
+    for mode in ("fp32", "bf16x3", "bf16"):  # bf16x3 = what the module computes outside autocast (DEFAULT_FP32_MODE): held to the fp32 tolerance
         n = EDMPrecond(compute_dtype=mode, **KW_MF)
         n.load_state_dict(mf_sd, strict=True)
         out[mode] = n.to(dev()).eval()
     return out
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16"])
 def test_meanflow_forward_against_reference_golden(mf_nets, mf_sd, golden_dir, mode):
     fx = load(golden_dir, "meanflow_full_b2.pt")
     net = mf_nets[mode]
@@ -394,7 +394,7 @@ def test_meanflow_forward_against_reference_golden(mf_nets, mf_sd, golden_dir, m
             check(nv(x, t, r=r), fx[f"out_drop_{dp}"], mode, f"drop_precond={dp}")
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16"])
 def test_meanflow_sampler_against_reference_golden(mf_nets, golden_dir, mode):
     fx = load(golden_dir, "meanflow_full_b2.pt")
     net = mf_nets[mode]
@@ -429,7 +429,7 @@ def test_meanflow_batch16_against_oracle(mf_nets, mf_sd):
     cfg = R.CIFAR10_MEANFLOW
     want_sde = R.generator_fn(mf_sd, cfg, noise, None, 4, sample_type="sde", eps_list=eps, loop="meanflow")
     want_ode = R.generator_fn(mf_sd, cfg, noise, None, 2, sample_type="ode", loop="meanflow")
-    for mode in ("fp32", "bf16"):
+    for mode in ("fp32", "bf16x3", "bf16"):
         got = MeanFlowModel.generator_fn(mf_nets[mode], noise.to(dev()), student_sample_steps=4,
                                          student_sample_type="sde", eps=torch.stack(eps).to(dev()))
         check(got, want_sde, mode, f"meanflow B=16 sde {mode}")
@@ -441,7 +441,7 @@ def test_meanflow_batch16_against_oracle(mf_nets, mf_sd):
 # ---- encoder feature taps (the DMD2 discriminator's inputs, EDM/network.py:525-544) ------------------------------------
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16"])
 def test_feature_taps(nets, sd, golden_dir, mode):
     fx = load(golden_dir, "forward_full_b2.pt")
     net = nets[mode]
@@ -475,7 +475,7 @@ def test_feature_taps(nets, sd, golden_dir, mode):
             net(xd, td, condition=cd, feature_indices={0, 7}, return_features_early=True)
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16"])
 def test_teacher_euler_sampler(nets, golden_dir, mode):
     """EDMPrecond.sample (EDM/network.py:976-1026): Euler steps with classifier-free guidance through the module's forward.
     The reference evaluates the network in float64 from the second step on (x is promoted by the division by t); this engine
@@ -492,10 +492,11 @@ def test_teacher_euler_sampler(nets, golden_dir, mode):
         check(out, fx["out_plain"], mode, "Euler sampler without guidance")
 
 
-def test_meanflow_full_size_properties(mf_nets):
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_meanflow_full_size_properties(mf_nets, mode):
     """MeanFlow sampler at batch 512: per-image independence (bit-exact vs. the same images in a batch of 16), determinism,
     seed control, and agreement of 'ode' one-step with a hand-written x - t * u(x, t, 0)."""
-    net = mf_nets["bf16"]
+    net = mf_nets[mode]
     B = 512
     noise = seeded((B, 3, 32, 32), 13).to(dev())
     eps = torch.stack([seeded((B, 3, 32, 32), s) for s in (14, 15, 16)]).to(dev())
@@ -1025,21 +1026,25 @@ def test_module_autograd_feature_taps_and_input_gradient(nets, golden_dir):
         net.zero_grad(set_to_none=True)
 
 
-def test_meanflow_network_backward_against_reference_golden(mf_nets, golden_dir):
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_meanflow_network_backward_against_reference_golden(mf_nets, golden_dir, mode):
     """Autograd through the MeanFlow network (r_timestep embedding, drop_precond='both', unconditional, flow prediction): every
-    parameter gradient and the input gradient against the reference's autograd (tests/golden/meanflow_backward_b2.pt);
-    relative L2 of the sampled entries <= 1e-1 for every tensor, <= 6e-2 for 95 % of them, median <= 4e-2; norms within 3 %."""
+    parameter gradient and the input gradient against the reference's autograd (tests/golden/meanflow_backward_b2.pt).
+    bf16x3 (the module's arithmetic without autocast = the reference's fp32 training precision for this config): relative L2 of the
+    sampled entries <= 1e-3 for EVERY tensor, norms within 1e-3.  bf16: <= 1e-1 for every tensor, <= 6e-2 for 95 % of them, median
+    <= 4e-2; norms within 3 %."""
     fx = load(golden_dir, "meanflow_backward_b2.pt")
-    net = mf_nets["bf16"]
+    net = mf_nets[mode]
+    x3 = mode == "bf16x3"
     params = dict(net.named_parameters())
     x = seeded((2, 3, 32, 32), 61).to(dev()).requires_grad_(True)
     dout = seeded((2, 3, 32, 32), 62).to(dev())
     try:
         net.zero_grad(set_to_none=True)
         out = net(x, fx["t"].to(dev()), r=fx["r"].to(dev()))
-        check(out, fx["out"], "bf16", "MeanFlow forward under autograd")
+        check(out, fx["out"], mode, "MeanFlow forward under autograd")
         out.backward(dout)
-        assert float((x.grad.cpu() - fx["dx"]).norm() / fx["dx"].norm()) <= 8e-2
+        assert float((x.grad.cpu() - fx["dx"]).norm() / fx["dx"].norm()) <= (1e-3 if x3 else 8e-2)
         assert len(fx["names"]) > 400
         errs = []
         for n in fx["names"]:
@@ -1047,16 +1052,19 @@ def test_meanflow_network_backward_against_reference_golden(mf_nets, golden_dir)
             smp = g[:: max(1, g.numel() // 512)][:512]
             want = fx[f"{n}/sample"]
             errs.append((float((smp - want).norm() / want.norm().clamp_min(1e-20)), n))
-            assert abs(float(g.double().norm()) / float(fx[f"{n}/norm"]) - 1) <= 3e-2, n
+            assert abs(float(g.double().norm()) / float(fx[f"{n}/norm"]) - 1) <= (1e-3 if x3 else 3e-2), n
         errs.sort(reverse=True)
-        print("worst five:", errs[:5], "median:", errs[len(errs) // 2][0])
-        # Accumulated bf16 rounding: every block's backward stores ~6 gradient tensors in bf16 (2^-9 relative each), so after 36
-        # blocks the gradient signal carries sqrt(6 * 36) * 2^-9 ~ 3 % of independent noise - what bf16 autocast training has on
-        # any backend; largest where few pixels are summed (8x8 layers at B = 2).  Every tensor <= 1e-1, 95 % <= 6e-2, median
-        # <= 4e-2; the norms (above) within 3 %.  The per-block tests bound each block at 2e-2.
-        assert errs[0][0] <= 1e-1, errs[:5]
-        assert errs[len(errs) // 20][0] <= 6e-2, errs[: len(errs) // 20 + 1]
-        assert errs[len(errs) // 2][0] <= 4e-2
+        print(mode, "worst five:", errs[:5], "median:", errs[len(errs) // 2][0])
+        if x3:
+            assert errs[0][0] <= 1e-3, errs[:5]
+        else:
+            # Accumulated bf16 rounding: every block's backward stores ~6 gradient tensors in bf16 (2^-9 relative each), so after 36
+            # blocks the gradient signal carries sqrt(6 * 36) * 2^-9 ~ 3 % of independent noise - what bf16 autocast training has on
+            # any backend; largest where few pixels are summed (8x8 layers at B = 2).  Every tensor <= 1e-1, 95 % <= 6e-2, median
+            # <= 4e-2; the norms (above) within 3 %.  The per-block tests bound each block at 2e-2.
+            assert errs[0][0] <= 1e-1, errs[:5]
+            assert errs[len(errs) // 20][0] <= 6e-2, errs[: len(errs) // 20 + 1]
+            assert errs[len(errs) // 2][0] <= 4e-2
     finally:
         net.zero_grad(set_to_none=True)
 

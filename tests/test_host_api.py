@@ -45,6 +45,15 @@ def test_library_exports_nothing_but_its_api():
     assert funcs and all(f.startswith("fg_") for f in funcs), [f for f in funcs if not f.startswith("fg_")]
 
 
+def test_no_timing_switches_in_the_product_library():
+    """The attention kernel's FASTGEN_AMD_FA_ABL switches and the token GEMM's act bits 4 / 8 / 16 skip work and compute garbage: they
+    exist only in libfastgen_amd_timing.so (`make -C fastgen_amd/csrc timing`, -DFG_TIMING_BUILD), never in the product library - no
+    environment variable may corrupt its outputs.  (act values other than 0 / 1 are refused: tests/test_gemm.py, on the GPU.)"""
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"FASTGEN_AMD_FA_ABL" not in blob
+    assert b"act must be 0 (none) or 1 (GELU tanh)" in blob  # the refusal itself is in
+
+
 def test_create_rejects_unsupported_configs():
     L = _lib.lib()
     cfg = _lib.fg_edm_config()

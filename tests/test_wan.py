@@ -113,11 +113,21 @@ def test_autoregressive_calls_against_oracle():
             got = net(x[:, :, lo:hi].cuda(), tt.cuda(), condition=text.cuda(), fwd_pred_type="flow", cur_start_frame=lo, store_kv=store, is_ar=True)
             assert got.shape == want.shape
             assert _rel(got.cpu(), want) < 2e-2, (lo, t, store, _rel(got.cpu(), want))
-        # the x0 conversion of the RF schedule: x0 = x_t - t * flow
+        # a store_kv = False call on frames whose keys / values are stored would clobber them for later chunks (this build writes the
+        # chunk's K / V to its cache rows in every call; the reference leaves its cache alone there): refused, not answered differently
+        from fastgen_amd import _lib
+
         tt = torch.full((B,), 0.6, dtype=torch.float64)
-        got = net(x[:, :, 2:4].cuda(), tt.cuda(), condition=text.cuda(), fwd_pred_type="x0", cur_start_frame=2, is_ar=True)
-        want = x[:, :, 2:4] - 0.6 * ref.forward(x[:, :, 2:4], tt, text, cur_start_frame=2)
+        with pytest.raises(_lib.FastGenAMDError, match="store_kv = 0"):
+            net(x[:, :, 2:4].cuda(), tt.cuda(), condition=text.cuda(), fwd_pred_type="x0", cur_start_frame=2, is_ar=True)
+        # the x0 conversion of the RF schedule: x0 = x_t - t * flow (frames 4-5: behind everything stored)
+        x45 = torch.randn(B, 16, 2, H, W, generator=g)
+        got = net(x45.cuda(), tt.cuda(), condition=text.cuda(), fwd_pred_type="x0", cur_start_frame=4, is_ar=True)
+        want = x45 - 0.6 * ref.forward(x45, tt, text, cur_start_frame=4)
         assert _rel(got.cpu(), want) < 2e-2
+        net.clear_caches()
+        # ... and after clear_caches nothing is stored any more
+        net(x[:, :, 2:4].cuda(), tt.cuda(), condition=text.cuda(), fwd_pred_type="x0", cur_start_frame=2, is_ar=True)
         net.clear_caches()
 
 
@@ -142,6 +152,102 @@ def test_width_of_the_1p3b_network_against_oracle():
             want = ref.forward(x[:, :, lo:hi], tt, text, cur_start_frame=lo, store_kv=store)
             got = net(x[:, :, lo:hi].cuda(), tt.cuda(), condition=text.cuda(), fwd_pred_type="flow", cur_start_frame=lo, store_kv=store, is_ar=True)
             assert _rel(got.cpu(), want) < 2e-2, (lo, _rel(got.cpu(), want))
+
+
+@pytest.mark.gpu
+def test_width_of_the_14b_network_against_oracle():
+    """Inner dim 5120 (40 heads), MLP 13824 (`Wan2.1-T2V-14B`, fastgen/configs/net.py:180-181): the widest configuration the C ABI lists
+    (include/fastgen_amd.h, fg_wan_config) - RMSNorm / LayerNorm / output kernels at 40 x 128, GEMMs with K = 5120 / 13824 - two layers,
+    two chunks of two 16 x 16-token frames."""
+    from fastgen_amd.networks.Wan.network_causal import CausalWan
+
+    cfg = R.WanConfig(num_heads=40, head_dim=128, text_dim=256, ffn_dim=13824, num_layers=2, chunk_size=2, total_num_frames=4)
+    sd = R.random_state_dict(cfg, 31)
+    ref = R.CausalWanRef(sd, cfg)
+    net = CausalWan(num_attention_heads=40, attention_head_dim=128, text_dim=256, ffn_dim=13824, num_layers=2, chunk_size=2, total_num_frames=4)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(1, 16, 4, 32, 32, generator=g)
+    text = torch.randn(1, 64, 256, generator=g)
+    with torch.inference_mode():
+        for (lo, hi, t, store) in [(0, 2, 0.0, True), (2, 4, 0.5, False)]:
+            tt = torch.full((1,), t, dtype=torch.float64)
+            want = ref.forward(x[:, :, lo:hi], tt, text, cur_start_frame=lo, store_kv=store)
+            got = net(x[:, :, lo:hi].cuda(), tt.cuda(), condition=text.cuda(), fwd_pred_type="flow", cur_start_frame=lo, store_kv=store, is_ar=True)
+            assert _rel(got.cpu(), want) < 2e-2, (lo, _rel(got.cpu(), want))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames,H,W", [(21, 60, 104), (16, 90, 160)])
+def test_full_size_video_shapes_properties(frames, H, W):
+    """The 1.3B network (30 layers, 12 heads, MLP 8960, text 512 x 4096) on the real latent shapes - 480p / 21 frames
+    (configs/experiments/WanT2V/config_sf.py:19-43: `[16, 21, 60, 104]`, chunks of 3) and BASELINE.json's 720p / 16 frames (`[16, 16, 90, 160]`:
+    the remainder frame joins the first chunk) - which no oracle run reaches (32 760 / 57 600 tokens).  Size-independent properties:
+    finite, run-to-run identical, and the block-wise causal call over all frames == the autoregressive calls chunk by chunk over the
+    cache that the earlier chunks' store_kv calls left (same keys, same RoPE positions, same per-frame timestep) within the bf16
+    tolerance.  Only these sizes reach the key-split attention at 7+ chunks of keys, split-K token GEMMs beside full grids, and the
+    32-bit buffer-offset guards."""
+    from fastgen_amd.networks.Wan.network_causal import CausalWan
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(frames)
+    net = CausalWan(total_num_frames=frames).to(dev).eval()  # defaults = Wan2.1-T2V-1.3B, chunk_size 3
+    g = torch.Generator(device=dev).manual_seed(100 + frames)
+    x = torch.randn(1, 16, frames, H, W, generator=g, device=dev)
+    text = torch.randn(1, 512, 4096, generator=g, device=dev)
+    t = torch.full((1, frames), 0.4, dtype=torch.float64, device=dev)
+    with torch.inference_mode():
+        full = net(x, t, condition=text, fwd_pred_type="flow", is_ar=False)
+        assert full.shape == x.shape and torch.isfinite(full).all()
+        assert float(full.std()) > 1e-3  # (not a degenerate all-equal output)
+        assert torch.equal(full, net(x, t, condition=text, fwd_pred_type="flow", is_ar=False))  # fixed-order reductions: bit-identical
+        rem = frames % 3
+        bounds = [0] + [3 * (i + 1) + rem for i in range(frames // 3)]
+        outs = []
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            o = net(x[:, :, a:b], t[:, 0], condition=text, fwd_pred_type="flow", cur_start_frame=a, store_kv=True, is_ar=True)
+            assert torch.isfinite(o).all()
+            r = _rel(o, full[:, :, a:b])
+            assert r < 2e-2, (a, b, r)
+            outs.append(o)
+        # the last chunk once more over the complete cache: the same bits (the K / V it rewrites are the ones already there)
+        o2 = net(x[:, :, bounds[-2]:], t[:, 0], condition=text, fwd_pred_type="flow", cur_start_frame=bounds[-2], store_kv=True, is_ar=True)
+        assert torch.equal(o2, outs[-1])
+        net.clear_caches()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Lq,Lkv", [(4680, 32760), (10800, 57600)])
+def test_key_split_attention_at_full_length(Lq, Lkv):
+    """The last chunk's self-attention of the 480p / 720p video shapes (one sample, 12 heads x 128): the launcher's key-split choice
+    (cost model) against one workgroup per query tile walking all keys, against a forced 8-way split, and against fp32 softmax
+    attention of the same bf16 operands."""
+    from fastgen_amd import _lib
+
+    B, H, hd = 1, 12, 128
+    g = torch.Generator(device="cuda").manual_seed(Lkv)
+    q = torch.randn(B, Lq, H * hd, generator=g, device="cuda").bfloat16()
+    k = torch.randn(B, Lkv, H * hd, generator=g, device="cuda").bfloat16()
+    v = torch.randn(B, Lkv, H * hd, generator=g, device="cuda").bfloat16()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    outs = {}
+    for ns in (0, 1, 8):
+        out = torch.full_like(q, float("nan"))
+        _lib.check(_lib.lib().fg_op_attention_split(p(q), p(k), p(v), p(out), B, H, hd, Lq, Lkv, ns,
+                                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all()
+        outs[ns] = out
+    want = torch.empty(B, Lq, H * hd, device="cuda")
+    for h in range(H):  # fp32, one head at a time (Lq x Lkv scores: 0.6 / 2.5 GB)
+        sl = slice(h * hd, (h + 1) * hd)
+        sc = torch.softmax(q[0, :, sl].float() @ k[0, :, sl].float().t() * hd ** -0.5, dim=-1)
+        want[0, :, sl] = sc @ v[0, :, sl].float()
+        del sc
+    for ns, out in outs.items():
+        assert _rel(out, want) < 1e-2, (ns, _rel(out, want))
+    assert _rel(outs[0], outs[1]) < 4e-3 and _rel(outs[8], outs[1]) < 4e-3  # (two bf16 roundings of nearly equal fp32 values)
 
 
 @pytest.mark.gpu
