@@ -11,7 +11,7 @@ FG_MAX_LEVELS = 8
 FG_DTYPE_F32, FG_DTYPE_BF16, FG_DTYPE_BF16X3 = 0, 1, 2
 DTYPE_NAMES = {"fp32": FG_DTYPE_F32, "bf16": FG_DTYPE_BF16, "bf16x3": FG_DTYPE_BF16X3}
 FG_SAMPLE_SDE, FG_SAMPLE_ODE = 0, 1
-FG_LOOP_X0, FG_LOOP_MEANFLOW = 0, 1
+FG_LOOP_X0, FG_LOOP_MEANFLOW, FG_LOOP_EULER = 0, 1, 2
 FG_SCHEDULE_EDM, FG_SCHEDULE_RF = 0, 1
 FG_DROP_PRECOND_INPUT, FG_DROP_PRECOND_OUTPUT = 1, 2
 FG_BWD_DECODER, FG_BWD_ENCODER, FG_BWD_EMBED = 1, 2, 4
@@ -37,6 +37,15 @@ class fg_wan_config(ctypes.Structure):
     _fields_ = [("num_heads", c_int), ("head_dim", c_int), ("in_channels", c_int), ("out_channels", c_int), ("text_dim", c_int),
                 ("freq_dim", c_int), ("ffn_dim", c_int), ("num_layers", c_int), ("rope_max_seq_len", c_int), ("chunk_size", c_int),
                 ("total_num_frames", c_int), ("eps", c_float)]
+
+
+class fg_dit_sampler_config(ctypes.Structure):
+    _fields_ = [("t_scale", c_double), ("guidance_scale", c_double), ("use_sit_convention", c_int), ("time_cond_diff", c_int),
+                ("net_pred_flow", c_int), ("schedule", c_int)]
+
+
+class fg_wan_sampler_config(ctypes.Structure):
+    _fields_ = [("t_scale", c_double), ("context_noise", c_double), ("net_pred_flow", c_int), ("schedule", c_int), ("prefill_frames", c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/fastgen_amd.h declares
@@ -95,6 +104,12 @@ SIGNATURES = {
     "fg_dit_pack_weights": (c_int, [c_void_p, c_void_p]),
     "fg_dit_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "fg_dit_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "fg_dit_sampler_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "fg_dit_sampler_run": (c_int, [c_void_p, POINTER(fg_dit_sampler_config), c_void_p, c_void_p, c_void_p, POINTER(c_double), c_int, c_int, c_int,
+                                   c_void_p, c_uint64, c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
+    "fg_wan_sampler_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int, c_int]),
+    "fg_wan_sampler_run": (c_int, [c_void_p, POINTER(fg_wan_sampler_config), c_void_p, POINTER(c_double), c_int, c_int, POINTER(c_int), c_void_p,
+                                   c_uint64, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "fg_wan_create": (c_int, [POINTER(fg_wan_config), POINTER(c_void_p)]),
     "fg_wan_destroy": (None, [c_void_p]),
     "fg_wan_num_params": (c_int, [c_void_p]),

@@ -1142,6 +1142,7 @@ int fg_edm_run_block(fg_edm* h, int index, const float* x1, int c1, const float*
 #include "engine_train.inc"  // block / network backward, forward-mode pass and their entry points
 #include "engine_dit.inc"    // the DiT engine (fg_dit_*)
 #include "engine_wan.inc"    // the causal video DiT engine (fg_wan_*)
+#include "engine_sampler.inc"  // fg_dit_sampler_run / fg_wan_sampler_run: the student loops of the two transformer networks
 
 int fg_op_gn_coeffs(const float* x1, int c1, const float* x2, int c2, const float* gamma, const float* beta, float eps,
                     float* ab_out, int batch, int hw, void* stream) {

@@ -26,6 +26,13 @@ int launch_x0_to_eps(const float* xt, const float* x0, double tv, const double* 
 int launch_meanflow_update(const float* x, const float* u, const double* tp, int ia, int ib, float* out, int64_t total,
                            hipStream_t s);
 int launch_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, const uint64_t* seed_dev, hipStream_t s);
+// sampler loops of the transformer networks (misc.hip; engine_sampler.inc)
+int launch_embed_times(const double* tp, int ti, double tv, int ri, double rv, double scale, int sit, int diff, int f32in, float* te, float* re,
+                       int n, hipStream_t s);
+int launch_flow_to_x0(const float* xt, const float* v, const double* tp, int ti, float sign, float* out, int64_t total, hipStream_t s);
+int launch_euler_step(const float* x, const float* v, const double* tp, int ti, float g, int cfg, float sign, float* out, float* out2,
+                      int64_t total, hipStream_t s);
+int launch_copy_rows(const float* src, int64_t src_pitch, float* dst, int64_t dst_pitch, int64_t run, int64_t rows, hipStream_t s);
 // out[B,H,W,C] = mean over 2x2 of silu(a*x+b), x [B,2H,2W,C]
 int launch_gn_silu_pool(int dtype, const void* x, const float2* ab, void* out, int B, int H, int W, int C, hipStream_t s);
 int launch_to_act(int dtype, const float* in, void* out, int64_t total, hipStream_t s);

@@ -523,6 +523,73 @@ __global__ void convert_kernel(const A* __restrict__ in, B* __restrict__ out, in
         out[i] = (B)(float)in[i];
 }
 
+// ---- sampler loops of the transformer networks (fg_dit_sampler_run / fg_wan_sampler_run) --------------------------------------
+// The timestep as the embedder consumes it, written per sample / per frame from the device-resident t_list (graph replay with new
+// timesteps): t_e = fp32(scale * t) with the product in fp64 (`noise_scheduler.rescale_t` on the sampler's float64 timesteps, then
+// `.to(float32)`: DiT.prepare_t, DiT/network.py:457-462; CausalWan._compute_timestep_inputs, Wan/network_causal.py:1063-1075), the SiT
+// flip t_e = 1 - t_e (:503-504) and, for the second embedding, r_e likewise with the 'diff' form r_e = t_e - r_e (:520-521) in fp32.
+// ti / ri: index into tp, or -1 = the host value tv / rv (f32in: that value is an fp32 tensor in the reference - the cache-fill call's
+// `context_noise` - so the product is an fp32 one), ri == -2: no r.
+__global__ void embed_times_kernel(const double* __restrict__ tp, int ti, double tv, int ri, double rv, double scale, int sit, int diff,
+                                   int f32in, float* __restrict__ te, float* __restrict__ re, int n) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double t = ti >= 0 ? tp[ti] : tv;
+    float t_e = f32in ? (float)scale * (float)t : (float)(scale * t);
+    if (sit) t_e = 1.0f - t_e;
+    te[i] = t_e;
+    if (ri != -2 && re) {
+        const double r = ri >= 0 ? tp[ri] : rv;
+        float r_e = (float)(scale * r);
+        if (diff) r_e = t_e - r_e;
+        re[i] = r_e;
+    }
+}
+// x0 = x_t - t * flow in fp64, one rounding to fp32 (`flow_to_x0`, noise_schedule.py:975-1004, 1426-1455: the EDM and RF forms
+// coincide); sign = -1 folds the SiT convention's `model_output = -model_output` (DiT/network.py:555-558) in (a negation is exact).
+__global__ void flow_to_x0_kernel(const float* __restrict__ xt, const float* __restrict__ v, const double* __restrict__ tp, int ti, float sign,
+                                  float* __restrict__ out, int64_t total) {
+#pragma clang fp contract(off)
+    const double t = tp[ti];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (float)((double)xt[i] - (double)(sign * v[i]) * t);
+}
+// One Euler step of the flow ODE with optional classifier-free guidance (`DiT._sample_flow`, DiT/network.py:605-651), every operation an
+// fp32 one with its own rounding, as torch evaluates `v = v_uncond + g * (v_cond - v_uncond); x = x + dt * v`, dt = fp32(t_next - t):
+// v holds [v_uncond | v_cond] (two batches of `total` elements) when cfg, else the one velocity; out2 (nullable) receives a second
+// copy of the new x (the doubled batch of the guided call).
+__global__ void euler_step_kernel(const float* x, const float* __restrict__ v, const double* __restrict__ tp, int ti, float g, int cfg, float sign,
+                                  float* out, float* out2, int64_t total) {  // out may alias x
+#pragma clang fp contract(off)
+    const float dt = (float)(tp[ti + 1] - tp[ti]);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float vv;
+        if (cfg) {
+            const float vu = sign * v[i], vc = sign * v[total + i];
+            const float d = vc - vu;
+            const float gd = g * d;
+            vv = vu + gd;
+        } else {
+            vv = sign * v[i];
+        }
+        const float dx = dt * vv;
+        const float nx = x[i] + dx;
+        out[i] = nx;
+        if (out2) out2[i] = nx;
+    }
+}
+// rows of `run` contiguous elements between a tensor with row pitch src_pitch and one with dst_pitch (elements): the frame slice
+// x[:, :, f0:f1] of a [B, C, F, H, W] video <-> a contiguous chunk [B, C, f1 - f0, H, W] (rows = B * C, run = (f1 - f0) * H * W)
+__global__ void copy_rows_kernel(const float* __restrict__ src, int64_t src_pitch, float* __restrict__ dst, int64_t dst_pitch, int64_t run,
+                                 int64_t rows) {
+    const int64_t total = rows * run;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / run, c = i - r * run;
+        dst[r * dst_pitch + c] = src[r * src_pitch + c];
+    }
+}
+
 inline int ew_grid(int64_t total) {
     int64_t g = (total + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -645,6 +712,24 @@ int launch_x0_to_eps(const float* xt, const float* x0, double tv, const double* 
 int launch_meanflow_update(const float* x, const float* u, const double* tp, int ia, int ib, float* out, int64_t total,
                            hipStream_t s) {
     hipLaunchKernelGGL(meanflow_update_kernel, dim3(ew_grid(total)), dim3(256), 0, s, x, u, tp, ia, ib, out, total);
+    RET_LAST();
+}
+int launch_embed_times(const double* tp, int ti, double tv, int ri, double rv, double scale, int sit, int diff, int f32in, float* te, float* re,
+                       int n, hipStream_t s) {
+    hipLaunchKernelGGL(embed_times_kernel, dim3((n + 255) / 256), dim3(256), 0, s, tp, ti, tv, ri, rv, scale, sit, diff, f32in, te, re, n);
+    RET_LAST();
+}
+int launch_flow_to_x0(const float* xt, const float* v, const double* tp, int ti, float sign, float* out, int64_t total, hipStream_t s) {
+    hipLaunchKernelGGL(flow_to_x0_kernel, dim3(ew_grid(total)), dim3(256), 0, s, xt, v, tp, ti, sign, out, total);
+    RET_LAST();
+}
+int launch_euler_step(const float* x, const float* v, const double* tp, int ti, float g, int cfg, float sign, float* out, float* out2,
+                      int64_t total, hipStream_t s) {
+    hipLaunchKernelGGL(euler_step_kernel, dim3(ew_grid(total)), dim3(256), 0, s, x, v, tp, ti, g, cfg, sign, out, out2, total);
+    RET_LAST();
+}
+int launch_copy_rows(const float* src, int64_t src_pitch, float* dst, int64_t dst_pitch, int64_t run, int64_t rows, hipStream_t s) {
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(ew_grid(rows * run)), dim3(256), 0, s, src, src_pitch, dst, dst_pitch, run, rows);
     RET_LAST();
 }
 int launch_randn(float* out, int64_t total, uint64_t seed, uint64_t offset, const uint64_t* seed_dev, hipStream_t s) {

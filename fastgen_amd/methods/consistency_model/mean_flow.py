@@ -12,7 +12,7 @@ from typing import Any
 
 import torch
 
-from fastgen_amd.methods.model import FastGenModel
+from fastgen_amd.methods.model import _FUSED_LOOPS, FastGenModel
 from fastgen_amd.networks.noise_schedule import expand_like
 
 
@@ -52,3 +52,5 @@ class MeanFlowModel(FastGenModel):
                            v_r=torch.zeros_like(r, dtype=torch.float32), fwd_pred_type="flow" if net.net_pred_type == "flow" else None)
         return u_jvp
 
+
+_FUSED_LOOPS.add(MeanFlowModel._student_sample_loop.__func__)

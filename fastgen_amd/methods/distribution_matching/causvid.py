@@ -1,6 +1,7 @@
 """`CausVidModel` sampling classmethods with the reference's signatures (fastgen/methods/distribution_matching/causvid.py:87-185):
 the chunk-by-chunk student loop of the causal video DiT - per chunk N x {x0 prediction over the cached frames + this chunk;
-re-noise to the next timestep}, then one network call on the finished chunk that fills the KV cache."""
+re-noise to the next timestep}, then one network call on the finished chunk that fills the KV cache.  The loop itself lives in the
+library (`fg_wan_sampler_run`, csrc/engine_sampler.inc); these are thin callers."""
 from __future__ import annotations
 
 from typing import Any, Optional
@@ -14,41 +15,9 @@ class CausVidModel(FastGenModel):
     @classmethod
     def _student_sample_loop(cls, net, x: torch.Tensor, t_list: torch.Tensor, condition: Any = None, student_sample_type: str = "sde",
                              context_noise: Optional[float] = 0, **kwargs) -> torch.Tensor:
-        net.clear_caches()
-        batch_size, num_frames = x.shape[0], x.shape[2]
-        chunk_size = net.chunk_size
-        num_chunks, remaining = num_frames // chunk_size, num_frames % chunk_size
-        sched = net.noise_scheduler
-        for i in range(max(1, num_chunks)):
-            if num_chunks == 0:
-                start, end = 0, remaining
-            else:
-                start = 0 if i == 0 else chunk_size * i + remaining
-                end = chunk_size * (i + 1) + remaining
-            x_next = x[:, :, start:end, ...]
-            for step in range(len(t_list) - 1):
-                t_cur = t_list[step].expand(batch_size)
-                x_cur = x_next
-                x_next = net(x_cur, t_cur, condition=condition, fwd_pred_type="x0", cache_tag="pos", cur_start_frame=start, store_kv=False,
-                             is_ar=True, **kwargs)
-                t_next = t_list[step + 1]
-                if t_next > 0:
-                    if student_sample_type == "sde":
-                        eps = torch.randn_like(x_next)
-                    elif student_sample_type == "ode":
-                        eps = sched.x0_to_eps(xt=x_cur, x0=x_next, t=t_cur)
-                    else:
-                        raise NotImplementedError(f"student_sample_type must be one of 'sde', 'ode' but got {student_sample_type}")
-                    x_next = sched.forward_process(x_next, eps, t_next.expand(batch_size))
-            x[:, :, start:end, ...] = x_next
-            x_cache, t_cache = x_next, t_list[-1].expand(batch_size)
-            if context_noise > 0:
-                t_cache = torch.full((batch_size,), context_noise, device=x.device, dtype=x.dtype)
-                x_cache = sched.forward_process(x_next, torch.randn_like(x_next), t_cache)
-            net(x_cache, t_cache, condition=condition, fwd_pred_type="x0", cache_tag="pos", cur_start_frame=start, store_kv=True, is_ar=True,
-                **kwargs)
-        net.clear_caches()
-        return x
+        """The reference's signature (causvid.py:87-98) over `CausalWan.student_sample`: the whole loop - chunking, the N denoising calls
+        and the cache-fill call per chunk, re-noising, RNG - runs inside the library (`fg_wan_sampler_run`, one hipGraph per chunk)."""
+        return net.student_sample(x, t_list, condition, sample_type=student_sample_type, context_noise=context_noise or 0.0, **kwargs)
 
     @classmethod
     def generator_fn_extrapolation(cls, net, noise: torch.Tensor, condition: Any = None, *, num_segments: int, overlap_frames: int,
@@ -78,42 +47,16 @@ class CausVidModel(FastGenModel):
                     f"t_list length (excluding zero) != student_sample_steps: {len(t_list) - 1} != {student_sample_steps}")
                 t_list = torch.tensor(t_list, device=device, dtype=torch.float32)
             assert t_list[-1].item() == 0, "t_list[-1] must be zero"
-            call = dict(condition=condition, fwd_pred_type="x0", cache_tag="pos", is_ar=True, **kwargs)
 
             def run_segment(segment_latents: torch.Tensor, prefill_frames: int) -> torch.Tensor:
+                # the bridged head [0, prefill_frames) fills the caches at t = 0 as it is; the rest starts from latents at t_list[0]
                 x = segment_latents.clone()
-                net.clear_caches()
-                for start in range(0, prefill_frames, chunk_size):  # the bridged head: cache fill at t = 0
-                    net(x[:, :, start:min(start + chunk_size, prefill_frames)], t_list[-1].expand(batch_size), cur_start_frame=start, store_kv=True,
-                        **call)
                 if prefill_frames == 0:
                     x = sched.latents(x, t_init=t_list[0])
                 else:
                     x[:, :, prefill_frames:] = sched.latents(x[:, :, prefill_frames:], t_init=t_list[0])
-                for start in range(prefill_frames, segment_frames, chunk_size):
-                    end = min(start + chunk_size, segment_frames)
-                    x_next = x[:, :, start:end]
-                    for step in range(len(t_list) - 1):
-                        t_cur = t_list[step].expand(batch_size)
-                        x_cur = x_next
-                        x_next = net(x_cur, t_cur, cur_start_frame=start, store_kv=False, **call)
-                        t_next = t_list[step + 1]
-                        if t_next > 0:
-                            if student_sample_type == "sde":
-                                eps = torch.randn_like(x_next)
-                            elif student_sample_type == "ode":
-                                eps = sched.x0_to_eps(xt=x_cur, x0=x_next, t=t_cur)
-                            else:
-                                raise NotImplementedError(f"student_sample_type must be one of 'sde', 'ode' but got {student_sample_type}")
-                            x_next = sched.forward_process(x_next, eps, t_next.expand(batch_size))
-                    x[:, :, start:end] = x_next
-                    x_cache, t_cache = x_next, t_list[-1].expand(batch_size)
-                    if context_noise and context_noise > 0:
-                        t_cache = torch.full((batch_size,), context_noise, device=device, dtype=dtype)
-                        x_cache = sched.forward_process(x_next, torch.randn_like(x_next), t_cache)
-                    net(x_cache, t_cache, cur_start_frame=start, store_kv=True, **call)
-                net.clear_caches()
-                return x
+                return net.student_sample(x, t_list, condition, sample_type=student_sample_type, context_noise=context_noise or 0.0,
+                                          prefill_frames=prefill_frames, **kwargs)
 
             segments, current, prefill = [], noise, 0
             for i in range(num_segments):

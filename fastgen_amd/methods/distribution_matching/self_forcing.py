@@ -42,9 +42,10 @@ class SelfForcingModel(CausVidModel):
 
     def rollout_with_gradient(self, noise: torch.Tensor, condition: Optional[Any] = None, enable_gradient: bool = True,
                               start_gradient_frame: int = 0) -> torch.Tensor:
+        """Block by block: denoise from t_list[0] down to the block's sampled exit step, keep that step's x0 prediction as the block's
+        output, then the cache-fill call on it (self_forcing.py:92-241) - one `fg_wan_sampler_run` call with the exit steps."""
         net, cfg = self.net, self.config
-        net.clear_caches()
-        batch_size, _, num_frames = noise.shape[:3]
+        num_frames = noise.shape[2]
         chunk_size = net.chunk_size
         num_blocks, remaining = num_frames // chunk_size, num_frames % chunk_size
         steps = cfg.student_sample_steps
@@ -52,47 +53,23 @@ class SelfForcingModel(CausVidModel):
         end_steps = self._sample_denoising_end_steps(num_blocks)
         t_list = cfg.sample_t_cfg.t_list
         if t_list is None:
-            t_list = sched.get_t_list(steps, device=noise.device)
+            t_list = sched.get_t_list(steps, device="cpu")
         else:
             assert len(t_list) - 1 == steps, f"t_list length (excluding zero) != student_sample_steps: {len(t_list) - 1} != {steps}"
-            t_list = torch.tensor(t_list, device=noise.device, dtype=sched.t_precision)
-        call = dict(condition=condition, cache_tag="pos", fwd_pred_type="x0", is_ar=True)
-
-        blocks = []
-        for b in range(num_blocks):
-            start = 0 if b == 0 else chunk_size * b + remaining
-            end = chunk_size * (b + 1) + remaining
-            x = noise[:, :, start:end]
-            exit_step = end_steps[0] if cfg.same_step_across_blocks else end_steps[b]
-            for step, t_cur in enumerate(t_list):
-                t = t_cur.expand(batch_size)
-                if step != exit_step:
-                    with torch.no_grad():
-                        x0 = net(x, t, store_kv=False, cur_start_frame=start, **call)
-                    t_next = t_list[step + 1].expand(batch_size)
-                    if cfg.student_sample_type == "sde":
-                        eps = torch.randn_like(x0)
-                    elif cfg.student_sample_type == "ode":
-                        eps = sched.x0_to_eps(xt=x, x0=x0, t=t)
-                    else:
-                        raise NotImplementedError(f"student_sample_type must be one of 'sde', 'ode' but got {cfg.student_sample_type}")
-                    x = sched.forward_process(x0, eps, t_next)
-                else:
-                    grad = enable_gradient and torch.is_grad_enabled() and start >= start_gradient_frame
-                    with torch.set_grad_enabled(grad):
-                        x0 = net(x, t, store_kv=False, cur_start_frame=start, **call)
-                    break
-            blocks.append(x0)
-            with torch.no_grad():
-                if cfg.context_noise > 0:
-                    t_cache = torch.full((batch_size,), cfg.context_noise, device=noise.device, dtype=noise.dtype)
-                    x_cache = sched.forward_process(x0, torch.randn_like(x0), t_cache)
-                else:
-                    x_cache, t_cache = x0, torch.zeros(batch_size, device=noise.device, dtype=noise.dtype)
-                net(x_cache, t_cache, store_kv=True, cur_start_frame=start, **call)
-        out = torch.cat(blocks, dim=2) if blocks else torch.empty_like(noise)
-        net.clear_caches()
-        return out
+            t_list = torch.tensor(t_list, dtype=sched.t_precision)
+        if num_blocks == 0:
+            net.clear_caches()
+            return torch.empty_like(noise)
+        # the exit step of a block from start_gradient_frame on runs with autograd in the reference; this network has no backward
+        starts = [0 if b == 0 else chunk_size * b + remaining for b in range(num_blocks)]
+        if (enable_gradient and torch.is_grad_enabled() and any(s >= start_gradient_frame for s in starts)
+                and any(p.requires_grad for p in net.parameters())):
+            raise NotImplementedError("fastgen_amd.CausalWan: the backward pass is not implemented (the exit step of the rollout would run "
+                                      "with gradients); call under torch.no_grad() or with enable_gradient=False")
+        exits = [end_steps[0] if cfg.same_step_across_blocks else end_steps[b] for b in range(num_blocks)]
+        with torch.no_grad():
+            return net.student_sample(noise.clone(), t_list, condition, sample_type=cfg.student_sample_type,
+                                      context_noise=cfg.context_noise or 0.0, exit_steps=exits)
 
     def gen_data_from_net(self, input_student: torch.Tensor, t_student: torch.Tensor, condition: Optional[Any] = None) -> torch.Tensor:
         del t_student

@@ -1,8 +1,8 @@
 """Student sampling entry points with the reference's signatures: `FastGenModel.generator_fn` and
 `FastGenModel._student_sample_loop` (fastgen/methods/model.py:315-420).
 
-For a `fastgen_amd` EDM network the whole loop is one library call (`fg_sampler_run`: latents -> N x {U-Net forward,
-re-noise} as a replayed hipGraph, host syncs of the reference loop hoisted to host scalars).  Any other
+For a `fastgen_amd` EDM or DiT network the whole loop is one library call (`fg_sampler_run` / `fg_dit_sampler_run`: latents ->
+N x {network forward, re-noise} as a replayed hipGraph, host syncs of the reference loop hoisted to host scalars).  Any other
 `FastGenNetwork`-shaped module takes the generic per-step loop, which is what the reference itself runs.
 """
 from __future__ import annotations
@@ -29,6 +29,9 @@ def inference_mode(*modules, precision_amp: Optional[torch.dtype] = None, device
     finally:
         for m, was in zip(mods, prev):
             m.train(was)
+
+
+_FUSED_LOOPS = set()  # the `_student_sample_loop` implementations the library's loops restate (a subclass that overrides it opts out)
 
 
 class FastGenModel:
@@ -78,8 +81,8 @@ class FastGenModel:
                     f"t_list length (excluding zero) != student_sample_steps: {len(t_list) - 1} != {student_sample_steps}")
                 t_list = torch.tensor(t_list, dtype=net.noise_scheduler.t_precision)
             assert t_list[-1].item() == 0, "t_list[-1] must be zero"
-            fused = (isinstance(net, EDMPrecond) and net.fused_loop() == cls._fused_loop and data is None
-                     and not hasattr(net, "preserve_conditioning"))
+            fused = (getattr(net, "supports_fused_loop", lambda k: False)(cls._fused_loop) and data is None
+                     and not hasattr(net, "preserve_conditioning") and cls._student_sample_loop.__func__ in _FUSED_LOOPS)
             if fused:
                 kw = dict(kwargs)
                 out = net.few_step_sample(noise, kw.pop("condition", None), t_list,
@@ -96,3 +99,6 @@ class FastGenModel:
             for k in ("eps", "seed", "use_graph"):
                 kwargs.pop(k, None)
             return cls._student_sample_loop(net, latents, t_list=t_dev, **kwargs).to(dtype=noise.dtype)
+
+
+_FUSED_LOOPS.add(FastGenModel._student_sample_loop.__func__)

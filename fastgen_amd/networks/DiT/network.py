@@ -7,7 +7,8 @@ state-dict keys and shapes (`tests/golden/dit_*_state_dict_keys.txt`, recorded f
 embedding / attention / MLP layers are those of the `timm` classes the reference imports).  Select it with
 `_target_: fastgen_amd.networks.DiT.network.DiT` in a config built on `DiT_IN256_*_Config` (fastgen/configs/net.py:98-127).
 
-This round: inference / sampling (RF Euler `sample()`, the MeanFlow and x0 student loops through their generic per-step form).
+Inference / sampling: `forward`, and the three sampling loops as single library calls replayed as hipGraphs (`few_step_sample`:
+`FastGenModel` / `MeanFlowModel._student_sample_loop`; `sample()`: the RF Euler sampler with classifier-free guidance) - `fg_dit_sampler_run`.
 Raises (never falls back): autograd through the network, `feature_indices`, token counts other than 256, and any device but a HIP GPU.
 """
 from __future__ import annotations
@@ -156,6 +157,24 @@ class DiT(FastGenNetwork):
             self._refs[dt], self._bound_sig[dt] = refs, sig
         return dt, h
 
+    def _class_ids(self, condition: Optional[torch.Tensor], B: int, dev) -> torch.Tensor:
+        """one-hot -> class index, an all-zero row -> the extra "unconditional" row (:493-498); training-time label dropout (:120-149)."""
+        if condition is None:
+            raise ValueError("DiT needs a class condition (one-hot [B, num_classes] or class indices [B])")
+        if condition.ndim == 2:
+            mask = torch.any(condition != 0, dim=1)
+            if self._cfg.embedding_rows == self.num_classes and not bool(mask.all()):
+                # (the table has the extra row only for class_dropout_prob > 0, :116-118; the reference's nn.Embedding device-asserts here)
+                raise ValueError("an all-zero (unconditional) condition row needs the extra row of y_embedder.class_embeddings, "
+                                 "which exists only for class_dropout_prob > 0")
+            condition = torch.where(~mask, self.num_classes, condition.argmax(dim=1))
+        cls = condition.to(device=dev, dtype=torch.int64)
+        if self.training and self.class_dropout_prob > 0:
+            cls = torch.where(torch.rand(B, device=dev) < self.class_dropout_prob, self.num_classes, cls)
+        if int(cls.numel()) == 1 and B > 1:
+            cls = cls.expand(B)
+        return cls.contiguous()
+
     def prepare_t(self, t: Optional[torch.Tensor], dtype) -> Optional[torch.Tensor]:
         if t is None:
             return None
@@ -182,22 +201,7 @@ class DiT(FastGenNetwork):
         B, dev = x_t.shape[0], x_t.device
         if tuple(x_t.shape[1:]) != (self.in_channels, self.input_size, self.input_size):
             raise ValueError(f"x_t must be [B,{self.in_channels},{self.input_size},{self.input_size}], got {tuple(x_t.shape)}")
-        if condition is None:
-            raise ValueError("DiT.forward needs a class condition (one-hot [B, num_classes] or class indices [B])")
-        # one-hot -> class index, an all-zero row -> the extra "unconditional" row (:493-498); training-time label dropout (:120-149)
-        if condition.ndim == 2:
-            mask = torch.any(condition != 0, dim=1)
-            if self._cfg.embedding_rows == self.num_classes and not bool(mask.all()):
-                # (the table has the extra row only for class_dropout_prob > 0, :116-118; the reference's nn.Embedding device-asserts here)
-                raise ValueError("an all-zero (unconditional) condition row needs the extra row of y_embedder.class_embeddings, "
-                                 "which exists only for class_dropout_prob > 0")
-            condition = torch.where(~mask, self.num_classes, condition.argmax(dim=1))
-        cls = condition.to(device=dev, dtype=torch.int64)
-        if self.training and self.class_dropout_prob > 0:
-            cls = torch.where(torch.rand(B, device=dev) < self.class_dropout_prob, self.num_classes, cls)
-        if int(cls.numel()) == 1 and B > 1:
-            cls = cls.expand(B)
-        cls = cls.contiguous()
+        cls = self._class_ids(condition, B, dev)
         x32 = x_t.detach().to(torch.float32).contiguous()
         t_in = torch.atleast_1d(t.detach()).to(dev)
         if t_in.numel() == 1 and B > 1:
@@ -246,22 +250,80 @@ class DiT(FastGenNetwork):
         lv = self._modules["logvar_linear"]
         return t_emb @ lv.weight.t() + lv.bias
 
+    # ---- the sampling loops as one library call ----------------------------------------------------------------------------
+    def supports_fused_loop(self, kind: str) -> bool:
+        """Which loops `fg_dit_sampler_run` restates for this network: 'x0' (FastGenModel._student_sample_loop, flow- or
+        x0-predicting network), 'meanflow' (MeanFlowModel._student_sample_loop: flow-predicting r_timestep network), 'euler' (`sample()`)."""
+        if self.net_pred_type not in ("flow", "x0") or self.schedule_type not in ("rf", "rectified_flow", "edm"):
+            return False
+        if kind == "x0":
+            return True
+        if kind == "meanflow":
+            return self.r_timestep and self.net_pred_type == "flow" and not self.use_sit_convention
+        return kind == "euler" and self.net_pred_type == "flow"
+
+    def few_step_sample(self, noise: torch.Tensor, condition: Optional[torch.Tensor], t_list, sample_type: str = "sde",
+                        eps: Optional[torch.Tensor] = None, seed: Optional[int] = None, use_graph: bool = True, loop: str = "x0",
+                        neg_condition: Optional[torch.Tensor] = None, guidance_scale: float = 1.0) -> torch.Tensor:
+        """The whole sampling loop as ONE `fg_dit_sampler_run` call / one hipGraph replay: latents = noise * sigma(t_list[0]), then per
+        step the network call and the schedule arithmetic of `loop` ('x0' | 'meanflow' | 'euler').  t_list: steps + 1 decreasing
+        timesteps ending in 0; 'sde' re-noises with `eps` ([steps - 1, B, C, H, W], injected) or device normals drawn from `seed`."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("the fused sampler builds no autograd graph; call it under torch.no_grad() / torch.inference_mode()")
+        if not self.supports_fused_loop(loop):
+            raise NotImplementedError(f"the fused sampler has no loop {loop!r} for net_pred_type={self.net_pred_type!r}, "
+                                      f"r_timestep={self.r_timestep}, schedule_type={self.schedule_type!r}")
+        if noise.device.type != "cuda":
+            raise RuntimeError("fastgen_amd runs on a HIP GPU only (no CPU path); got a tensor on " + str(noise.device))
+        if sample_type not in ("sde", "ode"):
+            raise NotImplementedError(f"student_sample_type must be one of 'sde', 'ode' but got {sample_type}")
+        B, dev = noise.shape[0], noise.device
+        if tuple(noise.shape[1:]) != (self.in_channels, self.input_size, self.input_size):
+            raise ValueError(f"noise must be [B,{self.in_channels},{self.input_size},{self.input_size}], got {tuple(noise.shape)}")
+        tl = [float(v) for v in (t_list.tolist() if isinstance(t_list, torch.Tensor) else t_list)]
+        steps = len(tl) - 1
+        assert tl[-1] == 0, "t_list[-1] must be zero"
+        n32 = noise if (noise.dtype == torch.float32 and noise.is_contiguous()) else noise.to(torch.float32).contiguous()
+        cls = self._class_ids(condition, B, dev)
+        neg = self._class_ids(neg_condition, B, dev) if (loop == "euler" and neg_condition is not None) else None
+        if eps is not None:
+            eps = eps.to(device=dev, dtype=torch.float32).contiguous()
+            if eps.numel() != max(steps - 1, 0) * n32.numel():
+                raise ValueError(f"eps must hold steps-1 = {steps - 1} noise tensors shaped like `noise`")
+        if seed is None:
+            seed = int(torch.randint(0, 2**62, (1,)).item())  # host RNG: follows torch.manual_seed / set_random_seed
+        sc = _lib.fg_dit_sampler_config()
+        rf = self.schedule_type != "edm"
+        sc.t_scale = float(self.noise_scheduler.num_steps) if (self.scale_t and rf) else 1.0  # rescale_t (noise_schedule.py:140-148)
+        sc.guidance_scale = float(guidance_scale)
+        sc.use_sit_convention, sc.time_cond_diff = int(self.use_sit_convention), int(self.time_cond_type == "diff")
+        sc.net_pred_flow = int(self.net_pred_type == "flow")
+        sc.schedule = _lib.FG_SCHEDULE_RF if rf else _lib.FG_SCHEDULE_EDM
+        dt, h = self._engine(dev)
+        L = _lib.lib()
+        need = L.fg_dit_sampler_workspace_bytes(h, B, int(neg is not None))
+        ws = self._ws.get(dt)
+        if ws is None or ws.numel() < need or ws.device != dev:
+            ws = self._ws[dt] = torch.empty(need, dtype=torch.uint8, device=dev)
+        out = torch.empty_like(n32)
+        self._keep = (n32, cls, neg, eps, out)  # graph replays read these buffers; keep them alive
+        p = lambda a: ctypes.c_void_p(a.data_ptr() if a is not None and a.numel() else None)  # noqa: E731
+        _lib.check(L.fg_dit_sampler_run(
+            h, ctypes.byref(sc), p(n32), p(cls), p(neg), (ctypes.c_double * (steps + 1))(*tl), steps,
+            _lib.FG_SAMPLE_SDE if sample_type == "sde" else _lib.FG_SAMPLE_ODE,
+            {"x0": _lib.FG_LOOP_X0, "meanflow": _lib.FG_LOOP_MEANFLOW, "euler": _lib.FG_LOOP_EULER}[loop], p(eps), ctypes.c_uint64(seed), p(out), B,
+            ctypes.c_void_p(ws.data_ptr()), ws.numel(), 1 if use_graph else 0, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return out.to(noise.dtype)
+
     @torch.no_grad()
     def sample(self, noise: torch.Tensor, condition: Optional[torch.Tensor] = None, neg_condition: Optional[torch.Tensor] = None,
-               guidance_scale: Optional[float] = 5.0, num_steps: int = 50, **kwargs) -> torch.Tensor:
-        """Euler sampler of the flow ODE with optional classifier-free guidance (`_sample_flow`, :605-651)."""
+               guidance_scale: Optional[float] = 5.0, num_steps: int = 50, use_graph: bool = True, **kwargs) -> torch.Tensor:
+        """Euler sampler of the flow ODE with optional classifier-free guidance (`_sample_flow`, :605-651): one `fg_dit_sampler_run`
+        call (FG_LOOP_EULER).  x += fp32(t_next - t) * v per step; guided: v = v_uncond + g (v_cond - v_uncond) from one forward of the
+        doubled batch."""
         if self.schedule_type != "rf":
             raise NotImplementedError(f"sample() is implemented for schedule_type='rf', got {self.schedule_type!r}")
-        t_list = self.noise_scheduler.get_t_list(num_steps, device=noise.device)
-        x = self.noise_scheduler.latents(noise=noise, t_init=t_list[0])
-        for t, t_next in zip(t_list[:-1], t_list[1:]):
-            tb = t.expand(x.shape[0])
-            dt = (t_next - t).to(x.dtype)
-            if guidance_scale is not None and guidance_scale > 1.0 and neg_condition is not None:
-                v = self(torch.cat([x, x], 0), torch.cat([tb, tb], 0), condition=torch.cat([neg_condition, condition], 0), fwd_pred_type="flow")
-                v_uncond, v_cond = v.chunk(2)
-                v = v_uncond + guidance_scale * (v_cond - v_uncond)
-            else:
-                v = self(x, tb, condition=condition, fwd_pred_type="flow")
-            x = x + dt * v
-        return x
+        t_list = self.noise_scheduler.get_t_list(num_steps, device="cpu")
+        guided = guidance_scale is not None and guidance_scale > 1.0 and neg_condition is not None
+        return self.few_step_sample(noise, condition, t_list, sample_type="ode", loop="euler", use_graph=use_graph,
+                                    neg_condition=neg_condition if guided else None, guidance_scale=guidance_scale if guided else 1.0)

@@ -812,6 +812,9 @@ class EDMPrecond(FastGenNetwork):
             return "meanflow"
         return None
 
+    def supports_fused_loop(self, kind: str) -> bool:
+        return kind is not None and self.fused_loop() == kind
+
     def few_step_sample(self, noise: torch.Tensor, condition: Optional[torch.Tensor], t_list, sample_type: str = "sde",
                         eps: Optional[torch.Tensor] = None, seed: Optional[int] = None, use_graph: bool = True,
                         out: Optional[torch.Tensor] = None, loop: Optional[str] = None) -> torch.Tensor:

@@ -8,8 +8,9 @@ weights and config, unavailable offline); here the fields of that config are con
 the parameters carry the same state-dict keys (`transformer.` + diffusers' names), so a converted checkpoint loads with
 `load_state_dict`.  PARITY UNPINNED (the arithmetic lives in un-vendored diffusers: oracle/wan_ref.py restates it).
 
-This round: autoregressive inference (`is_ar=True`, one cache tag) and the teacher- / diffusion-forcing forward over all
-total_num_frames frames (`is_ar=False`: block-wise causal mask, per-frame timesteps [B, F]).  Raises (never falls back): autograd,
+Autoregressive inference (`is_ar=True`, one cache tag), the teacher- / diffusion-forcing forward over all total_num_frames frames
+(`is_ar=False`: block-wise causal mask, per-frame timesteps [B, F]), and the whole chunk-by-chunk student loop as one library call
+replayed as per-chunk hipGraphs (`student_sample` -> `fg_wan_sampler_run`; CausVidModel / SelfForcingModel call it).  Raises (never falls back): autograd,
 feature taps, r / image conditioning, `is_ar=False` on fewer frames, any device but a HIP GPU.
 """
 from __future__ import annotations
@@ -120,6 +121,20 @@ class CausalWan(FastGenNetwork):
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
         return self._ws
 
+    def _set_text(self, condition: torch.Tensor, B: int, dev, ws: torch.Tensor) -> None:
+        """The text condition: embedded (and its cross-attention k / v cached) once per tensor, as the reference's static cache
+        (the same tensor OBJECT at the same in-place version; a new object with recycled storage is embedded again)."""
+        ver = 0 if condition.is_inference() else condition._version
+        same = self._text_key is not None and self._text_key[0]() is condition and self._text_key[1:] == (ver, tuple(condition.shape))
+        if same:
+            return
+        c32 = condition.detach().to(device=dev, dtype=torch.float32).contiguous()
+        if c32.shape[0] != B:
+            raise ValueError(f"condition batch {c32.shape[0]} != {B}")
+        _lib.check(_lib.lib().fg_wan_set_text(self._h, ctypes.c_void_p(c32.data_ptr()), B, c32.shape[1], ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                              self._stream(dev)))
+        self._text_key = (weakref.ref(condition), ver, tuple(condition.shape))
+
     def clear_caches(self) -> None:
         """`CausalWan.clear_caches` (network_causal.py:1030-1054)."""
         if torch.cuda.is_available():
@@ -159,17 +174,7 @@ class CausalWan(FastGenNetwork):
         self._bind(dev)
         ws = self._workspace(dev, B, F, H, W)
         L = _lib.lib()
-        # the text condition: embedded (and its cross-attention k / v cached) once per tensor, as the reference's static cache
-        # (the same tensor OBJECT at the same in-place version; a new object with recycled storage is embedded again)
-        ver = 0 if condition.is_inference() else condition._version
-        same = self._text_key is not None and self._text_key[0]() is condition and self._text_key[1:] == (ver, tuple(condition.shape))
-        if not same:
-            c32 = condition.detach().to(device=dev, dtype=torch.float32).contiguous()
-            if c32.shape[0] != B:
-                raise ValueError(f"condition batch {c32.shape[0]} != {B}")
-            _lib.check(L.fg_wan_set_text(self._h, ctypes.c_void_p(c32.data_ptr()), B, c32.shape[1], ctypes.c_void_p(ws.data_ptr()), ws.numel(),
-                                         self._stream(dev)))
-            self._text_key = (weakref.ref(condition), ver, tuple(condition.shape))
+        self._set_text(condition, B, dev, ws)
         # per-frame timesteps in the embedder's units (`_compute_timestep_inputs`, :1063-1075: rescale_t, [B] -> [B, F])
         t_in = torch.atleast_1d(t.detach()).to(dev)
         ts = self.noise_scheduler.rescale_t(t_in)
@@ -187,3 +192,73 @@ class CausalWan(FastGenNetwork):
         out = out.to(x_t.dtype)
         t_conv = t_in[:, None, :, None, None] if t_in.ndim == 2 else t_in
         return self.noise_scheduler.convert_model_output(x_t, out, t_conv, src_pred_type=self.net_pred_type, target_pred_type=fwd_pred_type)
+
+    # ---- the chunk-by-chunk student loop as one library call ------------------------------------------------------------------
+    @torch.no_grad()
+    def student_sample(self, x: torch.Tensor, t_list, condition: Any, sample_type: str = "sde", context_noise: float = 0.0,
+                       eps: Optional[torch.Tensor] = None, seed: Optional[int] = None, use_graph: bool = True, prefill_frames: int = 0,
+                       exit_steps=None) -> torch.Tensor:
+        """`CausVidModel._student_sample_loop` (fastgen/methods/distribution_matching/causvid.py:87-185) over `fg_wan_sampler_run`: x
+        [B, C, F, H, W] latents (already scaled to t_list[0]) are overwritten chunk by chunk with the generated frames - per chunk N x {x0
+        prediction over the cached frames + this chunk; re-noise to the next timestep}, then the cache-fill call.  prefill_frames: frames at
+        the head that only fill the caches (`generator_fn_extrapolation`'s bridged segment head); exit_steps: one exit index per chunk
+        (`SelfForcingModel.rollout_with_gradient`).  eps: noise videos to inject instead of device draws, [steps - 1 (+ 1 if context_noise
+        > 0), B, C, F, H, W].  The caches are empty afterwards, as after the reference's loop."""
+        if x.device.type != "cuda":
+            raise RuntimeError("fastgen_amd runs on a HIP GPU only (no CPU path); got a tensor on " + str(x.device))
+        if sample_type not in ("sde", "ode"):
+            raise NotImplementedError(f"student_sample_type must be one of 'sde', 'ode' but got {sample_type}")
+        if self.net_pred_type not in ("flow", "x0"):
+            raise NotImplementedError(f"net_pred_type {self.net_pred_type!r} has no fused loop")
+        if condition is None:
+            raise ValueError("CausalWan needs the text condition [B, L, text_dim]")
+        condition = torch.stack(condition, dim=0) if isinstance(condition, list) else condition
+        B, C, F, H, W = x.shape
+        dev = x.device
+        if C != self.in_channels:
+            raise ValueError(f"x must have {self.in_channels} channels, got {C}")
+        tl = [float(v) for v in (t_list.tolist() if isinstance(t_list, torch.Tensor) else t_list)]
+        steps = len(tl) - 1
+        assert tl[-1] == 0, "t_list[-1] must be zero"
+        self._bind(dev)
+        L = _lib.lib()
+        need = L.fg_wan_sampler_workspace_bytes(self._h, B, F, H, W)
+        if need == 0:
+            raise ValueError(f"bad video shape: batch {B}, frames {F}, {H}x{W} (height and width must be even)")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        ws = self._ws
+        self._set_text(condition, B, dev, ws)
+        x32 = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.to(torch.float32).contiguous()
+        n_eps = max(steps - 1, 0) + (1 if context_noise and context_noise > 0 else 0)
+        if eps is not None:
+            eps = eps.to(device=dev, dtype=torch.float32).contiguous()
+            if eps.numel() != n_eps * x32.numel():
+                raise ValueError(f"eps must hold {n_eps} noise videos shaped like x")
+        if seed is None:
+            seed = int(torch.randint(0, 2**62, (1,)).item())
+        sc = _lib.fg_wan_sampler_config()
+        rf = self.schedule_type != "edm"
+        sc.t_scale = float(self.noise_scheduler.num_steps) if rf else 1.0
+        sc.context_noise = float(context_noise or 0.0)
+        sc.net_pred_flow = int(self.net_pred_type == "flow")
+        sc.schedule = _lib.FG_SCHEDULE_RF if rf else _lib.FG_SCHEDULE_EDM
+        sc.prefill_frames = int(prefill_frames)
+        ex = None
+        if exit_steps is not None:
+            ex = (ctypes.c_int * len(exit_steps))(*[int(e) for e in exit_steps])
+            n_chunks = max(1, F // self.chunk_size)
+            if len(exit_steps) < n_chunks:
+                raise ValueError(f"exit_steps must hold one index per chunk ({n_chunks})")
+        self._keep = (x32, eps)
+        try:
+            _lib.check(L.fg_wan_sampler_run(
+                self._h, ctypes.byref(sc), ctypes.c_void_p(x32.data_ptr()), (ctypes.c_double * (steps + 1))(*tl), steps,
+                _lib.FG_SAMPLE_SDE if sample_type == "sde" else _lib.FG_SAMPLE_ODE, ex,
+                ctypes.c_void_p(eps.data_ptr() if eps is not None and eps.numel() else None), ctypes.c_uint64(seed), B, F, H, W,
+                ctypes.c_void_p(ws.data_ptr()), ws.numel(), 1 if use_graph else 0, self._stream(dev)))
+        finally:
+            self._text_key = None  # the loop ends with clear_caches(): the text is forgotten with them
+        if x32 is not x:
+            x.copy_(x32)
+        return x

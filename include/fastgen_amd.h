@@ -51,6 +51,8 @@ extern "C" {
 
 #define FG_LOOP_X0 0        /* FastGenModel._student_sample_loop: x0 prediction + re-noise (methods/model.py:315-372) */
 #define FG_LOOP_MEANFLOW 1  /* MeanFlowModel._student_sample_loop: x -= dt * u(x,t,r) (consistency_model/mean_flow.py:336-381) */
+#define FG_LOOP_EULER 2     /* DiT._sample_flow: Euler steps of the flow ODE, optional classifier-free guidance (DiT/network.py:605-651);
+                               fg_dit_sampler_run only */
 
 #define FG_SCHEDULE_EDM 0   /* EDMNoiseSchedule: alpha = 1, sigma = t, t in [0.002, 80] (noise_schedule.py:729-777) */
 #define FG_SCHEDULE_RF 1    /* RFNoiseSchedule:  alpha = 1 - t, sigma = t, t in [0, 0.999] (noise_schedule.py:1306-1341) */
@@ -312,6 +314,30 @@ FG_API size_t fg_dit_workspace_bytes(const fg_dit* h, int batch);
 FG_API int fg_dit_forward(fg_dit* h, const float* x_t, const float* t, const float* r, const int64_t* class_ids, float* out,
                           float* cond_out, int batch, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The sampling loops around fg_dit_forward as ONE call (replayed as one hipGraph per (batch, steps, pointers) when use_graph != 0):
+ *   FG_LOOP_X0        FastGenModel.generator_fn + _student_sample_loop (methods/model.py:315-420): x = noise * sigma(t_0); per step
+ *                     x0 = convert(forward(x, t_i)) [flow -> x0: x - t v, fp64]; if t_{i+1} > 0: x = alpha(t_{i+1}) x0 + sigma(t_{i+1}) eps_i
+ *                     ('ode': eps_i = x0_to_eps(x, x0, t_i)); returns the last x0.
+ *   FG_LOOP_MEANFLOW  MeanFlowModel._student_sample_loop (consistency_model/mean_flow.py:336-381), as fg_sampler_run's.
+ *   FG_LOOP_EULER     DiT._sample_flow (DiT/network.py:605-651): x += fp32(t_{i+1} - t_i) * v, with neg_class_ids != NULL
+ *                     v = v_uncond + guidance_scale * (v_cond - v_uncond) from ONE forward of the doubled batch [x | x], [neg | cond].
+ * The time conditioning that DiT.forward derives on the host (prepare_t's rescaling :457-462, the SiT flip :503-504 and sign :555-558,
+ * the 'diff' form of r :520-521) is described by fg_dit_sampler_config and evaluated on the device from the resident t_list.
+ * noise, out: [B,C,H,W] fp32; class_ids / neg_class_ids: [B] int64; t_list: HOST array of steps+1 doubles ending in 0; eps as for
+ * fg_sampler_run.  Bit-identical to the same loop run step by step through fg_dit_forward and the fg_op_* elementwise kernels. */
+typedef struct fg_dit_sampler_config {
+    double t_scale;          /* the embedder sees fp32(t_scale * t): noise_scheduler.num_steps (1000) with scale_t on the RF schedule, else 1 */
+    double guidance_scale;   /* FG_LOOP_EULER with neg_class_ids */
+    int use_sit_convention;  /* t_e = 1 - t_e, flow output negated */
+    int time_cond_diff;      /* time_cond_type == "diff": r_e = t_e - r_e */
+    int net_pred_flow;       /* net_pred_type == "flow" (1) or "x0" (0) */
+    int schedule;            /* FG_SCHEDULE_* of net.noise_scheduler */
+} fg_dit_sampler_config;
+FG_API size_t fg_dit_sampler_workspace_bytes(const fg_dit* h, int batch, int guided);
+FG_API int fg_dit_sampler_run(fg_dit* h, const fg_dit_sampler_config* cfg, const float* noise, const int64_t* class_ids,
+                              const int64_t* neg_class_ids, const double* t_list, int steps, int sample_type, int loop_kind, const float* eps,
+                              uint64_t seed, float* out, int batch, void* workspace, size_t workspace_bytes, int use_graph, void* stream);
+
 /* ---- Causal video DiT (SURVEY 8(f)3 and the CausVid row of 8(a); reference fastgen/networks/Wan/network_causal.py `CausalWan`, driven
  * chunk by chunk by `CausVidModel._student_sample_loop`, fastgen/methods/distribution_matching/causvid.py:87-185) --------------
  * The arithmetic of this network is diffusers' WanTransformer3DModel (un-vendored, diffusers==0.35.1): the HIP path follows the
@@ -366,6 +392,31 @@ FG_API int fg_wan_forward(fg_wan* h, const float* x_t, const float* t_frames, fl
  * read nor written.  fg_wan_workspace_bytes(batch, total_num_frames, ...) covers this call's extra K / V buffers. */
 FG_API int fg_wan_forward_block_causal(fg_wan* h, const float* x_t, const float* t_frames, float* out, int batch, int frames, int height,
                                        int width, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The chunk-by-chunk student loop of the causal video DiT as ONE call: `CausVidModel._student_sample_loop` (causvid.py:87-185), the
+ * segment loop of `generator_fn_extrapolation` (:283-345, prefill_frames > 0) and the no-grad form of
+ * `SelfForcingModel.rollout_with_gradient` (self_forcing.py:92-241, exit_steps != NULL).  x: [B, C, frames, H, W] fp32 latents (already
+ * scaled by sigma(t_0) where the caller's generator_fn does that), overwritten in place with the generated frames.  Chunks: chunk_size
+ * frames each, the remainder of frames joins the FIRST chunk.  Per chunk: for i in 0 .. last (last = steps - 1, or exit_steps[chunk]):
+ * x0 = convert(fg_wan_forward(x_chunk, t_i, cur_start_frame, store_kv = 0)); unless i == last or t_{i+1} == 0 re-noise to t_{i+1} ('sde':
+ * fresh noise, 'ode': the noise implied by (x_chunk, x0)); then the cache-fill call fg_wan_forward(x0 [re-noised to context_noise],
+ * t = 0 [context_noise], store_kv = 1).  Chunks inside [0, prefill_frames) only run the cache-fill call at t = 0 on x as given.
+ * The self-attention caches are emptied first and cleared (zeroed, text forgotten) at the end, as the reference's loop does: call
+ * fg_wan_set_text before every run.  eps (nullable): steps - 1 (+ 1 if context_noise > 0) noise videos [B, C, frames, H, W] to inject,
+ * indexed by re-noising step (last: the cache call's); NULL: Philox4x32-10 from (seed; chunk, step).  use_graph != 0: one hipGraph per
+ * chunk (start frame, frame count and key length are baked in), replayed while shapes and pointers stay the same.  Bit-identical to
+ * the same sequence of fg_wan_forward + fg_op_* calls. */
+typedef struct fg_wan_sampler_config {
+    double t_scale;        /* the embedder sees fp32(t_scale * t): noise_scheduler.num_steps (1000) on the RF schedule */
+    double context_noise;  /* 0: the cache-fill call sees the clean chunk at t = 0 */
+    int net_pred_flow;     /* net_pred_type == "flow" (1) or "x0" (0) */
+    int schedule;          /* FG_SCHEDULE_* */
+    int prefill_frames;    /* frames at the head of x that only fill the caches (multiple of chunk_size; frames then too) */
+} fg_wan_sampler_config;
+FG_API size_t fg_wan_sampler_workspace_bytes(const fg_wan* h, int batch, int frames, int height, int width);
+FG_API int fg_wan_sampler_run(fg_wan* h, const fg_wan_sampler_config* cfg, float* x, const double* t_list, int steps, int sample_type,
+                              const int* exit_steps, const float* eps, uint64_t seed, int batch, int frames, int height, int width,
+                              void* workspace, size_t workspace_bytes, int use_graph, void* stream);
 
 /* Samples to image bytes, the step after generator_fn in the reference's sample writer
  * (scripts/fid/compute_fid_from_ckpts.py:199): out[n,y,x,c] = uint8(clip(images[n,c,y,x] * 127.5 + 128, 0, 255)),

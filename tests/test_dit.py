@@ -176,3 +176,89 @@ def test_class_index_outside_the_embedding_table_is_reported():
         with pytest.raises(_lib.FastGenAMDError, match="class index"):
             net(x, t, condition=torch.tensor([5, 999], device=dev))
         assert torch.equal(net(x, t, condition=torch.tensor([5, 999], device=dev)), good)  # reported once, then back to normal
+
+
+def _euler_per_step(net, noise, cond, neg, g, steps):
+    """`DiT._sample_flow` (DiT/network.py:605-651) step by step through the module's forward: the loop `fg_dit_sampler_run(FG_LOOP_EULER)` fuses."""
+    sch = net.noise_scheduler
+    tl = sch.get_t_list(steps, device=noise.device)
+    x = sch.latents(noise=noise, t_init=tl[0])
+    n = x.shape[0]
+    for t, tn in zip(tl[:-1], tl[1:]):
+        if neg is not None:
+            vu, vc = net(torch.cat([x, x]), torch.cat([t.expand(n)] * 2), condition=torch.cat([neg, cond]), fwd_pred_type="flow").chunk(2)
+            v = vu + g * (vc - vu)
+        else:
+            v = net(x, t.expand(n), condition=cond, fwd_pred_type="flow")
+        x = x + (tn - t).to(x.dtype) * v
+    return x
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,mode,B", [("s", "bf16x3", 3), ("xl_r", "bf16", 2)])
+def test_fused_sampler_loops_equal_the_per_step_loops(tag, mode, B, monkeypatch):
+    """`fg_dit_sampler_run` - the x0 student loop (methods/model.py:315-420), the MeanFlow loop (mean_flow.py:336-381) and the Euler
+    sampler with classifier-free guidance (DiT/network.py:605-651) as one library call each, replayed as a hipGraph - against the same
+    loops run step by step through `DiT.forward` and the schedule mirror: bit-identical ('sde' with injected noise, 'ode'; graph and
+    eager; a replay with other timesteps)."""
+    from fastgen_amd.methods.consistency_model.mean_flow import MeanFlowModel
+    from fastgen_amd.methods.model import FastGenModel
+    from fastgen_amd.networks.DiT.network import DiT
+
+    dev = torch.device("cuda:0")
+    net = DiT(compute_dtype=mode, **KW[tag])
+    net.load_state_dict(R.random_state_dict(CFGS[tag], seed=77), strict=True)
+    net = net.to(dev).eval()
+    g = torch.Generator().manual_seed(31)
+    noise = torch.randn((B, 4, 32, 32), generator=g).to(dev)
+    cond = torch.nn.functional.one_hot(torch.tensor([3, 500, 999][:B]), 1000).float().to(dev)
+    eps = torch.randn((3, B, 4, 32, 32), generator=g).to(dev)
+    sch = net.noise_scheduler
+
+    def per_step(model_cls, steps, kind, t_list=None):
+        tl = sch.get_t_list(steps, device=dev) if t_list is None else torch.tensor(t_list, dtype=torch.float64, device=dev)
+        pending = [e for e in eps[: steps - 1]]
+        monkeypatch.setattr(torch, "randn_like", lambda x, **kw: pending.pop(0))
+        with torch.inference_mode():
+            out = model_cls._student_sample_loop(net, sch.latents(noise, tl[0]), tl, condition=cond, student_sample_type=kind)
+        monkeypatch.undo()
+        return out
+
+    gf = FastGenModel.generator_fn
+    for kind in ("sde", "ode"):
+        want = per_step(FastGenModel, 4, kind)
+        got = gf(net, noise, student_sample_steps=4, condition=cond, student_sample_type=kind, eps=eps)
+        assert torch.isfinite(got).all() and torch.equal(got, want), kind
+        assert torch.equal(gf(net, noise, student_sample_steps=4, condition=cond, student_sample_type=kind, eps=eps, use_graph=False), want)
+    # the cached graph replayed with another timestep list (same steps / zero pattern), then 1 step
+    tl2 = [0.9, 0.61, 0.33, 0.12, 0.0]
+    assert torch.equal(gf(net, noise, student_sample_steps=4, t_list=tl2, condition=cond, student_sample_type="ode"), per_step(FastGenModel, 4, "ode", tl2))
+    assert torch.equal(gf(net, noise, student_sample_steps=1, condition=cond), per_step(FastGenModel, 1, "sde"))
+    # device RNG: seed control
+    a = gf(net, noise, student_sample_steps=3, condition=cond, seed=5)
+    assert torch.equal(a, gf(net, noise, student_sample_steps=3, condition=cond, seed=5))
+    assert not torch.equal(a, gf(net, noise, student_sample_steps=3, condition=cond, seed=6))
+    if CFGS[tag].r_timestep:
+        mf = MeanFlowModel.generator_fn
+        for kind in ("sde", "ode"):
+            want = per_step(MeanFlowModel, 4, kind)
+            got = mf(net, noise, student_sample_steps=4, condition=cond, student_sample_type=kind, eps=eps)
+            assert torch.isfinite(got).all() and torch.equal(got, want), kind
+        assert torch.equal(mf(net, noise, student_sample_steps=2, t_list=[0.999, 0.5, 0.0], condition=cond, student_sample_type="ode"),
+                           per_step(MeanFlowModel, 2, "ode", [0.999, 0.5, 0.0]))
+    # Euler sampler, guided and plain
+    neg = torch.zeros(B, 1000, device=dev)
+    with torch.inference_mode():
+        want = _euler_per_step(net, noise, cond, neg, 2.5, 4)
+        assert torch.equal(net.sample(noise, condition=cond, neg_condition=neg, guidance_scale=2.5, num_steps=4), want)
+        assert torch.equal(net.sample(noise, condition=cond, neg_condition=neg, guidance_scale=2.5, num_steps=4, use_graph=False), want)
+        want = _euler_per_step(net, noise, cond, None, 1.0, 3)
+        assert torch.equal(net.sample(noise, condition=cond, guidance_scale=None, num_steps=3), want)
+    # refused, not approximated
+    from fastgen_amd import _lib
+
+    with pytest.raises(_lib.FastGenAMDError):
+        gf(net, noise, student_sample_steps=1, t_list=[1.5, 0.0], condition=cond)
+    if not CFGS[tag].r_timestep:
+        with pytest.raises(NotImplementedError):
+            net.few_step_sample(noise, cond, [0.999, 0.0], loop="meanflow")

@@ -267,6 +267,71 @@ def test_causvid_student_loop_against_oracle():
     assert _rel(got.cpu(), want) < 3e-2, _rel(got.cpu(), want)
 
 
+def _per_call_loop(net, x, tl, text, sample_type, context_noise=0.0, eps=None, exits=None):
+    """The chunked student loop as separate network calls through the module's forward and the schedule mirror (what `fg_wan_sampler_run`
+    fuses): chunks of chunk_size frames with the remainder in the first one; per chunk the denoising calls down to the exit step, then the
+    cache-fill call on the result (re-noised to context_noise if asked)."""
+    B, F, cs, sch = x.shape[0], x.shape[2], net.chunk_size, net.noise_scheduler
+    n, rem = F // cs, F % cs
+    bounds = [(0, rem)] if n == 0 else [(0 if i == 0 else cs * i + rem, cs * (i + 1) + rem) for i in range(n)]
+    call = dict(condition=text, fwd_pred_type="x0", is_ar=True)
+    net.clear_caches()
+    for ci, (a, b) in enumerate(bounds):
+        cur = x[:, :, a:b]
+        last = len(tl) - 2 if exits is None else exits[ci]
+        for i in range(last + 1):
+            t = tl[i].expand(B)
+            x0 = net(cur, t, cur_start_frame=a, store_kv=False, **call)
+            if i < last and tl[i + 1] > 0:
+                e = eps[i][:, :, a:b] if sample_type == "sde" else sch.x0_to_eps(xt=cur, x0=x0, t=t)
+                x0 = sch.forward_process(x0, e, tl[i + 1].expand(B))
+            cur = x0
+        x[:, :, a:b] = cur
+        tc, xc = tl[-1].expand(B), cur
+        if context_noise > 0:
+            tc = torch.full((B,), context_noise, device=x.device, dtype=x.dtype)
+            xc = sch.forward_process(cur, eps[-1][:, :, a:b], tc)
+        net(xc, tc, cur_start_frame=a, store_kv=True, **call)
+    net.clear_caches()
+    return x
+
+
+@pytest.mark.gpu
+def test_fused_student_loop_equals_the_per_call_loop():
+    """`fg_wan_sampler_run` (the whole CausVid loop in the library, one hipGraph per chunk) against the same sequence of `CausalWan.forward`
+    calls and schedule-mirror arithmetic: bit-identical - 'ode'; 'sde' with injected noise and a context-noise cache call; chunks of 3 + 2
+    frames; graph, graph replayed (other timesteps), eager; Self-Forcing's per-chunk exit steps."""
+    _, net = _nets(23)
+    g = torch.Generator().manual_seed(24)
+    B, F, H, W = 2, 5, 16, 24
+    lat = (torch.randn(B, 16, F, H, W, generator=g) * 0.999).cuda()
+    text = torch.randn(B, 16, 128, generator=g).cuda()
+    eps = torch.randn(3, B, 16, F, H, W, generator=g).cuda()
+    tl = torch.tensor([0.999, 0.7, 0.3, 0.0], dtype=torch.float64, device="cuda")
+    with torch.inference_mode():
+        want = _per_call_loop(net, lat.clone(), tl, text, "ode")
+        got = net.student_sample(lat.clone(), tl, text, sample_type="ode")
+        assert torch.isfinite(got).all() and torch.equal(got, want)
+        assert torch.equal(net.student_sample(lat.clone(), tl, text, sample_type="ode"), want)  # replay of the cached chunk graphs
+        assert torch.equal(net.student_sample(lat.clone(), tl, text, sample_type="ode", use_graph=False), want)
+        tl2 = torch.tensor([0.95, 0.6, 0.2, 0.0], dtype=torch.float64, device="cuda")
+        assert torch.equal(net.student_sample(lat.clone(), tl2, text, sample_type="ode"), _per_call_loop(net, lat.clone(), tl2, text, "ode"))
+        want = _per_call_loop(net, lat.clone(), tl, text, "sde", context_noise=0.1, eps=eps)
+        got = net.student_sample(lat.clone(), tl, text, sample_type="sde", context_noise=0.1, eps=eps)
+        assert torch.equal(got, want)
+        assert torch.equal(net.student_sample(lat.clone(), tl, text, sample_type="sde", context_noise=0.1, eps=eps, use_graph=False), want)
+        want = _per_call_loop(net, lat.clone(), tl, text, "ode", exits=[0, 2])
+        assert torch.equal(net.student_sample(lat.clone(), tl, text, sample_type="ode", exit_steps=[0, 2]), want)
+        # device RNG: seed control
+        a = net.student_sample(lat.clone(), tl, text, sample_type="sde", seed=3)
+        assert torch.equal(a, net.student_sample(lat.clone(), tl, text, sample_type="sde", seed=3))
+        assert not torch.equal(a, net.student_sample(lat.clone(), tl, text, sample_type="sde", seed=4))
+        # the per-call entry points still work afterwards (caches cleared, text set again on demand)
+        t0 = torch.full((B,), 0.5, dtype=torch.float64, device="cuda")
+        assert torch.isfinite(net(lat[:, :, :3], t0, condition=text, cur_start_frame=0, store_kv=True, is_ar=True)).all()
+        net.clear_caches()
+
+
 class _SFConfig:
     """The ModelConfig fields SelfForcingModel reads (configs/methods/config_self_forcing.py:23-29 + the DMD2 sampling fields)."""
 
