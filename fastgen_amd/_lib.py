@@ -102,8 +102,11 @@ SIGNATURES = {
     "fg_dit_param_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int), POINTER(c_int64)]),
     "fg_dit_bind_param": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
     "fg_dit_pack_weights": (c_int, [c_void_p, c_void_p]),
+    "fg_dit_pack_group": (c_int, [c_void_p, c_char_p, c_char_p, c_void_p]),
     "fg_dit_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "fg_dit_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "fg_dit_forward_features": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int), POINTER(c_void_p),
+                                        c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "fg_dit_sampler_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "fg_dit_sampler_run": (c_int, [c_void_p, POINTER(fg_dit_sampler_config), c_void_p, c_void_p, c_void_p, POINTER(c_double), c_int, c_int, c_int,
                                    c_void_p, c_uint64, c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
@@ -116,6 +119,7 @@ SIGNATURES = {
     "fg_wan_param_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int), POINTER(c_int64)]),
     "fg_wan_bind_param": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
     "fg_wan_pack_weights": (c_int, [c_void_p, c_void_p]),
+    "fg_wan_pack_group": (c_int, [c_void_p, c_char_p, c_char_p, c_void_p]),
     "fg_wan_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int, c_int]),
     "fg_wan_clear_caches": (c_int, [c_void_p, c_void_p]),
     "fg_wan_set_text": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),

@@ -9,7 +9,7 @@ embedding / attention / MLP layers are those of the `timm` classes the reference
 
 Inference / sampling: `forward`, and the three sampling loops as single library calls replayed as hipGraphs (`few_step_sample`:
 `FastGenModel` / `MeanFlowModel._student_sample_loop`; `sample()`: the RF Euler sampler with classifier-free guidance) - `fg_dit_sampler_run`.
-Raises (never falls back): autograd through the network, `feature_indices`, token counts other than 256, and any device but a HIP GPU.
+Raises (never falls back): autograd through the network, token counts other than 256, and any device but a HIP GPU.
 """
 from __future__ import annotations
 
@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from fastgen_amd import _lib
+from fastgen_amd.networks import _weights
 from fastgen_amd.networks.EDM import network as _edm
 from fastgen_amd.networks.network import FastGenNetwork
 from fastgen_amd.networks.noise_schedule import NET_PRED_TYPES
@@ -67,8 +68,7 @@ class DiT(FastGenNetwork):
         self._cfg = cfg
         self.hidden_size = hidden_size
         self._engines: Dict[int, ctypes.c_void_p] = {}
-        self._bound_sig: Dict[int, Any] = {}
-        self._refs: Dict[int, list] = {}
+        self._bound_sig: Dict[int, Dict[str, tuple]] = {}
         self._ws: Dict[int, torch.Tensor] = {}
         # module tree with the reference's key paths; names / shapes come from the library's own plan
         self._names: List[str] = []
@@ -140,22 +140,28 @@ class DiT(FastGenNetwork):
         if dt not in self._engines:
             self._engines[dt] = self._make_engine(dt)
         h = self._engines[dt]
-        tensors = {**dict(self.named_parameters()), "pos_embed": self.pos_embed}
-        sig = tuple((tensors[n].data_ptr(), tensors[n]._version, tensors[n].dtype) for n in self._names)
-        if self._bound_sig.get(dt) != sig:
-            L, refs = _lib.lib(), []
-            for n in self._names:
-                p = tensors[n]
-                if p.device.type != "cuda":
-                    raise RuntimeError(f"parameter {n} is on {p.device}; fastgen_amd runs on a HIP GPU only (no CPU path)")
-                q = p.detach()
-                if q.dtype != torch.float32 or not q.is_contiguous():
-                    q = q.to(torch.float32).contiguous()
-                refs.append(q)
-                _lib.check(L.fg_dit_bind_param(h, n.encode(), ctypes.c_void_p(q.data_ptr()), q.numel()))
-            _lib.check(L.fg_dit_pack_weights(h, ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
-            self._refs[dt], self._bound_sig[dt] = refs, sig
+        L = _lib.lib()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        _weights.sync_weights(
+            self, self._names, self._bound_sig.setdefault(dt, {}),
+            tensors=lambda: {**dict(self.named_parameters()), "pos_embed": self.pos_embed},
+            bind=lambda n, q: _lib.check(L.fg_dit_bind_param(h, n.encode(), ctypes.c_void_p(q.data_ptr()), q.numel())),
+            pack_group=lambda pre, exc: _lib.check(L.fg_dit_pack_group(h, pre.encode(), exc.encode() if exc else None, stream)))
         return dt, h
+
+    def fully_shard(self, **kwargs):
+        """FSDP2 with the reference's grouping (DiT/network.py:402-420): one parameter group per transformer block, one each for the
+        patch / time / class (/ r) embedders and the output layer; `pos_embed` and `logvar_linear` stay whole on the root, as there.
+        Between calls every grouped parameter is a sharded DTensor - state dict, optimizer and checkpointing see what they see in the
+        reference.  The engine keeps its own packed copy of the weights (fastgen_amd/networks/_weights.py): when a group's parameters
+        have changed it is all-gathered, packed and resharded, one group at a time with the next group's all-gather in flight."""
+        from torch.distributed.fsdp import fully_shard
+
+        for block in self._modules["blocks"]._modules.values():
+            fully_shard(block, **kwargs)
+        for name in ("x_embedder", "t_embedder", "y_embedder", "final_layer", "r_embedder"):
+            if name in self._modules:
+                fully_shard(self._modules[name], **kwargs)
 
     def _class_ids(self, condition: Optional[torch.Tensor], B: int, dev) -> torch.Tensor:
         """one-hot -> class index, an all-zero row -> the extra "unconditional" row (:493-498); training-time label dropout (:120-149)."""
@@ -185,8 +191,8 @@ class DiT(FastGenNetwork):
     def forward(self, x_t: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None, r: Optional[torch.Tensor] = None,
                 return_features_early: bool = False, feature_indices: Optional[Set[int]] = None, return_logvar: bool = False,
                 fwd_pred_type: Optional[str] = None, **fwd_kwargs):
-        if feature_indices:
-            raise NotImplementedError("feature_indices (block outputs for a discriminator) are not implemented for the DiT path")
+        if feature_indices is None:
+            feature_indices = {}
         if fwd_kwargs:
             raise TypeError(f"unexpected forward kwargs: {sorted(fwd_kwargs)}")
         if fwd_pred_type is None:
@@ -225,15 +231,29 @@ class DiT(FastGenNetwork):
         ws = self._ws.get(dt)
         if ws is None or ws.numel() < need or ws.device != dev:
             ws = self._ws[dt] = torch.empty(need, dtype=torch.uint8, device=dev)
-        out = torch.empty_like(x32)
-        _lib.check(L.fg_dit_forward(h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t_e.data_ptr()),
-                                    ctypes.c_void_p(r_e.data_ptr() if r_e is not None else None), ctypes.c_void_p(cls.data_ptr()),
-                                    ctypes.c_void_p(out.data_ptr()), None, B, ctypes.c_void_p(ws.data_ptr()), ws.numel(),
-                                    ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        # block-output taps (:536-543): token tensors [B, 256, D] behind the requested blocks; with return_features_early the call
+        # stops at the last of them (no requested index: after the first block, an empty list - as the reference's loop does)
+        depth = self._cfg.depth
+        taps = sorted(i for i in set(feature_indices) if 0 <= i < depth)
+        if return_features_early and len(taps) == len(feature_indices) and not taps:
+            return []
+        early = return_features_early and len(taps) == len(feature_indices)  # (an index past the last block: the reference never returns early)
+        feats = [torch.empty(B, 256, self.hidden_size, dtype=torch.float32, device=dev) for _ in taps]
+        out = None if early else torch.empty_like(x32)
+        _lib.check(L.fg_dit_forward_features(
+            h, ctypes.c_void_p(x32.data_ptr()), ctypes.c_void_p(t_e.data_ptr()), ctypes.c_void_p(r_e.data_ptr() if r_e is not None else None),
+            ctypes.c_void_p(cls.data_ptr()), ctypes.c_void_p(out.data_ptr() if out is not None else None), None,
+            (ctypes.c_int * len(taps))(*taps) if taps else None, (ctypes.c_void_p * len(taps))(*[f.data_ptr() for f in feats]) if taps else None,
+            len(taps), B, ctypes.c_void_p(ws.data_ptr()), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        feats = [f.to(x_t.dtype) for f in feats]
+        if early:
+            return feats
         out = out.to(x_t.dtype)
         if self.use_sit_convention and self.net_pred_type == "flow":
             out = -out  # :555-558
         out = self.noise_scheduler.convert_model_output(x_t, out, t_in, src_pred_type=self.net_pred_type, target_pred_type=fwd_pred_type)
+        if len(feature_indices) != 0:
+            out = [out, feats]
         if return_logvar:
             return out, self._logvar(t_e)
         return out

@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from fastgen_amd import _lib
+from fastgen_amd.networks import _weights
 from fastgen_amd.networks.EDM import network as _edm
 from fastgen_amd.networks.network import FastGenNetwork
 from fastgen_amd.networks.noise_schedule import NET_PRED_TYPES
@@ -52,7 +53,7 @@ class CausalWan(FastGenNetwork):
         h = ctypes.c_void_p()
         _lib.check(_lib.lib().fg_wan_create(ctypes.byref(cfg), ctypes.byref(h)))
         self._h = h
-        self._names, self._bound_sig, self._refs, self._ws = [], None, [], None
+        self._names, self._bound_sig, self._ws = [], {}, None
         self._text_key = None
         L = _lib.lib()
         name, ndim, shape = ctypes.c_char_p(), ctypes.c_int(), (ctypes.c_int64 * 5)()
@@ -96,22 +97,26 @@ class CausalWan(FastGenNetwork):
         return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
     def _bind(self, dev: torch.device):
-        tensors = dict(self.named_parameters())
+        L = _lib.lib()
         names = [n for n in self._names if "logvar_linear" not in n]
-        sig = tuple((tensors[n].data_ptr(), tensors[n]._version, tensors[n].dtype) for n in names)
-        if self._bound_sig != sig:
-            L, refs = _lib.lib(), []
-            for n in names:
-                p = tensors[n]
-                if p.device.type != "cuda":
-                    raise RuntimeError(f"parameter {n} is on {p.device}; fastgen_amd runs on a HIP GPU only (no CPU path)")
-                q = p.detach()
-                if q.dtype != torch.float32 or not q.is_contiguous():
-                    q = q.to(torch.float32).contiguous()
-                refs.append(q)
-                _lib.check(L.fg_wan_bind_param(self._h, n.encode(), ctypes.c_void_p(q.data_ptr()), q.numel()))
-            _lib.check(L.fg_wan_pack_weights(self._h, self._stream(dev)))
-            self._refs, self._bound_sig, self._text_key = refs, sig, None
+        changed = _weights.sync_weights(
+            self, names, self._bound_sig, tensors=lambda: dict(self.named_parameters()),
+            bind=lambda n, q: _lib.check(L.fg_wan_bind_param(self._h, n.encode(), ctypes.c_void_p(q.data_ptr()), q.numel())),
+            pack_group=lambda pre, exc: _lib.check(L.fg_wan_pack_group(self._h, pre.encode(), exc.encode() if exc else None, self._stream(dev))))
+        if changed:
+            self._text_key = None  # the text caches were computed with the previous weights
+
+    def fully_shard(self, **kwargs):
+        """FSDP2 with the reference's grouping (Wan/network.py:761-782): one parameter group per transformer block, then the transformer
+        itself (embedders, output layer, `logvar_linear`) as the root group.  The engine keeps its own packed bf16 copy of the weights
+        (fastgen_amd/networks/_weights.py): a group whose parameters changed is all-gathered, packed and resharded - ONE block's fp32
+        parameters whole at a time, which is what carries to the 14B network (40 blocks of 350M parameters)."""
+        from torch.distributed.fsdp import fully_shard
+
+        tr = self._modules["transformer"]
+        for block in tr._modules["blocks"]._modules.values():
+            fully_shard(block, **kwargs)
+        fully_shard(tr, **kwargs)
 
     def _workspace(self, dev, B, F, H, W) -> torch.Tensor:
         need = _lib.lib().fg_wan_workspace_bytes(self._h, B, F, H, W)

@@ -298,11 +298,18 @@ typedef struct fg_dit fg_dit; /* opaque */
 FG_API int fg_dit_create(const fg_dit_config* cfg, fg_dit** out);
 FG_API void fg_dit_destroy(fg_dit* h);
 /* State-dict view: the reference's names and shapes (restated timm attribute names for the patch embedding / attention / MLP
- * layers), `pos_embed` (a persistent buffer there) included; bind / pack as for fg_edm. */
+ * layers), `pos_embed` (a persistent buffer there) included.  bind + pack: unlike fg_edm (which borrows its parameters' memory until
+ * the next pack) this engine copies at pack time - see fg_dit_pack_group. */
 FG_API int fg_dit_num_params(const fg_dit* h);
 FG_API int fg_dit_param_info(const fg_dit* h, int index, const char** name, int* ndim, int64_t shape[4]);
 FG_API int fg_dit_bind_param(fg_dit* h, const char* name, const float* device_ptr, int64_t numel);
 FG_API int fg_dit_pack_weights(fg_dit* h, void* stream);
+/* fg_dit_pack_weights for the parameters whose names start with `prefix` and not with `exclude` (nullable) - "blocks.7.", "x_embedder.",
+ * ... : the unit a sharded-data-parallel wrapper gathers at a time (DiT.fully_shard, DiT/network.py:402-420).  Packing COPIES: the block
+ * linears into their GEMM layouts, every other parameter into engine-owned fp32 storage, so a bound pointer is read during
+ * fg_dit_pack_group / fg_dit_pack_weights only and may be freed once that call's work on `stream` has been ordered before the free.
+ * fg_dit_forward runs once every parameter has been packed since its last bind. */
+FG_API int fg_dit_pack_group(fg_dit* h, const char* prefix, const char* exclude, void* stream);
 FG_API size_t fg_dit_workspace_bytes(const fg_dit* h, int batch);
 /* The network part of DiT.forward (:511-547): patch embedding + positional table, conditioning vector, the transformer blocks,
  * output projection, unpatchify.  x_t, out: [B,C,H,W] fp32; t, r: [B] fp32 AS THE EMBEDDERS SEE THEM (after prepare_t's rescaling,
@@ -313,6 +320,13 @@ FG_API size_t fg_dit_workspace_bytes(const fg_dit* h, int batch);
  * cond_out (nullable): [B, hidden_size] conditioning vector c.  Prediction-type conversion and the SiT sign stay with the caller. */
 FG_API int fg_dit_forward(fg_dit* h, const float* x_t, const float* t, const float* r, const int64_t* class_ids, float* out,
                           float* cond_out, int batch, void* workspace, size_t workspace_bytes, void* stream);
+
+/* fg_dit_forward with the block-output taps of DiT.forward (`feature_indices` / `return_features_early`, :483-484, 536-543, 563-566):
+ * feature_blocks: HOST array of num_features ascending block indices; features: HOST array of as many device buffers, each
+ * [B, tokens, hidden_size] fp32 = the token tensor behind that block.  out == NULL: return after the last requested block. */
+FG_API int fg_dit_forward_features(fg_dit* h, const float* x_t, const float* t, const float* r, const int64_t* class_ids, float* out,
+                                   float* cond_out, const int* feature_blocks, float* const* features, int num_features, int batch,
+                                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* The sampling loops around fg_dit_forward as ONE call (replayed as one hipGraph per (batch, steps, pointers) when use_graph != 0):
  *   FG_LOOP_X0        FastGenModel.generator_fn + _student_sample_loop (methods/model.py:315-420): x = noise * sigma(t_0); per step
@@ -369,6 +383,9 @@ FG_API int fg_wan_num_params(const fg_wan* h);
 FG_API int fg_wan_param_info(const fg_wan* h, int index, const char** name, int* ndim, int64_t shape[5]);
 FG_API int fg_wan_bind_param(fg_wan* h, const char* name, const float* device_ptr, int64_t numel);
 FG_API int fg_wan_pack_weights(fg_wan* h, void* stream);
+/* As fg_dit_pack_group: "transformer.blocks.7." packs one block, prefix "transformer." with exclude "transformer.blocks." the rest
+ * (the grouping of Wan.fully_shard, Wan/network.py:761-782).  Bound pointers are read at pack time only. */
+FG_API int fg_wan_pack_group(fg_wan* h, const char* prefix, const char* exclude, void* stream);
 /* Workspace for one forward over a chunk of `frames` latent frames of height x width (also enough for fg_wan_set_text). */
 FG_API size_t fg_wan_workspace_bytes(const fg_wan* h, int batch, int frames, int height, int width);
 /* `CausalWan.clear_caches` (:1030-1054): zero the self-attention caches, forget the text (cross-attention) caches. */

@@ -262,3 +262,40 @@ def test_fused_sampler_loops_equal_the_per_step_loops(tag, mode, B, monkeypatch)
     if not CFGS[tag].r_timestep:
         with pytest.raises(NotImplementedError):
             net.few_step_sample(noise, cond, [0.999, 0.0], loop="meanflow")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_feature_taps(golden_dir, mode):
+    """`feature_indices` / `return_features_early` (DiT/network.py:483-484, 536-543, 563-566): the token tensors behind the requested
+    blocks, against the oracle's trace of the same forward and the strided samples recorded from the reference's own blocks."""
+    from fastgen_amd.networks.DiT.network import DiT
+
+    fx = torch.load(os.path.join(golden_dir, "dit_forward_b2.pt"), weights_only=True)
+    dev = torch.device("cuda:0")
+    cfg = CFGS["s"]
+    sd = R.random_state_dict(cfg, seed=77)
+    net = DiT(compute_dtype=mode, **KW["s"])
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    x, t, cond, _ = _inputs(fx, "s")
+    tr = {}
+    R.dit_forward(sd, cfg, x, t, cond, trace=tr)
+    xd, td, cd = x.to(dev), t.to(dev), cond.to(dev)
+    tol = 5e-5 if mode == "bf16x3" else 2e-2
+    with torch.inference_mode():
+        plain = net(xd, td, condition=cd)
+        out, feats = net(xd, td, condition=cd, feature_indices={0, 6, 11})
+        early = net(xd, td, condition=cd, feature_indices={0, 6}, return_features_early=True)
+        (out_lv, feats_lv), logvar = net(xd, td, condition=cd, feature_indices={11}, return_logvar=True)
+        assert net(xd, td, condition=cd, return_features_early=True) == []
+        out_past, feats_past = net(xd, td, condition=cd, feature_indices={6, 40}, return_features_early=True)  # block 40 never comes: no early return
+    assert torch.equal(out, plain) and torch.equal(out_lv, plain) and torch.equal(out_past, plain) and logvar.shape == (2, 1)
+    assert [tuple(f.shape) for f in feats] == [(2, 256, 384)] * 3 and len(early) == 2 and len(feats_lv) == 1 and len(feats_past) == 1
+    for f, i in zip(feats, (0, 6, 11)):
+        want = tr[f"block{i}"]
+        assert float((f.cpu() - want).norm() / want.norm()) <= tol, i
+        v = f.float().cpu().reshape(-1)
+        smp = v[:: max(1, v.numel() // 1024)][:1024]
+        assert float((smp - fx[f"s/block{i}/sample"]).norm() / fx[f"s/block{i}/sample"].norm()) <= tol, i
+    assert torch.equal(early[0], feats[0]) and torch.equal(early[1], feats[1]) and torch.equal(feats_lv[0], feats[2]) and torch.equal(feats_past[0], feats[1])
