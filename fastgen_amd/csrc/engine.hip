@@ -1262,7 +1262,7 @@ int fg_op_attention(const void* q, const void* k, const void* v, void* out, int 
 int fg_op_gemm_bf16(const void* a, const void* w, const float* bias, void* out, int m, int n, int k, int act, const float* gate,
                     int gate_stride, int gate_rows, const void* resid, int tile_order, void* stream) {
 #ifdef FG_TIMING_BUILD
-    const int act_ok = 1 | 4 | 8, order_ok = 255;  // + act 4 / 8: no stores / no epilogue; tile_order 128: cycle stamps (gemm.hip, GM_TIMING)
+    const int act_ok = 1 | 4 | 8 | 32, order_ok = 255;  // + act 4 / 8: no stores / no epilogue; tile_order 128: cycle stamps (gemm.hip, GM_TIMING)
 #else
     const int act_ok = 1, order_ok = 127;
 #endif

@@ -428,6 +428,10 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
+    auto mem_done5 = [&]() {  // (timing build: a phase that also issued one trickled store)
+        asm volatile("s_waitcnt vmcnt(5)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto cmp_done = [&]() {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_barrier" ::: "memory");
@@ -678,12 +682,23 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
     if (wr == 1) asm volatile("s_barrier" ::: "memory");  // the second group runs one barrier behind
 
     // one K-step = four phases
-    auto kstep = [&](int t) {
+    int tr_m0 = 0, tr_n0 = 0;  // (timing build, act bit 32: origin of the tile whose outputs are trickled out during this tile's K-loop)
+    auto kstep = [&](int t, int kk) {
         const int cb = t & 1, nb = cb ^ 1;
         // phase 0: quadrant (0,0)
         read_w(W0, cb, 0);
+        bool trickled = false;
+        if constexpr (EPI == GM_EPI_TOK) {
+            if (GM_TIMING((a.act & 32) && kk < 16)) {
+                // experiment: is a store issued here, one per K-step, hidden behind the loop?  (X1's registers: free until phase 2)
+                const int so = __builtin_amdgcn_readfirstlane(((tr_m0 + (kk & 7) * 16) * a.N + tr_n0 + 32 * (kk >> 3)) * 2);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fg_u32x4, X1[0][0]), make_rsrc(a.out), ((wr * 128 + col) * a.N + wc * 64 + 16 * (g & 1) + 8 * (g >> 1)) * 2, so, 0);
+                trickled = true;
+            }
+        }
         dmaA(nb * 65536 + 16384, c1.sa + 128 * KA2);
-        mem_done();
+        if (trickled) mem_done5();
+        else mem_done();
         __builtin_amdgcn_s_setprio(1);
         mma(0, 0, X0, W0);
         __builtin_amdgcn_s_setprio(0);
@@ -731,7 +746,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         stamp(0);
         if (ti > 0 && wr == 1) asm volatile("s_barrier" ::: "memory");  // the second group falls one barrier behind again
         for (int kk = 0; kk + 1 < nk; ++kk) {
-            kstep(t);
+            kstep(t, kk);
             advance();
         }
         stamp(1);
@@ -747,7 +762,8 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
             b10 = *reinterpret_cast<const f32x4*>(bp + 32);
             b11 = *reinterpret_cast<const f32x4*>(bp + 48);
         }
-        kstep(t);
+        kstep(t, nk - 1);
+        tr_m0 = ep_m0, tr_n0 = ep_n0;
         // the groups meet before the epilogue (the first one waits out the second's last compute part) and run it side by side:
         // one barrier apart, each group's 7 000-cycle epilogue stalled the other at its next barrier (cycle stamps,
         // scripts/gemm_stamps.py: 14 800 of a K = 1152 tile's 70 000 cycles)
