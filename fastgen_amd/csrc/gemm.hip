@@ -321,21 +321,34 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
     count *= ks;
     const int my_tiles = first < count ? (count - first + stride - 1) / stride : 0;  // work items of this workgroup
     if (my_tiles == 0) return;
+    const int nk = (a.K / GM_KC) / ks;  // K-steps per work item
+    // ---- stagger: every workgroup's tiles take the same time, so left alone all 256 CUs end their tiles together and their stores - 32 MB
+    // per round of tiles - hit HBM as one burst that nothing overlaps: the wave's own next loads queue behind its stores (vmcnt retires
+    // in order).  At K = 1152 that burst is a fifth of the kernel's time (scripts/gemm_exp.py: timing builds without the stores; and with
+    // XCD x started x / 8 of a tile late: the cost is gone, traded for the idle start).  Here the offset costs nothing: a workgroup on XCD x
+    // (blockIdx.x & 7: the workgroups of one XCD stay in lockstep - they share A rows and W columns through their L2) first walks the
+    // K-steps [ksh, nk) of its first tile, ksh = x nk / 8, parks those partial sums in fp32 scratch, walks its other tiles whole, and ends
+    // with the K-steps [0, ksh) of the first tile, added to the parked sums.  The XCDs' tile ends are nk / 8 K-steps apart.
+    // item i -> tile: i < my_tiles: tile i; i == my_tiles (the closing piece): tile 0.
+    const int ksh = (EPI == GM_EPI_TOK && a.stagger_on && my_tiles >= 2) ? (((int)blockIdx.x & 7) * nk) / 8 : 0;
+    const int items = my_tiles + (ksh ? 1 : 0);
+    auto item_tile = [&](int i) { return i >= my_tiles ? (ksh ? 0 : my_tiles - 1) : i; };  // (cursors running past the end re-read a valid tile)
+    auto item_kbegin = [&](int i) { return i == 0 ? ksh : 0; };
+    auto item_kend = [&](int i) { return (ksh && i >= my_tiles) ? ksh : nk; };
     auto tile_origin = [&](int i, int& m0, int& n0) {
-        const int lt = (first + min(i, my_tiles - 1) * stride) / ks;  // (cursors running past the end re-read the last tile)
+        const int lt = (first + item_tile(i) * stride) / ks;
         const int q = lt / nx;
         m0 = min((mlo + q) * GM_TM, a.M - GM_TM);
         n0 = min((nlo + (lt - q * nx)) * TN, a.N - TN);
     };
-    auto item_split = [&](int i) { return (first + min(i, my_tiles - 1) * stride) % ks; };
+    auto item_split = [&](int i) { return (first + item_tile(i) * stride) % ks; };
     // where the tile would start without the shift: rows / columns below are the neighbour tile's and are not stored again
     auto tile_keep_from = [&](int i, int& mk, int& nk_) {
-        const int lt = (first + min(i, my_tiles - 1) * stride) / ks;
+        const int lt = (first + item_tile(i) * stride) / ks;
         const int q = lt / nx;
         mk = (mlo + q) * GM_TM;
         nk_ = (nlo + (lt - q * nx)) * TN;
     };
-    const int nk = (a.K / GM_KC) / ks;  // K-steps per work item
     const int S = my_tiles * nk;
     // row pitches in bytes (split-bf16 flavour: A rows hold [hi | lo] = 2 K1 elements, W rows [hi | lo | hi] = 3 K1 = K elements)
     const int KA2 = (a.lda ? a.lda : a.K) * 2, KW2 = (a.ldw ? a.ldw : a.K) * 2;
@@ -378,7 +391,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         c.sw = __builtin_amdgcn_readfirstlane(n0 * KW2 + ks_ * (GM_KC * 2));
     };
     auto cur_next = [&](Cur& c) {
-        if (++c.kk == nk) c.kk = 0, ++c.ti;
+        if (++c.kk >= item_kend(c.ti)) ++c.ti, c.kk = 0;  // (items behind the first begin at K-step 0)
         cur_set(c);
     };
 
@@ -663,9 +676,14 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
 
+    if (GM_TIMING(a.act & 64)) {  // (timing build) XCD x starts x / 8 of a tile's time late: do the XCDs' store bursts, apart, cost less?
+        const long long wait = (long long)((int)blockIdx.x & 7) * (long long)(a.K / GM_KC) * 3400 / 8;
+        const long long t0 = (long long)__builtin_readcyclecounter();
+        while ((long long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
     // ---- prologue: K-step 0 whole, the two early half-tiles of K-step 1 ------------------------------------------------
-    Cur c1{0, 0, 0, 0}, c2{0, 0, 0, 0};
-    cur_set(c1);                 // = K-step 0 for now
+    Cur c1{0, item_kbegin(0), 0, 0}, c2{0, 0, 0, 0};
+    cur_set(c1);                 // = the first K-step for now
     dmaA(0, c1.sa);
     dmaA(16384, c1.sa + 128 * KA2);
     dmaW(32768, c1.sw);
@@ -741,11 +759,14 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         if (t + 3 < S) cur_next(c2);
         ++t;
     };
-    for (int ti = 0; ti < my_tiles; ++ti) {
+    // the parked partial sums of the first tile: [workgroup][accumulator quad 0 .. 31][thread] x 16 bytes (every thread re-reads its own)
+    float* const park = a.stagger ? a.stagger + (size_t)blockIdx.x * 32 * GM_NTHR * 4 + (size_t)tid * 4 : nullptr;
+    for (int ti = 0; ti < items; ++ti) {
         stamp_tile = ti;
         stamp(0);
         if (ti > 0 && wr == 1) asm volatile("s_barrier" ::: "memory");  // the second group falls one barrier behind again
-        for (int kk = 0; kk + 1 < nk; ++kk) {
+        const int len = item_kend(ti) - item_kbegin(ti);
+        for (int kk = 0; kk + 1 < len; ++kk) {
             kstep(t, kk);
             advance();
         }
@@ -754,7 +775,8 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         f32x4 b00 = {0.f, 0.f, 0.f, 0.f}, b01 = b00, b10 = b00, b11 = b00;
         tile_origin(ti, ep_m0, ep_n0);
         tile_keep_from(ti, ep_mk, ep_nk);
-        if (a.bias && EPI != GM_EPI_RAW) {
+        const bool parks = ksh && ti == 0;  // (uniform) the first piece of the split tile: no epilogue, its sums are parked
+        if (a.bias && EPI != GM_EPI_RAW && !parks) {
             const int n0 = ep_n0;
             const float* bp = a.bias + n0 + wc * 64 + 4 * g;
             b00 = *reinterpret_cast<const f32x4*>(bp);
@@ -762,20 +784,42 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
             b10 = *reinterpret_cast<const f32x4*>(bp + 32);
             b11 = *reinterpret_cast<const f32x4*>(bp + 48);
         }
-        kstep(t, nk - 1);
+        kstep(t, len - 1);
         tr_m0 = ep_m0, tr_n0 = ep_n0;
         // the groups meet before the epilogue (the first one waits out the second's last compute part) and run it side by side:
         // one barrier apart, each group's 7 000-cycle epilogue stalled the other at its next barrier (cycle stamps,
         // scripts/gemm_stamps.py: 14 800 of a K = 1152 tile's 70 000 cycles)
         if (wr == 0) asm volatile("s_barrier" ::: "memory");
         stamp(2);
-        slice(I0{}, I0{}, ti, b00, b01);
-        stamp(4);
-        slice(I0{}, I1{}, ti, b10, b11);
-        stamp(5);
-        slice(I1{}, I1{}, ti, b10, b11);
-        stamp(6);
-        slice(I1{}, I0{}, ti, b00, b01);
+        if (parks) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    *reinterpret_cast<f32x4*>(park + (size_t)(m * 4 + nt) * GM_NTHR * 4) = acc[m][nt];
+                    acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            if (ksh && ti == my_tiles) {  // the closing piece: + the sums parked by the first one (this thread's own stores, long retired)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    f32x4 p4[4];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) p4[nt] = *reinterpret_cast<const f32x4*>(park + (size_t)(m * 4 + nt) * GM_NTHR * 4);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[m][nt] += p4[nt];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            slice(I0{}, I0{}, ti, b00, b01);
+            stamp(4);
+            slice(I0{}, I1{}, ti, b10, b11);
+            stamp(5);
+            slice(I1{}, I1{}, ti, b10, b11);
+            stamp(6);
+            slice(I1{}, I0{}, ti, b00, b01);
+        }
         stamp(3);
         advance();
     }
@@ -887,6 +931,15 @@ int launch_gm(const GemmArgs& a, hipStream_t s, bool prepare_only) {
     return (int)hipGetLastError();
 }
 
+// FASTGEN_AMD_GEMM_STAGGER=0 keeps every workgroup on whole tiles (A/B measurements; results are the same sums in another order)
+bool gm_env_stagger() {
+    static const bool on = [] {
+        const char* e = getenv("FASTGEN_AMD_GEMM_STAGGER");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 template <int EPI>
 int launch_pp(const GemmArgs& a, hipStream_t s, bool prepare_only) {
     constexpr int LDS = 131072;
@@ -921,6 +974,9 @@ int launch_pp(const GemmArgs& a, hipStream_t s, bool prepare_only) {
         if (a.xn <= 8 && (a.xn & (a.xn - 1)) == 0 && Nt % a.xn == 0 && a.xn != 1) xn = a.xn;
         b.xn = xn;
     }
+    // staggered tile boundaries (see the kernel): where every CU has at least three tiles of at least eight K-steps
+    b.stagger_on = (EPI == GM_EPI_TOK && a.stagger && (grid & 7) == 0 && grid <= 512 && b.ksplit <= 1 && (a.K / GM_KC) >= 8 && items >= 3LL * grid &&
+                    gm_env_stagger()) ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(GM_NTHR), LDS, s, b);
     if (EPI == GM_EPI_RAW) {
         const int64_t n = (int64_t)a.M * (a.N / 8);

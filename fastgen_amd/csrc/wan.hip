@@ -211,7 +211,7 @@ template <int HD, int MINW, bool FA_DMA>
 __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict__ q, int ldq, int64_t q_bs, const __bf16* __restrict__ k,
                                                        const __bf16* __restrict__ v, int ldk, int64_t kv_bs, __bf16* __restrict__ out, int ldo,
                                                        int64_t o_bs, int Lq, int Lkv, float scale_log2e, int nsplit, float* __restrict__ po,
-                                                       float* __restrict__ plse, int heads, int batch FA_ABL_PARAM) {
+                                                       float* __restrict__ plse, int heads, int batch, int sample_major FA_ABL_PARAM) {
     constexpr int KS = (HD + 15) / 16;   // 16-deep steps of q k^T
     constexpr int DT_ = (HD + 31) / 32;  // 32-wide tiles of output dims
     constexpr int RP = HD * 2;           // LDS row pitch of the K tile
@@ -235,9 +235,22 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
     // log2-domain log-sum-exp of its keys; fa128_combine_kernel merges the splits.
     const int qtiles = (Lq + 127) / 128, units = batch * heads * nsplit;
     const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-    const int unit = (slot / qtiles) * 8 + xcd, qt = slot % qtiles;
-    if (unit >= units) return;  // (the grid is padded to a multiple of 8 units; uniform per workgroup, before any barrier)
-    const int split = unit % nsplit, bh = unit / nsplit, head = bh % heads, b = bh / heads;
+    const int qt = slot % qtiles;
+    int split, head, b;
+    if (sample_major) {
+        // many samples of few tokens (DiT: 256 tokens, 16 heads x 72 in one [token][3 x 1152] tensor): ALL heads of a sample on one XCD, one
+        // after the other.  A head's 144-byte rows straddle the 128-byte lines of its neighbours' rows: dealt head by head to the eight
+        // L2s every line was fetched by two or three of them (1.5 GB per launch for 0.6 GB of q / k / v / out at B = 256).
+        const int u = slot / qtiles;
+        b = (u / heads) * 8 + xcd, head = u % heads, split = 0;
+        if (b >= batch) return;
+    } else {
+        const int unit = (slot / qtiles) * 8 + xcd;
+        if (unit >= units) return;  // (the grid is padded to a multiple of 8 units; uniform per workgroup, before any barrier)
+        split = unit % nsplit;
+        const int bh = unit / nsplit;
+        head = bh % heads, b = bh / heads;
+    }
     const int q0 = qt * 128 + wave * 32;
     // this lane's query row (clamped: rows past Lq compute on the last row and are not stored)
     const __bf16* qrow = q + (size_t)b * q_bs + (size_t)min(q0 + r, Lq - 1) * ldq + head * HD + 8 * h;
@@ -788,7 +801,8 @@ int launch_fa(int hd, const void* q, int ldq, int64_t q_bs, const void* k, const
     }
     float* po = (float*)scratch;
     float* plse = po ? po + (size_t)FA_MAX_SPLIT * B * Lq * heads * hd : nullptr;
-    const long long units = (long long)B * heads * nsplit;
+    const int sample_major = (nsplit == 1 && B >= 8 && Lq <= 1024) ? 1 : 0;
+    const long long units = sample_major ? (long long)((B + 7) / 8) * 8 * heads : (long long)B * heads * nsplit;
     dim3 g((unsigned)(((units + 7) / 8) * 8 * qtiles));
     static int use_dma = -1;  // head dim 128: LDS-DMA ring (1, default) | two-deep register prefetch (0): FASTGEN_AMD_FA_DMA
     if (use_dma < 0) {
@@ -810,7 +824,7 @@ int launch_fa(int hd, const void* q, int ldq, int64_t q_bs, const void* k, const
     const float sc = 1.44269504088896341f / sqrtf((float)hd);
 #define FA_GO(HD, MW, LDS, DM)                                                                                                              \
     hipLaunchKernelGGL((fa_kernel<HD, MW, DM>), g, dim3(256), LDS, s, (const __bf16*)q, ldq, q_bs, (const __bf16*)k, (const __bf16*)v, ldk, kv_bs, \
-                       (__bf16*)out, ldo, o_bs, Lq, Lkv, sc, nsplit, po, plse, heads, B FA_ABL_ARG)
+                       (__bf16*)out, ldo, o_bs, Lq, Lkv, sc, nsplit, po, plse, heads, B, sample_major FA_ABL_ARG)
     if (hd == 128) {
         if ((size_t)Lkv * ldk * 2 >= ((size_t)1 << 31)) return (int)hipErrorInvalidValue;  // (buffer-resource offsets are 32-bit)
         if (!use_dma) FA_GO(128, 2, 32768, false);

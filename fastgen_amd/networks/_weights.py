@@ -72,15 +72,18 @@ def sync_weights(owner: torch.nn.Module, names: List[str], sigs: Dict[str, tuple
     pending = None  # the all-gather of the next sharded group, issued before the current one is packed
     for i, (pre, exc, mod, mine, sig) in enumerate(todo):
         if mod is not None:
-            if pending is not None and pending[0] is mod:
-                if pending[1] is not None:
-                    pending[1].wait()
-            else:
-                mod.unshard()
-            pending = None
-            nxt = next((t[2] for t in todo[i + 1:] if t[2] is not None), None)
-            if nxt is not None:
-                pending = (nxt, nxt.unshard(async_op=True))
+            # (FSDP2's all-gather buffers must be ordinary tensors: created under torch.inference_mode() they could not be reused - or
+            # version-checked - by a later gather outside it)
+            with torch.inference_mode(False), torch.no_grad():
+                if pending is not None and pending[0] is mod:
+                    if pending[1] is not None:
+                        pending[1].wait()
+                else:
+                    mod.unshard()
+                pending = None
+                nxt = next((t[2] for t in todo[i + 1:] if t[2] is not None), None)
+                if nxt is not None:
+                    pending = (nxt, nxt.unshard(async_op=True))
             cur = tensors()  # the group's parameters are whole tensors now
         keep = []
         for n in mine:
@@ -94,6 +97,7 @@ def sync_weights(owner: torch.nn.Module, names: List[str], sigs: Dict[str, tuple
             bind(n, q)
         pack_group(pre, exc)  # copies on the current stream: `keep` and the gathered parameters may go afterwards (stream-ordered frees)
         if mod is not None:
-            mod.reshard()
+            with torch.inference_mode(False), torch.no_grad():
+                mod.reshard()
         sigs[pre] = sig
     return True
