@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/fastgen_amd.h"
+#include "common.h"
 #include "conv.h"
 #include "misc.h"
 

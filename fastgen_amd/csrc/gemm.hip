@@ -286,7 +286,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_kernel(const GemmArgs a) {
 #endif
 #define GM_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
-template <int EPI>
+template <int EPI, bool STAG = false>
 __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a) {
     constexpr int TN = 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
     // K-steps [ksh, nk) of its first tile, ksh = x nk / 8, parks those partial sums in fp32 scratch, walks its other tiles whole, and ends
     // with the K-steps [0, ksh) of the first tile, added to the parked sums.  The XCDs' tile ends are nk / 8 K-steps apart.
     // item i -> tile: i < my_tiles: tile i; i == my_tiles (the closing piece): tile 0.
-    const int ksh = (EPI == GM_EPI_TOK && a.stagger_on && my_tiles >= 2) ? (((int)blockIdx.x & 7) * nk) / 8 : 0;
+    const int ksh = (STAG && EPI == GM_EPI_TOK && my_tiles >= 2) ? (((int)blockIdx.x & 7) * nk) / 8 : 0;  // (a kernel of its own: the launcher's stagger_on)
     const int items = my_tiles + (ksh ? 1 : 0);
     auto item_tile = [&](int i) { return i >= my_tiles ? (ksh ? 0 : my_tiles - 1) : i; };  // (cursors running past the end re-read a valid tile)
     auto item_kbegin = [&](int i) { return i == 0 ? ksh : 0; };
@@ -469,9 +469,40 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
     const int vo_out = ((wr * 128 + col) * a.N + lane_c8) * 2;
     const __amdgpu_buffer_rsrc_t rsO = make_rsrc(a.out), rsR = make_rsrc(a.resid), rsG = make_rsrc(a.gate);
     // (gate periods >= the tile height: a tile then spans at most two gate rows; launch_gemm_bf16 sends shorter ones to gemm_bf16_kernel)
-    auto slice = [&](auto MH_, auto NH_, int tile, f32x4 be, f32x4 bo) {
+    // pmode (uniform; stagger only): 1 = the first piece of the split tile - its raw fp32 sums are parked, nothing else happens;
+    // 2 = the closing piece - the parked sums join the accumulators before the epilogue
+    const int park_base = (int)blockIdx.x * 32 * GM_NTHR * 16;  // this workgroup's parked sums (<= 512 workgroups: launch_pp)
+    auto slice = [&](auto MH_, auto NH_, int tile, f32x4 be, f32x4 bo, int pmode = 0) {
         constexpr int MH = decltype(MH_)::value, NH = decltype(NH_)::value;
         if constexpr (EPI == GM_EPI_TOK) {
+            if (STAG && pmode) {
+                // parked sums: [workgroup][quadrant (MH, NH)][m 0..3][even | odd quad][thread] x 16 bytes; every thread re-reads its own
+                // (buffer-resource addressing: lane-constant offset tid * 16, everything else scalar)
+                const __amdgpu_buffer_rsrc_t rsP = make_rsrc(a.stagger);
+                const int pb = park_base + (MH * 2 + NH) * 8 * GM_NTHR * 16;
+                if (pmode == 1) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fg_u32x4, acc[MH * 4 + m][NH * 2]), rsP, tid * 16,
+                                                               __builtin_amdgcn_readfirstlane(pb + (2 * m) * GM_NTHR * 16), 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fg_u32x4, acc[MH * 4 + m][NH * 2 + 1]), rsP, tid * 16,
+                                                               __builtin_amdgcn_readfirstlane(pb + (2 * m + 1) * GM_NTHR * 16), 0);
+                        acc[MH * 4 + m][NH * 2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        acc[MH * 4 + m][NH * 2 + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    return;
+                }
+                f32x4 pe[4], po_[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    pe[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, tid * 16, __builtin_amdgcn_readfirstlane(pb + (2 * m) * GM_NTHR * 16), 0));
+                    po_[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, tid * 16, __builtin_amdgcn_readfirstlane(pb + (2 * m + 1) * GM_NTHR * 16), 0));
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[MH * 4 + m][NH * 2] += pe[m], acc[MH * 4 + m][NH * 2 + 1] += po_[m];
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (!GM_TIMING(a.act & 8)) {
                 const int m0 = ep_m0, n0 = ep_n0, mk = ep_mk, nk_ = ep_nk;  // (tile_origin / tile_keep_from of `tile`, computed once per tile)
                 const bool edge = (mk != m0) || (nk_ != n0);  // a shifted last tile: part of it is its neighbour's (uniform)
@@ -759,8 +790,6 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         if (t + 3 < S) cur_next(c2);
         ++t;
     };
-    // the parked partial sums of the first tile: [workgroup][accumulator quad 0 .. 31][thread] x 16 bytes (every thread re-reads its own)
-    float* const park = a.stagger ? a.stagger + (size_t)blockIdx.x * 32 * GM_NTHR * 4 + (size_t)tid * 4 : nullptr;
     for (int ti = 0; ti < items; ++ti) {
         stamp_tile = ti;
         stamp(0);
@@ -791,35 +820,14 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         // scripts/gemm_stamps.py: 14 800 of a K = 1152 tile's 70 000 cycles)
         if (wr == 0) asm volatile("s_barrier" ::: "memory");
         stamp(2);
-        if (parks) {
-#pragma unroll
-            for (int m = 0; m < 8; ++m)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    *reinterpret_cast<f32x4*>(park + (size_t)(m * 4 + nt) * GM_NTHR * 4) = acc[m][nt];
-                    acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            if (ksh && ti == my_tiles) {  // the closing piece: + the sums parked by the first one (this thread's own stores, long retired)
-#pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    f32x4 p4[4];
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) p4[nt] = *reinterpret_cast<const f32x4*>(park + (size_t)(m * 4 + nt) * GM_NTHR * 4);
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc[m][nt] += p4[nt];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            slice(I0{}, I0{}, ti, b00, b01);
-            stamp(4);
-            slice(I0{}, I1{}, ti, b10, b11);
-            stamp(5);
-            slice(I1{}, I1{}, ti, b10, b11);
-            stamp(6);
-            slice(I1{}, I0{}, ti, b00, b01);
-        }
+        const int pmode = parks ? 1 : (ksh && ti == my_tiles) ? 2 : 0;
+        slice(I0{}, I0{}, ti, b00, b01, pmode);
+        stamp(4);
+        slice(I0{}, I1{}, ti, b10, b11, pmode);
+        stamp(5);
+        slice(I1{}, I1{}, ti, b10, b11, pmode);
+        stamp(6);
+        slice(I1{}, I0{}, ti, b00, b01, pmode);
         stamp(3);
         advance();
     }
@@ -940,10 +948,10 @@ bool gm_env_stagger() {
     return on;
 }
 
-template <int EPI>
+template <int EPI, bool STAG = false>
 int launch_pp(const GemmArgs& a, hipStream_t s, bool prepare_only) {
     constexpr int LDS = 131072;
-    auto kern = gemm_bf16_pp_kernel<EPI>;
+    auto kern = gemm_bf16_pp_kernel<EPI, STAG>;
     const int dev = fg_device_slot();
     if (dev < 0) return (int)hipErrorInvalidDevice;
     static bool attr_done[16] = {};
@@ -974,9 +982,12 @@ int launch_pp(const GemmArgs& a, hipStream_t s, bool prepare_only) {
         if (a.xn <= 8 && (a.xn & (a.xn - 1)) == 0 && Nt % a.xn == 0 && a.xn != 1) xn = a.xn;
         b.xn = xn;
     }
-    // staggered tile boundaries (see the kernel): where every CU has at least three tiles of at least eight K-steps
-    b.stagger_on = (EPI == GM_EPI_TOK && a.stagger && (grid & 7) == 0 && grid <= 512 && b.ksplit <= 1 && (a.K / GM_KC) >= 8 && items >= 3LL * grid &&
-                    gm_env_stagger()) ? 1 : 0;
+    if (STAG) {
+        // staggered tile boundaries (see the kernel): where every CU has at least three tiles of at least eight K-steps
+        const bool ok = EPI == GM_EPI_TOK && a.stagger && (grid & 7) == 0 && grid <= 512 && b.ksplit <= 1 && (a.K / GM_KC) >= 8 && items >= 3LL * grid;
+        if (!ok) return launch_pp<EPI, false>(a, s, false);
+        b.stagger_on = 1;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(GM_NTHR), LDS, s, b);
     if (EPI == GM_EPI_RAW) {
         const int64_t n = (int64_t)a.M * (a.N / 8);
@@ -1032,7 +1043,7 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only) {
         int rc;
         if ((rc = launch_gm<4, GM_EPI_TOK>(a, s, true)) || (rc = launch_gm<3, GM_EPI_TOK>(a, s, true)) ||
             (rc = launch_gm<4, GM_EPI_HEADS>(a, s, true)) || (rc = launch_gm<3, GM_EPI_HEADS>(a, s, true)) ||
-            (rc = launch_pp<GM_EPI_TOK>(a, s, true)) || (rc = launch_pp<GM_EPI_HEADS>(a, s, true)) || (rc = launch_pp<GM_EPI_RAW>(a, s, true)) ||
+            (rc = launch_pp<GM_EPI_TOK>(a, s, true)) || (rc = launch_pp<GM_EPI_TOK, true>(a, s, true)) || (rc = launch_pp<GM_EPI_HEADS>(a, s, true)) || (rc = launch_pp<GM_EPI_RAW>(a, s, true)) ||
             (rc = launch_pp<GM_EPI_TOK32>(a, s, true)) || (rc = launch_pp<GM_EPI_SPLIT>(a, s, true)) || (rc = launch_pp<GM_EPI_HEADS32>(a, s, true)))
             return rc;
         return 0;
@@ -1064,7 +1075,8 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only) {
             if (rc3) return rc3;
             continue;
         }
-        const int rc = pp ? (heads ? launch_pp<GM_EPI_HEADS>(b, s, false) : launch_pp<GM_EPI_TOK>(b, s, false))
+        const bool stag = pp && !heads && a.stagger && rows_max >= a.M && gm_env_stagger();
+        const int rc = pp ? (heads ? launch_pp<GM_EPI_HEADS>(b, s, false) : stag ? launch_pp<GM_EPI_TOK, true>(b, s, false) : launch_pp<GM_EPI_TOK>(b, s, false))
                           : heads ? (n3 ? launch_gm<3, GM_EPI_HEADS>(b, s, false) : launch_gm<4, GM_EPI_HEADS>(b, s, false))
                                   : (n3 ? launch_gm<3, GM_EPI_TOK>(b, s, false) : launch_gm<4, GM_EPI_TOK>(b, s, false));
         if (rc) return rc;
