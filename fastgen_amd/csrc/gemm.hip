@@ -480,12 +480,15 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
                 // (buffer-resource addressing: lane-constant offset tid * 16, everything else scalar)
                 const __amdgpu_buffer_rsrc_t rsP = make_rsrc(a.stagger);
                 const int pb = park_base + (MH * 2 + NH) * 8 * GM_NTHR * 16;
+                int pt = tid;
+                asm volatile("" : "+v"(pt));
+                const int pv = pt * 16;
                 if (pmode == 1) {
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fg_u32x4, acc[MH * 4 + m][NH * 2]), rsP, tid * 16,
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fg_u32x4, acc[MH * 4 + m][NH * 2]), rsP, pv,
                                                                __builtin_amdgcn_readfirstlane(pb + (2 * m) * GM_NTHR * 16), 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fg_u32x4, acc[MH * 4 + m][NH * 2 + 1]), rsP, tid * 16,
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fg_u32x4, acc[MH * 4 + m][NH * 2 + 1]), rsP, pv,
                                                                __builtin_amdgcn_readfirstlane(pb + (2 * m + 1) * GM_NTHR * 16), 0);
                         acc[MH * 4 + m][NH * 2] = f32x4{0.f, 0.f, 0.f, 0.f};
                         acc[MH * 4 + m][NH * 2 + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -496,8 +499,8 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
                 f32x4 pe[4], po_[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    pe[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, tid * 16, __builtin_amdgcn_readfirstlane(pb + (2 * m) * GM_NTHR * 16), 0));
-                    po_[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, tid * 16, __builtin_amdgcn_readfirstlane(pb + (2 * m + 1) * GM_NTHR * 16), 0));
+                    pe[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, pv, __builtin_amdgcn_readfirstlane(pb + (2 * m) * GM_NTHR * 16), 0));
+                    po_[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, pv, __builtin_amdgcn_readfirstlane(pb + (2 * m + 1) * GM_NTHR * 16), 0));
                 }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc[MH * 4 + m][NH * 2] += pe[m], acc[MH * 4 + m][NH * 2 + 1] += po_[m];
@@ -515,11 +518,11 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
                     bnd = (gi0 + 1) * a.gate_rows - a.row0;  // first token (in this launch's rows) of the next gate period
                     const int gso = __builtin_amdgcn_readfirstlane((gi0 * a.gate_stride + n0 + 32 * NH) * 4);
                     g0e = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4, gso, 0));
-                    g0o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4 + 16, gso, 0));
+                    g0o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4, gso + 16, 0));
                     g1e = g0e, g1o = g0o;
                     if (bnd < m0 + GM_TM) {
                         g1e = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4, gso + a.gate_stride * 4, 0));
-                        g1o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4 + 16, gso + a.gate_stride * 4, 0));
+                        g1o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4, gso + a.gate_stride * 4 + 16, 0));
                     }
                 }
 #pragma unroll
@@ -806,12 +809,17 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         tile_keep_from(ti, ep_mk, ep_nk);
         const bool parks = ksh && ti == 0;  // (uniform) the first piece of the split tile: no epilogue, its sums are parked
         if (a.bias && EPI != GM_EPI_RAW && !parks) {
-            const int n0 = ep_n0;
-            const float* bp = a.bias + n0 + wc * 64 + 4 * g;
-            b00 = *reinterpret_cast<const f32x4*>(bp);
-            b01 = *reinterpret_cast<const f32x4*>(bp + 16);
-            b10 = *reinterpret_cast<const f32x4*>(bp + 32);
-            b11 = *reinterpret_cast<const f32x4*>(bp + 48);
+            // (buffer-resource addressing: a 64-bit per-lane pointer kept across the tile loop cost two spilled registers, and their reload
+            // here - a scratch load, waited for with vmcnt(0) - drained the DMA pipeline once per tile)
+            const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.bias);
+            const int bo_ = __builtin_amdgcn_readfirstlane((ep_n0 + wc * 64) * 4);
+            int ln = lane;  // (recomputed per tile from the lane id: hoisted out of the tile loop the four offsets are four more live registers)
+            asm volatile("" : "+v"(ln));
+            const int bl = (ln >> 4) * 16;
+            b00 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bl, bo_, 0));
+            b01 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bl, bo_ + 64, 0));
+            b10 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bl, bo_ + 128, 0));
+            b11 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bl, bo_ + 192, 0));
         }
         kstep(t, len - 1);
         tr_m0 = ep_m0, tr_n0 = ep_n0;
