@@ -1263,9 +1263,9 @@ int fg_op_attention(const void* q, const void* k, const void* v, void* out, int 
 int fg_op_gemm_bf16(const void* a, const void* w, const float* bias, void* out, int m, int n, int k, int act, const float* gate,
                     int gate_stride, int gate_rows, const void* resid, int tile_order, void* stream) {
 #ifdef FG_TIMING_BUILD
-    const int act_ok = 1 | 4 | 8 | 32 | 64, order_ok = 511;  // + act 4 / 8: no stores / no epilogue; tile_order 128: cycle stamps (gemm.hip, GM_TIMING)
+    const int act_ok = 1 | 4 | 8, order_ok = 255;  // + act 4 / 8: no stores / no epilogue; tile_order 128: cycle stamps (gemm.hip, GM_TIMING)
 #else
-    const int act_ok = 1, order_ok = 127 | 256;
+    const int act_ok = 1, order_ok = 127;
 #endif
     if (act < 0 || (act & ~act_ok)) return fail(FG_EINVAL, "fg_op_gemm_bf16: act must be 0 (none) or 1 (GELU tanh), got %d", act);
     if (tile_order < 0 || (tile_order & ~order_ok)) return fail(FG_EINVAL, "fg_op_gemm_bf16: bad tile_order %d", tile_order);
@@ -1289,20 +1289,10 @@ int fg_op_gemm_bf16(const void* a, const void* w, const float* bias, void* out, 
         g.act |= 16;
     }
 #endif
-    if ((tile_order & 64) && (tile_order & 256)) return fail(FG_EINVAL, "fg_op_gemm_bf16: tile_order bits 64 and 256 exclude each other");
     if (tile_order & 64) {  // let short grids split K
         g.scratch_bytes = (size_t)4 * m * n * 4;
         herr = hipMalloc(&scratch, g.scratch_bytes);
         g.scratch = (float*)scratch;
-    }
-    if (tile_order & 256) {  // let long grids stagger their tile boundaries (what the networks run, out of their workspaces)
-        // one buffer per device, kept for the life of the process: scripts/gemm_bench.py times back-to-back calls of this entry point,
-        // and an allocation + stream drain per call would sit inside its timed region
-        static void* parked[16] = {};
-        const int dev = fg_device_slot();
-        if (dev < 0) return fail(FG_EHIP, "no current device");
-        if (!parked[dev]) HIP_TRY(hipMalloc(&parked[dev], GM_STAGGER_BYTES));
-        g.stagger = (float*)parked[dev];
     }
     int rc = herr == hipSuccess ? launch_gemm_bf16(g, (hipStream_t)stream) : (int)herr;
     if (scratch) {

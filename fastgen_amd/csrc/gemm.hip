@@ -286,7 +286,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_kernel(const GemmArgs a) {
 #endif
 #define GM_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
-template <int EPI, bool STAG = false>
+template <int EPI>
 __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a) {
     constexpr int TN = 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -321,34 +321,21 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
     count *= ks;
     const int my_tiles = first < count ? (count - first + stride - 1) / stride : 0;  // work items of this workgroup
     if (my_tiles == 0) return;
-    const int nk = (a.K / GM_KC) / ks;  // K-steps per work item
-    // ---- stagger: every workgroup's tiles take the same time, so left alone all 256 CUs end their tiles together and their stores - 32 MB
-    // per round of tiles - hit HBM as one burst that nothing overlaps: the wave's own next loads queue behind its stores (vmcnt retires
-    // in order).  At K = 1152 that burst is a fifth of the kernel's time (scripts/gemm_exp.py: timing builds without the stores; and with
-    // XCD x started x / 8 of a tile late: the cost is gone, traded for the idle start).  Here the offset costs nothing: a workgroup on XCD x
-    // (blockIdx.x & 7: the workgroups of one XCD stay in lockstep - they share A rows and W columns through their L2) first walks the
-    // K-steps [ksh, nk) of its first tile, ksh = x nk / 8, parks those partial sums in fp32 scratch, walks its other tiles whole, and ends
-    // with the K-steps [0, ksh) of the first tile, added to the parked sums.  The XCDs' tile ends are nk / 8 K-steps apart.
-    // item i -> tile: i < my_tiles: tile i; i == my_tiles (the closing piece): tile 0.
-    const int ksh = (STAG && EPI == GM_EPI_TOK && my_tiles >= 2) ? (((int)blockIdx.x & 7) * nk) / 8 : 0;  // (a kernel of its own: the launcher's stagger_on)
-    const int items = my_tiles + (ksh ? 1 : 0);
-    auto item_tile = [&](int i) { return i >= my_tiles ? (ksh ? 0 : my_tiles - 1) : i; };  // (cursors running past the end re-read a valid tile)
-    auto item_kbegin = [&](int i) { return i == 0 ? ksh : 0; };
-    auto item_kend = [&](int i) { return (ksh && i >= my_tiles) ? ksh : nk; };
     auto tile_origin = [&](int i, int& m0, int& n0) {
-        const int lt = (first + item_tile(i) * stride) / ks;
+        const int lt = (first + min(i, my_tiles - 1) * stride) / ks;  // (cursors running past the end re-read the last tile)
         const int q = lt / nx;
         m0 = min((mlo + q) * GM_TM, a.M - GM_TM);
         n0 = min((nlo + (lt - q * nx)) * TN, a.N - TN);
     };
-    auto item_split = [&](int i) { return (first + item_tile(i) * stride) % ks; };
+    auto item_split = [&](int i) { return (first + min(i, my_tiles - 1) * stride) % ks; };
     // where the tile would start without the shift: rows / columns below are the neighbour tile's and are not stored again
     auto tile_keep_from = [&](int i, int& mk, int& nk_) {
-        const int lt = (first + item_tile(i) * stride) / ks;
+        const int lt = (first + min(i, my_tiles - 1) * stride) / ks;
         const int q = lt / nx;
         mk = (mlo + q) * GM_TM;
         nk_ = (nlo + (lt - q * nx)) * TN;
     };
+    const int nk = (a.K / GM_KC) / ks;  // K-steps per work item
     const int S = my_tiles * nk;
     // row pitches in bytes (split-bf16 flavour: A rows hold [hi | lo] = 2 K1 elements, W rows [hi | lo | hi] = 3 K1 = K elements)
     const int KA2 = (a.lda ? a.lda : a.K) * 2, KW2 = (a.ldw ? a.ldw : a.K) * 2;
@@ -391,7 +378,7 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         c.sw = __builtin_amdgcn_readfirstlane(n0 * KW2 + ks_ * (GM_KC * 2));
     };
     auto cur_next = [&](Cur& c) {
-        if (++c.kk >= item_kend(c.ti)) ++c.ti, c.kk = 0;  // (items behind the first begin at K-step 0)
+        if (++c.kk == nk) c.kk = 0, ++c.ti;
         cur_set(c);
     };
 
@@ -441,10 +428,6 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto mem_done5 = [&]() {  // (timing build: a phase that also issued one trickled store)
-        asm volatile("s_waitcnt vmcnt(5)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
     auto cmp_done = [&]() {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_barrier" ::: "memory");
@@ -469,43 +452,9 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
     const int vo_out = ((wr * 128 + col) * a.N + lane_c8) * 2;
     const __amdgpu_buffer_rsrc_t rsO = make_rsrc(a.out), rsR = make_rsrc(a.resid), rsG = make_rsrc(a.gate);
     // (gate periods >= the tile height: a tile then spans at most two gate rows; launch_gemm_bf16 sends shorter ones to gemm_bf16_kernel)
-    // pmode (uniform; stagger only): 1 = the first piece of the split tile - its raw fp32 sums are parked, nothing else happens;
-    // 2 = the closing piece - the parked sums join the accumulators before the epilogue
-    const int park_base = (int)blockIdx.x * 32 * GM_NTHR * 16;  // this workgroup's parked sums (<= 512 workgroups: launch_pp)
-    auto slice = [&](auto MH_, auto NH_, int tile, f32x4 be, f32x4 bo, int pmode = 0) {
+    auto slice = [&](auto MH_, auto NH_, int tile, f32x4 be, f32x4 bo) {
         constexpr int MH = decltype(MH_)::value, NH = decltype(NH_)::value;
         if constexpr (EPI == GM_EPI_TOK) {
-            if (STAG && pmode) {
-                // parked sums: [workgroup][quadrant (MH, NH)][m 0..3][even | odd quad][thread] x 16 bytes; every thread re-reads its own
-                // (buffer-resource addressing: lane-constant offset tid * 16, everything else scalar)
-                const __amdgpu_buffer_rsrc_t rsP = make_rsrc(a.stagger);
-                const int pb = park_base + (MH * 2 + NH) * 8 * GM_NTHR * 16;
-                int pt = tid;
-                asm volatile("" : "+v"(pt));
-                const int pv = pt * 16;
-                if (pmode == 1) {
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fg_u32x4, acc[MH * 4 + m][NH * 2]), rsP, pv,
-                                                               __builtin_amdgcn_readfirstlane(pb + (2 * m) * GM_NTHR * 16), 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fg_u32x4, acc[MH * 4 + m][NH * 2 + 1]), rsP, pv,
-                                                               __builtin_amdgcn_readfirstlane(pb + (2 * m + 1) * GM_NTHR * 16), 0);
-                        acc[MH * 4 + m][NH * 2] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        acc[MH * 4 + m][NH * 2 + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    return;
-                }
-                f32x4 pe[4], po_[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    pe[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, pv, __builtin_amdgcn_readfirstlane(pb + (2 * m) * GM_NTHR * 16), 0));
-                    po_[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, pv, __builtin_amdgcn_readfirstlane(pb + (2 * m + 1) * GM_NTHR * 16), 0));
-                }
-#pragma unroll
-                for (int m = 0; m < 4; ++m) acc[MH * 4 + m][NH * 2] += pe[m], acc[MH * 4 + m][NH * 2 + 1] += po_[m];
-                __builtin_amdgcn_sched_barrier(0);
-            }
             if (!GM_TIMING(a.act & 8)) {
                 const int m0 = ep_m0, n0 = ep_n0, mk = ep_mk, nk_ = ep_nk;  // (tile_origin / tile_keep_from of `tile`, computed once per tile)
                 const bool edge = (mk != m0) || (nk_ != n0);  // a shifted last tile: part of it is its neighbour's (uniform)
@@ -710,14 +659,9 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
 
-    if (GM_TIMING(a.act & 64)) {  // (timing build) XCD x starts x / 8 of a tile's time late: do the XCDs' store bursts, apart, cost less?
-        const long long wait = (long long)((int)blockIdx.x & 7) * (long long)(a.K / GM_KC) * 3400 / 8;
-        const long long t0 = (long long)__builtin_readcyclecounter();
-        while ((long long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-    }
     // ---- prologue: K-step 0 whole, the two early half-tiles of K-step 1 ------------------------------------------------
-    Cur c1{0, item_kbegin(0), 0, 0}, c2{0, 0, 0, 0};
-    cur_set(c1);                 // = the first K-step for now
+    Cur c1{0, 0, 0, 0}, c2{0, 0, 0, 0};
+    cur_set(c1);                 // = K-step 0 for now
     dmaA(0, c1.sa);
     dmaA(16384, c1.sa + 128 * KA2);
     dmaW(32768, c1.sw);
@@ -734,23 +678,12 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
     if (wr == 1) asm volatile("s_barrier" ::: "memory");  // the second group runs one barrier behind
 
     // one K-step = four phases
-    int tr_m0 = 0, tr_n0 = 0;  // (timing build, act bit 32: origin of the tile whose outputs are trickled out during this tile's K-loop)
-    auto kstep = [&](int t, int kk) {
+    auto kstep = [&](int t) {
         const int cb = t & 1, nb = cb ^ 1;
         // phase 0: quadrant (0,0)
         read_w(W0, cb, 0);
-        bool trickled = false;
-        if constexpr (EPI == GM_EPI_TOK) {
-            if (GM_TIMING((a.act & 32) && kk < 16)) {
-                // experiment: is a store issued here, one per K-step, hidden behind the loop?  (X1's registers: free until phase 2)
-                const int so = __builtin_amdgcn_readfirstlane(((tr_m0 + (kk & 7) * 16) * a.N + tr_n0 + 32 * (kk >> 3)) * 2);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fg_u32x4, X1[0][0]), make_rsrc(a.out), ((wr * 128 + col) * a.N + wc * 64 + 16 * (g & 1) + 8 * (g >> 1)) * 2, so, 0);
-                trickled = true;
-            }
-        }
         dmaA(nb * 65536 + 16384, c1.sa + 128 * KA2);
-        if (trickled) mem_done5();
-        else mem_done();
+        mem_done();
         __builtin_amdgcn_s_setprio(1);
         mma(0, 0, X0, W0);
         __builtin_amdgcn_s_setprio(0);
@@ -793,13 +726,12 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         if (t + 3 < S) cur_next(c2);
         ++t;
     };
-    for (int ti = 0; ti < items; ++ti) {
+    for (int ti = 0; ti < my_tiles; ++ti) {
         stamp_tile = ti;
         stamp(0);
         if (ti > 0 && wr == 1) asm volatile("s_barrier" ::: "memory");  // the second group falls one barrier behind again
-        const int len = item_kend(ti) - item_kbegin(ti);
-        for (int kk = 0; kk + 1 < len; ++kk) {
-            kstep(t, kk);
+        for (int kk = 0; kk + 1 < nk; ++kk) {
+            kstep(t);
             advance();
         }
         stamp(1);
@@ -807,13 +739,13 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
         f32x4 b00 = {0.f, 0.f, 0.f, 0.f}, b01 = b00, b10 = b00, b11 = b00;
         tile_origin(ti, ep_m0, ep_n0);
         tile_keep_from(ti, ep_mk, ep_nk);
-        const bool parks = ksh && ti == 0;  // (uniform) the first piece of the split tile: no epilogue, its sums are parked
-        if (a.bias && EPI != GM_EPI_RAW && !parks) {
-            // (buffer-resource addressing: a 64-bit per-lane pointer kept across the tile loop cost two spilled registers, and their reload
-            // here - a scratch load, waited for with vmcnt(0) - drained the DMA pipeline once per tile)
+        if (a.bias && EPI != GM_EPI_RAW) {
+            // (buffer-resource addressing, one lane-constant register + scalar offsets: as a 64-bit per-lane pointer kept across the tile
+            // loop this cost spilled registers in the head-split / fp32-output instantiations, and their reload here - a scratch load,
+            // waited for with vmcnt(0) - drained the DMA pipeline once per tile)
             const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.bias);
             const int bo_ = __builtin_amdgcn_readfirstlane((ep_n0 + wc * 64) * 4);
-            int ln = lane;  // (recomputed per tile from the lane id: hoisted out of the tile loop the four offsets are four more live registers)
+            int ln = lane;
             asm volatile("" : "+v"(ln));
             const int bl = (ln >> 4) * 16;
             b00 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bl, bo_, 0));
@@ -821,21 +753,19 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
             b10 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bl, bo_ + 128, 0));
             b11 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bl, bo_ + 192, 0));
         }
-        kstep(t, len - 1);
-        tr_m0 = ep_m0, tr_n0 = ep_n0;
+        kstep(t);
         // the groups meet before the epilogue (the first one waits out the second's last compute part) and run it side by side:
         // one barrier apart, each group's 7 000-cycle epilogue stalled the other at its next barrier (cycle stamps,
         // scripts/gemm_stamps.py: 14 800 of a K = 1152 tile's 70 000 cycles)
         if (wr == 0) asm volatile("s_barrier" ::: "memory");
         stamp(2);
-        const int pmode = parks ? 1 : (ksh && ti == my_tiles) ? 2 : 0;
-        slice(I0{}, I0{}, ti, b00, b01, pmode);
+        slice(I0{}, I0{}, ti, b00, b01);
         stamp(4);
-        slice(I0{}, I1{}, ti, b10, b11, pmode);
+        slice(I0{}, I1{}, ti, b10, b11);
         stamp(5);
-        slice(I1{}, I1{}, ti, b10, b11, pmode);
+        slice(I1{}, I1{}, ti, b10, b11);
         stamp(6);
-        slice(I1{}, I0{}, ti, b00, b01, pmode);
+        slice(I1{}, I0{}, ti, b00, b01);
         stamp(3);
         advance();
     }
@@ -947,19 +877,10 @@ int launch_gm(const GemmArgs& a, hipStream_t s, bool prepare_only) {
     return (int)hipGetLastError();
 }
 
-// FASTGEN_AMD_GEMM_STAGGER=0 keeps every workgroup on whole tiles (A/B measurements; results are the same sums in another order)
-bool gm_env_stagger() {
-    static const bool on = [] {
-        const char* e = getenv("FASTGEN_AMD_GEMM_STAGGER");
-        return !(e && e[0] == '0');
-    }();
-    return on;
-}
-
-template <int EPI, bool STAG = false>
+template <int EPI>
 int launch_pp(const GemmArgs& a, hipStream_t s, bool prepare_only) {
     constexpr int LDS = 131072;
-    auto kern = gemm_bf16_pp_kernel<EPI, STAG>;
+    auto kern = gemm_bf16_pp_kernel<EPI>;
     const int dev = fg_device_slot();
     if (dev < 0) return (int)hipErrorInvalidDevice;
     static bool attr_done[16] = {};
@@ -989,12 +910,6 @@ int launch_pp(const GemmArgs& a, hipStream_t s, bool prepare_only) {
             }
         if (a.xn <= 8 && (a.xn & (a.xn - 1)) == 0 && Nt % a.xn == 0 && a.xn != 1) xn = a.xn;
         b.xn = xn;
-    }
-    if (STAG) {
-        // staggered tile boundaries (see the kernel): where every CU has at least three tiles of at least eight K-steps
-        const bool ok = EPI == GM_EPI_TOK && a.stagger && (grid & 7) == 0 && grid <= 512 && b.ksplit <= 1 && (a.K / GM_KC) >= 8 && items >= 3LL * grid;
-        if (!ok) return launch_pp<EPI, false>(a, s, false);
-        b.stagger_on = 1;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(GM_NTHR), LDS, s, b);
     if (EPI == GM_EPI_RAW) {
@@ -1051,7 +966,7 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only) {
         int rc;
         if ((rc = launch_gm<4, GM_EPI_TOK>(a, s, true)) || (rc = launch_gm<3, GM_EPI_TOK>(a, s, true)) ||
             (rc = launch_gm<4, GM_EPI_HEADS>(a, s, true)) || (rc = launch_gm<3, GM_EPI_HEADS>(a, s, true)) ||
-            (rc = launch_pp<GM_EPI_TOK>(a, s, true)) || (rc = launch_pp<GM_EPI_TOK, true>(a, s, true)) || (rc = launch_pp<GM_EPI_HEADS>(a, s, true)) || (rc = launch_pp<GM_EPI_RAW>(a, s, true)) ||
+            (rc = launch_pp<GM_EPI_TOK>(a, s, true)) || (rc = launch_pp<GM_EPI_HEADS>(a, s, true)) || (rc = launch_pp<GM_EPI_RAW>(a, s, true)) ||
             (rc = launch_pp<GM_EPI_TOK32>(a, s, true)) || (rc = launch_pp<GM_EPI_SPLIT>(a, s, true)) || (rc = launch_pp<GM_EPI_HEADS32>(a, s, true)))
             return rc;
         return 0;
@@ -1083,8 +998,7 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only) {
             if (rc3) return rc3;
             continue;
         }
-        const bool stag = pp && !heads && a.stagger && rows_max >= a.M && gm_env_stagger();
-        const int rc = pp ? (heads ? launch_pp<GM_EPI_HEADS>(b, s, false) : stag ? launch_pp<GM_EPI_TOK, true>(b, s, false) : launch_pp<GM_EPI_TOK>(b, s, false))
+        const int rc = pp ? (heads ? launch_pp<GM_EPI_HEADS>(b, s, false) : launch_pp<GM_EPI_TOK>(b, s, false))
                           : heads ? (n3 ? launch_gm<3, GM_EPI_HEADS>(b, s, false) : launch_gm<4, GM_EPI_HEADS>(b, s, false))
                                   : (n3 ? launch_gm<3, GM_EPI_TOK>(b, s, false) : launch_gm<4, GM_EPI_TOK>(b, s, false));
         if (rc) return rc;

@@ -165,16 +165,10 @@ struct GemmArgs {
     float* scratch = nullptr;     // optional fp32 scratch for split-K partial sums (short grids; see gemm.hip gm_pick_ksplit)
     size_t scratch_bytes = 0;
     int ksplit = 1;               // set by the launcher
-    // Staggered tile boundaries (gemm.hip, "stagger"): optional fp32 scratch of GM_STAGGER_BYTES where a workgroup parks the partial sums
-    // of its first tile, whose K range it splits around its other tiles so that the eight XCDs reach their tile ends - their store
-    // bursts - an eighth of a tile apart.  nullptr: every workgroup walks whole tiles in lockstep.
-    float* stagger = nullptr;
-    int stagger_on = 0;           // set by the launcher
     int out_f32 = 0;              // 1: out (and resid) fp32 [M][N] instead of bf16 (ping-pong kernel only: M, N >= 256)
     int variant = -1;  // -1: default (env FASTGEN_AMD_GEMM_PP, 1 unless set to 0); 0 register-staged kernel; 1 LDS-DMA ping-pong kernel
     int xn = 1;    // 0: linear tile order; 1: XCD-aware order, split chosen by the launcher; 2 / 4 / 8: that many XCD columns over N
 };
-constexpr size_t GM_STAGGER_BYTES = (size_t)512 * 512 * 128 * 4;  // (up to 512 workgroups - one per CU - x 512 threads x 128 accumulators: 128 MiB)
 bool gemm_bf16_supported(const GemmArgs& a);
 int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only = false);
 int launch_cvt_bf16(const float* in, void* out, size_t n, hipStream_t s);

@@ -9,7 +9,7 @@ import torch
 from fastgen_amd import _lib
 
 M = next((int(a) for a in sys.argv[1:] if not a.startswith("--")), 65536)
-ORDERS = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--order=")] or [16 + 1, 32 + 1, 256 + 32 + 1]  # register-staged | LDS-DMA ping-pong | + staggered tile boundaries (what the networks run)
+ORDERS = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--order=")] or [16 + 1, 32 + 1]
 L = _lib.lib()
 p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

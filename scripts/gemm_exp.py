@@ -17,7 +17,7 @@ for name, n, k in [("qkv-like", 3456, 1152), ("n=3584 (14 full tiles)", 3584, 11
     w = (torch.randn(n, k, device="cuda") * k ** -0.5).bfloat16()
     bias = torch.randn(n, device="cuda")
     out = torch.empty(M, n, dtype=torch.bfloat16, device="cuda")
-    for act in (0, 64, 4, 8):  # 64: XCD x starts x / 8 of a tile late (store bursts of the XCDs apart)
+    for act in (0, 4, 8):
         for order in (32 + 1,):
             run = lambda: _lib.check(L.fg_op_gemm_bf16(p(a), p(w), p(bias), p(out), M, n, k, act, None, 0, 1, None, order, st))
             for _ in range(3):

@@ -100,29 +100,6 @@ def test_split_k_on_short_grids(m, n, k):
     assert (got.float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-3
 
 
-@pytest.mark.parametrize("m,n,k", [(16384 + 77, 3456, 1152), (32768, 1152, 1152), (16384, 1536, 8960)])
-def test_staggered_tile_boundaries(m, n, k):
-    """tile_order bit 256 (the networks' setting for long token counts): a workgroup on XCD x splits the K range of its first tile around
-    its other tiles and parks the partial sums in fp32 scratch, so that the XCDs' store bursts fall apart (gemm.hip, "stagger").  Same
-    sums in another order: one bf16 ulp against fp32 matmul, every epilogue, ragged token / output counts, in place."""
-    g = torch.Generator().manual_seed(m + n)
-    a = torch.randn(m, k, generator=g).bfloat16().cuda()
-    w = (torch.randn(n, k, generator=g) * k ** -0.5).bfloat16().cuda()
-    bias = torch.randn(n, generator=g).cuda()
-    rows = 256
-    gate = torch.randn((m + rows - 1) // rows, n, generator=g).cuda()
-    resid = torch.randn(m, n, generator=g).bfloat16().cuda()
-    want = _ref(a, w, bias, gate=gate, gate_rows=rows, resid=resid)
-    got = _run(a, w, bias, gate=gate, gate_rows=rows, resid=resid, order=256 + 32 + 1)
-    assert torch.isfinite(got.float()).all()
-    assert (got.float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-3
-    assert torch.equal(got, _run(a, w, bias, gate=gate, gate_rows=rows, resid=resid, order=256 + 32 + 1))  # fixed order: bit-identical
-    del want, got
-    want = _ref(a, w, bias, act=1)
-    got = _run(a, w, bias, act=1, order=256 + 32 + 1)
-    assert (got.float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-3
-
-
 def test_unsupported_shapes_are_refused():
     from fastgen_amd import _lib
 
@@ -137,7 +114,7 @@ def test_unsupported_shapes_are_refused():
     for act in (2, 4, 8, 16, 5, -1):
         with pytest.raises(_lib.FastGenAMDError, match="act must be"):
             _run(a, w, act=act)
-    for order in (128, 128 + 33, 16 + 32, 512, 64 + 256):
+    for order in (128, 128 + 33, 16 + 32, 256):
         with pytest.raises(_lib.FastGenAMDError, match="tile_order"):
             _run(a, w, order=order)
     assert torch.equal(_run(a, w, act=1), torch.zeros(256, 256, dtype=torch.bfloat16, device="cuda"))
