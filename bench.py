@@ -39,7 +39,7 @@ DOMINANT_KERNEL = {
 # how the JSON line names the arithmetic: bf16x3 is the fp32-grade mode (fp32 tensors and accumulation, every conv product from
 # hi/lo-split operands on the bf16 matrix pipe, held to the exact-fp32 parity tolerance in tests/test_gpu_parity.py)
 DTYPE_LABEL = {"bf16x3": "fp32 (tensors, accumulate) with split-bf16 x3 MFMA conv products", "fp32": "fp32", "bf16": "bf16"}
-TRAFFIC_FILE = {"bf16x3": "r02_x3d_pmc_dominant_kernel.json", "bf16": "r01_ws_pmc_dominant_kernel.json", "fp32": "none"}
+TRAFFIC_FILE = {"bf16x3": "r03_x3_pmc_dominant_kernel.json", "bf16": "r01_ws_pmc_dominant_kernel.json", "fp32": "none"}
 EDM_CIFAR10 = dict(img_resolution=32, img_channels=3, label_dim=10, sigma_shift=0.0, sigma_data=0.5,
                    model_type="SongUNet", augment_dim=9, model_channels=128, channel_mult=[2, 2, 2],
                    channel_mult_noise=1, embedding_type="positional", encoder_type="standard",

@@ -772,6 +772,274 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may land in an LDS allocation this workgroup has given up
 }
 
+// ---- the narrow tile: 256 tokens x 128 outputs, for SHORT token counts ---------------------------------------------------------
+// One sample of the causal video DiT hands the block linears M = 4 680 tokens (a chunk of 3 latent frames): 19 token tiles.  With
+// 256-wide tiles N = 1 536 gives 114 tiles for 256 CUs; the kernel above then cuts K in two (fp32 partial sums through HBM + a finishing
+// pass: 67 us for 22 GFLOP = 330 TFLOP/s for the attention-output and cross-attention projections), and at N = 4 608 it runs two rounds of
+// 342 tiles at two thirds occupancy.  With 128-wide tiles the same shapes are 228 / 684 work items and need neither.
+// Same ping-pong structure (8 waves = 2 token halves x 4 output eighths of 32, waves 4-7 one barrier behind), but a wave's 128 x 32
+// outputs are TWO quadrants of 16 MFMAs, so a K-step is two phases, and the 48 KiB stage (A rows 0-127 | A rows 128-255 | W) sits in a
+// ring of THREE: the DMA of K-step t + 2 goes into the buffer K-step t - 1 left.
+//   phase 0: read W(t), X(t) m 4-7       issue A (both halves) of t+2      16 MFMAs: m 0-3
+//   phase 1: read X(t+1) m 0-3           issue W of t+2                    16 MFMAs: m 4-7
+// Every memory part ends with vmcnt(6): behind the half-tile that the NEXT phase reads, a wave has issued exactly six younger pieces
+// (A: 4 per wave and K-step, W: 2).  LDS reads per MFMA are 1.7 x the wide tile's (20 fragments per 32 MFMAs): about 60 % of the LDS
+// bandwidth at the MFMA roof - the price of the narrow tile, paid only where the wide one leaves CUs idle.
+__global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp2_kernel(const GemmArgs a) {
+    constexpr int TN = 128;
+    constexpr int BUFB = 49152;  // bytes per stage: A rows 0-127 at 0, A rows 128-255 at 16384, W at 32768
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;  // token half (= ping-pong group), output eighth (32 outputs)
+    const int col = lane & 15, g = lane >> 4;
+
+    // ---- this workgroup's tiles (as gemm_bf16_pp_kernel) ----------------------------------------------------------------
+    const int Mt = (a.M + GM_TM - 1) / GM_TM, Nt = (a.N + TN - 1) / TN;
+    int mlo = 0, nlo = 0, nx = Nt, first, stride, count;
+    if ((gridDim.x & 7) == 0 && a.xn > 0) {
+        const int x = (int)blockIdx.x & 7, xm = 8 / a.xn, xi = x / a.xn, xj = x - xi * a.xn;
+        mlo = (int)((long long)xi * Mt / xm);
+        const int mhi = (int)((long long)(xi + 1) * Mt / xm);
+        nlo = xj * Nt / a.xn;
+        nx = (xj + 1) * Nt / a.xn - nlo;
+        first = (int)blockIdx.x >> 3;
+        stride = (int)gridDim.x >> 3;
+        count = (mhi - mlo) * nx;
+    } else {
+        first = (int)blockIdx.x;
+        stride = (int)gridDim.x;
+        count = Mt * Nt;
+    }
+    const int my_tiles = first < count ? (count - first + stride - 1) / stride : 0;
+    if (my_tiles == 0) return;
+    auto tile_origin = [&](int i, int& m0, int& n0) {
+        const int lt = first + min(i, my_tiles - 1) * stride;  // (cursors running past the end re-read the last tile)
+        const int q = lt / nx;
+        m0 = min((mlo + q) * GM_TM, a.M - GM_TM);
+        n0 = min((nlo + (lt - q * nx)) * TN, a.N - TN);
+    };
+    auto tile_keep_from = [&](int i, int& mk, int& nk_) {
+        const int lt = first + min(i, my_tiles - 1) * stride;
+        const int q = lt / nx;
+        mk = (mlo + q) * GM_TM;
+        nk_ = (nlo + (lt - q * nx)) * TN;
+    };
+    const int nk = a.K / GM_KC;
+    const int S = my_tiles * nk;
+    const int KA2 = a.K * 2, KW2 = a.K * 2;
+    // ---- DMA: wave w moves the 8-row groups 2 w, 2 w + 1 of every 128-row half-tile (see gemm_bf16_pp_kernel) -------------------
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.A), rsW = make_rsrc(a.W);
+    unsigned voffA[2], voffW[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 8 + (lane >> 3);
+        const unsigned sw = (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+        voffA[j] = (unsigned)row * (unsigned)KA2 + sw;
+        voffW[j] = (unsigned)row * (unsigned)KW2 + sw;
+    }
+    auto dmaA = [&](int region, int soff) {
+        const int so = __builtin_amdgcn_readfirstlane(soff);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(smem + region + (wave * 2 + j) * 1024), 16, voffA[j], so, 0, 0);
+    };
+    auto dmaW = [&](int region, int soff) {
+        const int so = __builtin_amdgcn_readfirstlane(soff);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(smem + region + (wave * 2 + j) * 1024), 16, voffW[j], so, 0, 0);
+    };
+    struct Cur {
+        int ti, kk, sa, sw;
+    };
+    auto cur_set = [&](Cur& c) {
+        int m0, n0;
+        tile_origin(c.ti, m0, n0);
+        c.sa = __builtin_amdgcn_readfirstlane(m0 * KA2 + c.kk * (GM_KC * 2));
+        c.sw = __builtin_amdgcn_readfirstlane(n0 * KW2 + c.kk * (GM_KC * 2));
+    };
+    auto cur_next = [&](Cur& c) {
+        if (++c.kk == nk) c.kk = 0, ++c.ti;
+        cur_set(c);
+    };
+    auto stage = [&](int buf, const Cur& c, int what) {  // what: 1 = A (both halves), 2 = W, 3 = both
+        if (what & 1) {
+            dmaA(buf * BUFB, c.sa);
+            dmaA(buf * BUFB + 16384, c.sa + 128 * KA2);
+        }
+        if (what & 2) dmaW(buf * BUFB + 32768, c.sw);
+    };
+
+    // ---- fragments --------------------------------------------------------------------------------------------------------
+    const int lrow0 = col * 128 + ((g ^ ((col >> 1) & 7)) * 16), lrow1 = lrow0 ^ 64;  // k-substep 0 / 1
+    const int fxa = wr * 16384;         // this wave's A half
+    const int fwb = 32768 + wc * 4096;  // this wave's 32 W rows
+    bf16x8 X0[4][2], X1[4][2], W0[2][2];  // [m | nt][k-substep]
+    f32x4 acc[8][2];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto read_x = [&](bf16x8 (&x)[4][2], int bufoff, int mh) {
+        const int a0 = bufoff + fxa + lrow0, a1 = bufoff + fxa + lrow1;
+        if (mh == 0) {
+            GM_DSR(x[0][0], a0, 0); GM_DSR(x[0][1], a1, 0); GM_DSR(x[1][0], a0, 2048); GM_DSR(x[1][1], a1, 2048);
+            GM_DSR(x[2][0], a0, 4096); GM_DSR(x[2][1], a1, 4096); GM_DSR(x[3][0], a0, 6144); GM_DSR(x[3][1], a1, 6144);
+        } else {
+            GM_DSR(x[0][0], a0, 8192); GM_DSR(x[0][1], a1, 8192); GM_DSR(x[1][0], a0, 10240); GM_DSR(x[1][1], a1, 10240);
+            GM_DSR(x[2][0], a0, 12288); GM_DSR(x[2][1], a1, 12288); GM_DSR(x[3][0], a0, 14336); GM_DSR(x[3][1], a1, 14336);
+        }
+    };
+    auto read_w = [&](bf16x8 (&w)[2][2], int bufoff) {
+        const int a0 = bufoff + fwb + lrow0, a1 = bufoff + fwb + lrow1;
+        GM_DSR(w[0][0], a0, 0); GM_DSR(w[0][1], a1, 0); GM_DSR(w[1][0], a0, 2048); GM_DSR(w[1][1], a1, 2048);
+    };
+    auto mma = [&](int mh, const bf16x8 (&x)[4][2], const bf16x8 (&w)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mh * 4 + m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt][j], x[m][j], acc[mh * 4 + m][nt], 0, 0, 0);
+    };
+    auto mem_done = [&]() {
+        asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto cmp_done = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+    };
+
+    // ---- token epilogue of one half (MH: 64 tokens x 32 outputs of this wave), as gemm_bf16_pp_kernel's -----------------------------
+    int ep_m0 = 0, ep_n0 = 0, ep_mk = 0, ep_nk = 0;
+    const int lane_c8 = wc * 32 + 16 * (g & 1) + 8 * (g >> 1);
+    const int vo_out = ((wr * 128 + col) * a.N + lane_c8) * 2;
+    const __amdgpu_buffer_rsrc_t rsO = make_rsrc(a.out), rsR = make_rsrc(a.resid), rsG = make_rsrc(a.gate);
+    auto slice = [&](auto MH_, f32x4 be, f32x4 bo) {
+        constexpr int MH = decltype(MH_)::value;
+        const int m0 = ep_m0, n0 = ep_n0, mk = ep_mk, nk_ = ep_nk;
+        const bool edge = (mk != m0) || (nk_ != n0);  // a shifted last tile: part of it is its neighbour's (uniform)
+        const int c8 = n0 + lane_c8;
+        f32x4 g0e = {1.f, 1.f, 1.f, 1.f}, g0o = g0e, g1e = g0e, g1o = g0e;
+        int bnd = 0x7fffffff;
+        if (a.gate) {
+            const int gi0 = (a.row0 + m0) / a.gate_rows;
+            bnd = (gi0 + 1) * a.gate_rows - a.row0;  // first token (in this launch's rows) of the next gate period
+            const int gso = __builtin_amdgcn_readfirstlane((gi0 * a.gate_stride + n0) * 4);
+            g0e = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4, gso, 0));
+            g0o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4, gso + 16, 0));
+            g1e = g0e, g1o = g0o;
+            if (bnd < m0 + GM_TM) {
+                g1e = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4, gso + a.gate_stride * 4, 0));
+                g1o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4, gso + a.gate_stride * 4 + 16, 0));
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int rb = (MH * 4 + m) * 16;  // 16-row block inside the wave's token half
+            const int row = m0 + wr * 128 + rb + col;
+            f32x4 ve = acc[MH * 4 + m][0] + be, vo = acc[MH * 4 + m][1] + bo;
+            acc[MH * 4 + m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[MH * 4 + m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.act & 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ve[e] = gm_gelu_tanh(ve[e]), vo[e] = gm_gelu_tanh(vo[e]);
+            }
+            {
+                float e0 = ve[0], e1 = ve[1], e2 = ve[2], e3 = ve[3], o0 = vo[0], o1 = vo[1], o2 = vo[2], o3 = vo[3];
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %6\n\t"
+                             "v_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                             : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));
+                ve = f32x4{e0, e1, e2, e3};
+                vo = f32x4{o0, o1, o2, o3};
+            }
+            if (edge && !(row >= mk && c8 >= nk_)) continue;
+            if (a.gate) {
+                const bool nx_ = row >= bnd;
+                ve *= nx_ ? g1e : g0e;
+                vo *= nx_ ? g1o : g0o;
+            }
+            const int so = __builtin_amdgcn_readfirstlane(((m0 + rb) * a.N + n0) * 2);  // (scalar; < 2 GiB: launch_gemm_bf16 chunks the rows)
+            if (a.resid) {
+                const bf16x8 r8 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsR, vo_out, so, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ve[e] += (float)r8[e], vo[e] += (float)r8[4 + e];
+            }
+            bf16x8 o8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o8[e] = (__bf16)ve[e], o8[4 + e] = (__bf16)vo[e];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fg_u32x4, o8), rsO, vo_out, so, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+
+    // ---- prologue: K-steps 0 and 1 whole -----------------------------------------------------------------------------------------
+    Cur c2{0, 0, 0, 0};
+    cur_set(c2);
+    stage(0, c2, 3);
+    if (S > 1) cur_next(c2);
+    stage(1, c2, 3);
+    if (S > 2) cur_next(c2);  // = K-step 2
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    read_x(X0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) asm volatile("s_barrier" ::: "memory");  // the second group runs one barrier behind
+
+    int t = 0, b0 = 0;  // flat K-step index, byte offset of its stage
+    auto kstep = [&]() {
+        const int b1 = b0 + BUFB >= 3 * BUFB ? 0 : b0 + BUFB;   // stage of K-step t + 1
+        const int b2 = b1 + BUFB >= 3 * BUFB ? 0 : b1 + BUFB;   // ... of t + 2 (= the one K-step t - 1 left)
+        // phase 0
+        read_w(W0, b0);
+        read_x(X1, b0, 1);
+        stage(b2 / BUFB, c2, 1);
+        mem_done();
+        __builtin_amdgcn_s_setprio(1);
+        mma(0, X0, W0);
+        __builtin_amdgcn_s_setprio(0);
+        cmp_done();
+        // phase 1
+        read_x(X0, b1, 0);
+        stage(b2 / BUFB, c2, 2);
+        mem_done();
+        __builtin_amdgcn_s_setprio(1);
+        mma(1, X1, W0);
+        __builtin_amdgcn_s_setprio(0);
+        cmp_done();
+        if (t + 3 < S) cur_next(c2);
+        ++t;
+        b0 = b1;
+    };
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        if (ti > 0 && wr == 1) asm volatile("s_barrier" ::: "memory");  // the second group falls one barrier behind again
+        for (int kk = 0; kk + 1 < nk; ++kk) kstep();
+        f32x4 b0v = {0.f, 0.f, 0.f, 0.f}, b1v = b0v;
+        tile_origin(ti, ep_m0, ep_n0);
+        tile_keep_from(ti, ep_mk, ep_nk);
+        if (a.bias) {
+            const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.bias);
+            const int bo_ = __builtin_amdgcn_readfirstlane((ep_n0 + wc * 32) * 4);
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int bl = (ln >> 4) * 16;
+            b0v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bl, bo_, 0));
+            b1v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bl, bo_ + 64, 0));
+        }
+        kstep();
+        if (wr == 0) asm volatile("s_barrier" ::: "memory");  // the groups meet before the epilogue and run it side by side
+        slice(I0{}, b0v, b1v);
+        slice(I1{}, b0v, b1v);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may land in an LDS allocation this workgroup has given up
+}
+
 // out[row][c .. c + 7] = epilogue(sum over the K splits of their fp32 partial sums): bias, tanh-GELU, gate x value + residual as in the
 // kernels' own token epilogue
 __global__ void gemm_splitk_finish_kernel(const GemmArgs a) {
@@ -919,6 +1187,55 @@ int launch_pp(const GemmArgs& a, hipStream_t s, bool prepare_only) {
     return (int)hipGetLastError();
 }
 
+// the narrow-tile kernel (256 x 128): token epilogue only
+int launch_pp2(const GemmArgs& a, hipStream_t s, bool prepare_only) {
+    constexpr int LDS = 3 * 49152;
+    const int dev = fg_device_slot();
+    if (dev < 0) return (int)hipErrorInvalidDevice;
+    static bool attr_done[16] = {};
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done[dev] = true;
+    }
+    if (!g_gm_cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return (int)hipErrorUnknown;
+        g_gm_cus[dev] = n;
+    }
+    if (prepare_only) return 0;
+    const int Mt = (a.M + GM_TM - 1) / GM_TM, Nt = (a.N + 127) / 128;
+    GemmArgs b = a;
+    int grid = g_gm_cus[dev];
+    const long long items = (long long)Mt * Nt;
+    if (items < grid) grid = (int)items, b.xn = 0;
+    if (grid & 7) b.xn = 0;
+    if (b.xn > 0) {
+        int xn = 1;
+        for (int c = 8; c >= 1; c >>= 1)
+            if (Nt % c == 0 && Mt / (8 / c) >= 4) {
+                xn = c;
+                break;
+            }
+        if (a.xn <= 8 && (a.xn & (a.xn - 1)) == 0 && Nt % a.xn == 0 && a.xn != 1) xn = a.xn;
+        b.xn = xn;
+    }
+    hipLaunchKernelGGL(gemm_bf16_pp2_kernel, dim3(grid), dim3(GM_NTHR), LDS, s, b);
+    return (int)hipGetLastError();
+}
+
+// Which short grids take the narrow tile: the 256-wide tiling would leave CUs idle (fewer than 2.5 tiles per CU) and the 128-wide one
+// fills at least 85 % of its last round (or the grid is so short that split-K was the alternative).
+bool gm_use_narrow(const GemmArgs& a, int cus) {
+    if (a.heads > 0 || a.out_f32 || a.N < 128 || a.M < GM_TM || (a.N % 16)) return false;
+    const long long wide = (long long)((a.M + GM_TM - 1) / GM_TM) * ((a.N + 255) / 256);
+    const long long narrow = (long long)((a.M + GM_TM - 1) / GM_TM) * ((a.N + 127) / 128);
+    if (wide * 2 >= 5LL * cus) return false;
+    if (wide * 2 <= cus) return true;  // split-K territory
+    const double fill_w = (double)wide / (double)(((wide + cus - 1) / cus) * cus), fill_n = (double)narrow / (double)(((narrow + cus - 1) / cus) * cus);
+    return fill_n > fill_w + 0.05;
+}
+
 // Split-K for short grids: with fewer 256 x 256 tiles than half the CUs (the video DiT's 4 680-token chunk x 1 536 outputs = 114
 // tiles) the K range of every tile is cut into ks pieces (ks | K / 64, tiles x ks <= CUs) that leave fp32 partial sums in the
 // caller's scratch; a finishing pass sums them and applies the token epilogue.
@@ -935,6 +1252,14 @@ int gm_pick_ksplit(const GemmArgs& a, int cus) {
 int gm_env(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
+}
+// FASTGEN_AMD_GEMM_NARROW=0: never the 256 x 128 tile (A/B measurements)
+bool gm_narrow_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("FASTGEN_AMD_GEMM_NARROW");
+        return !(e && e[0] == '0');
+    }();
+    return on;
 }
 // 0: gemm_bf16_kernel (register-staged), 1: gemm_bf16_pp_kernel (LDS-DMA, ping-pong) where the shape allows
 int gm_variant() {
@@ -967,7 +1292,8 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only) {
         if ((rc = launch_gm<4, GM_EPI_TOK>(a, s, true)) || (rc = launch_gm<3, GM_EPI_TOK>(a, s, true)) ||
             (rc = launch_gm<4, GM_EPI_HEADS>(a, s, true)) || (rc = launch_gm<3, GM_EPI_HEADS>(a, s, true)) ||
             (rc = launch_pp<GM_EPI_TOK>(a, s, true)) || (rc = launch_pp<GM_EPI_HEADS>(a, s, true)) || (rc = launch_pp<GM_EPI_RAW>(a, s, true)) ||
-            (rc = launch_pp<GM_EPI_TOK32>(a, s, true)) || (rc = launch_pp<GM_EPI_SPLIT>(a, s, true)) || (rc = launch_pp<GM_EPI_HEADS32>(a, s, true)))
+            (rc = launch_pp<GM_EPI_TOK32>(a, s, true)) || (rc = launch_pp<GM_EPI_SPLIT>(a, s, true)) || (rc = launch_pp<GM_EPI_HEADS32>(a, s, true)) ||
+            (rc = launch_pp2(a, s, true)))
             return rc;
         return 0;
     }
@@ -981,11 +1307,17 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only) {
         b.A = reinterpret_cast<const __bf16*>(a.A) + (size_t)r0 * a.K;
         if (a.out) b.out = reinterpret_cast<__bf16*>(a.out) + (size_t)r0 * a.N;
         if (a.resid) b.resid = reinterpret_cast<const __bf16*>(a.resid) + (size_t)r0 * a.N;
-        const bool pp = (a.variant < 0 ? gm_variant() : a.variant) == 1 && b.M >= GM_TM && a.N >= 256 && a.K >= 2 * GM_KC &&
+        const bool pp = (a.variant < 0 ? gm_variant() : (a.variant == 2 ? 1 : a.variant)) == 1 && b.M >= GM_TM && a.N >= 256 && a.K >= 2 * GM_KC &&
                         (!a.gate || a.gate_rows >= GM_TM);  // (the ping-pong kernel's token epilogue: a tile spans at most two gate rows)
         if (pp && !heads && !a.out_f32 && rows_max >= a.M) {
             const int dev = fg_device_slot();
-            b.ksplit = gm_pick_ksplit(b, dev >= 0 && g_gm_cus[dev] ? g_gm_cus[dev] : 256);
+            const int cus = dev >= 0 && g_gm_cus[dev] ? g_gm_cus[dev] : 256;
+            if (a.variant == 2 || (a.variant < 0 && gm_narrow_enabled() && gm_use_narrow(b, cus))) {
+                const int rc0 = launch_pp2(b, s, false);
+                if (rc0) return rc0;
+                continue;
+            }
+            b.ksplit = gm_pick_ksplit(b, cus);
             if (b.ksplit > 1) {
                 const int rc2 = launch_pp<GM_EPI_RAW>(b, s, false);
                 if (rc2) return rc2;

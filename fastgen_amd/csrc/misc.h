@@ -166,7 +166,7 @@ struct GemmArgs {
     size_t scratch_bytes = 0;
     int ksplit = 1;               // set by the launcher
     int out_f32 = 0;              // 1: out (and resid) fp32 [M][N] instead of bf16 (ping-pong kernel only: M, N >= 256)
-    int variant = -1;  // -1: default (env FASTGEN_AMD_GEMM_PP, 1 unless set to 0); 0 register-staged kernel; 1 LDS-DMA ping-pong kernel
+    int variant = -1;  // -1: default (env FASTGEN_AMD_GEMM_PP, 1 unless set to 0); 0 register-staged kernel; 1 LDS-DMA ping-pong kernel; 2 its narrow-tile form
     int xn = 1;    // 0: linear tile order; 1: XCD-aware order, split chosen by the launcher; 2 / 4 / 8: that many XCD columns over N
 };
 bool gemm_bf16_supported(const GemmArgs& a);

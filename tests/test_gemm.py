@@ -100,6 +100,41 @@ def test_split_k_on_short_grids(m, n, k):
     assert (got.float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-3
 
 
+@pytest.mark.parametrize("m,n,k", [(4680, 1536, 1536), (4680, 4608, 1536), (4680, 1536, 8960), (300, 128, 128), (1000, 1152, 1152), (513, 400, 256)])
+def test_narrow_tile_kernel(m, n, k):
+    """tile_order bit 256: the 256 x 128 form of the ping-pong kernel (what the launcher gives short token counts - one sample of the
+    video DiT is 4 680 tokens - instead of split-K or two-thirds-empty rounds of 256-wide tiles): every epilogue, ragged token and
+    output counts, gate periods that straddle a tile, in place."""
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g).bfloat16().cuda()
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).bfloat16().cuda()
+    bias = torch.randn(n, generator=g).cuda()
+    rows = 1560 if m > 2000 else 256
+    gate = torch.randn((m + rows - 1) // rows, n, generator=g).cuda()
+    resid = torch.randn(m, n, generator=g).bfloat16().cuda()
+    want = _ref(a, w, bias, gate=gate, gate_rows=rows, resid=resid)
+    got = _run(a, w, bias, gate=gate, gate_rows=rows, resid=resid, order=256 + 1)
+    assert torch.isfinite(got.float()).all()
+    assert (got.float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-3
+    assert torch.equal(got, _run(a, w, bias, gate=gate, gate_rows=rows, resid=resid, order=256 + 1))
+    want = _ref(a, w, bias, act=1)
+    got = _run(a, w, bias, act=1, order=256 + 0)
+    assert (got.float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-3
+    got = _run(a, w, order=256 + 1)
+    want = _ref(a, w)
+    assert (got.float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-6
+    # in place: out aliases the residual
+    from fastgen_amd import _lib
+
+    want = _ref(a, w, bias, gate=gate, gate_rows=rows, resid=resid)
+    x = resid.clone()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(_lib.lib().fg_op_gemm_bf16(p(a), p(w), p(bias), p(x), m, n, k, 0, p(gate), n, rows, p(x), 256 + 1,
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert (x.float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-3
+
+
 def test_unsupported_shapes_are_refused():
     from fastgen_amd import _lib
 
@@ -114,7 +149,7 @@ def test_unsupported_shapes_are_refused():
     for act in (2, 4, 8, 16, 5, -1):
         with pytest.raises(_lib.FastGenAMDError, match="act must be"):
             _run(a, w, act=act)
-    for order in (128, 128 + 33, 16 + 32, 256):
+    for order in (128, 128 + 33, 16 + 32, 512, 256 + 32):
         with pytest.raises(_lib.FastGenAMDError, match="tile_order"):
             _run(a, w, order=order)
     assert torch.equal(_run(a, w, act=1), torch.zeros(256, 256, dtype=torch.bfloat16, device="cuda"))
