@@ -193,6 +193,9 @@ __device__ __forceinline__ s16x4 fa_tr_read(const char* lds_addr) {
 
 // Timing experiments (scripts/fa_ablate.sh) skip one ingredient of the pipelined step each and compute garbage: they exist only in the
 // separately built libfastgen_amd_timing.so (`make timing`, -DFG_TIMING_BUILD); the product kernel has neither the argument nor the tests.
+#ifndef FA2_EXP
+#define FA2_EXP 0  // fa2_kernel timing experiments (scripts/fa2_exp.sh builds one library per bit: results are garbage): 0 in every shipped build
+#endif
 #ifdef FG_TIMING_BUILD
 #define FA_ABL_PARAM , int abl
 #define FA_ABL_ARG , abl
@@ -642,6 +645,452 @@ __global__ __launch_bounds__(256, MINW) void fa_kernel(const __bf16* __restrict_
     }
 }
 
+// MFMAs with their register files pinned (hipcc, left to itself, keeps this kernel's 64 registers of Q fragments in accumulator
+// registers and COPIES four of them into vector registers in front of every S^T MFMA: 13 v_accvgpr_* per MFMA in the tile loop):
+// S^T accumulates in vector registers (the softmax reads it), the Q fragments are accumulator-file operands, O^T accumulates in the
+// accumulator file.  Inline asm: the compiler pads no hazards here - every reader of a result below is dozens of instructions away
+// (the S^T of tile t + 1 is first read by tile t + 1's softmax; O^T by the next tile's rare rescale or, behind an s_nop, by the epilogue).
+__device__ __forceinline__ void fa2_mfma_s0(f32x16& d, const bf16x8& kf, const bf16x8& qf) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(kf), "a"(qf));
+}
+__device__ __forceinline__ void fa2_mfma_s(f32x16& d, const bf16x8& kf, const bf16x8& qf) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(kf), "a"(qf));
+}
+// (the last link of a chain: d = kf qf + c, so the finished S^T lands in the registers the softmax has just been done with)
+__device__ __forceinline__ void fa2_mfma_sl(f32x16& d, const bf16x8& kf, const bf16x8& qf, const f32x16& c) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "+v"(d) : "v"(kf), "a"(qf), "v"(c));  // ("+": the old set, no copy at the loop's back edge)
+}
+template <typename VT>
+__device__ __forceinline__ void fa2_mfma_o(f32x16& d, const VT& vv, const bf16x8& pf) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(vv), "v"(pf));
+}
+
+// ---- attention, head dim 128, 64 queries per wave ---------------------------------------------------------------------------------
+// fa_kernel<128> is bound by instruction issue, not by the matrix pipe (profiles/r02_fa_ablation.txt): per 32-key tile a wave issues 16 MFMAs
+// beside ~90 vector instructions, 24 LDS fragment reads and 4 LDS-DMA pieces, and the two waves of a SIMD share one issue port.  Here a wave
+// owns TWO 32-query blocks (64 queries) and the whole 512-register file (one wave per SIMD, one 256-thread workgroup per CU): every K / V
+// fragment read and every DMA piece feeds two MFMAs, so per query only the softmax arithmetic is left as it was.  Same tiles, same LDS
+// image and ring (4 x 16 KiB by LDS-DMA, three tiles ahead), same software pipelining as fa_kernel's pipelined step - S^T of tile t + 1 (for
+// both blocks: sixteen chained MFMAs) is issued between the pieces of tile t's two softmaxes, then O += V P for both blocks off ONE set
+// of V fragments.  Workgroup = 4 waves = 256 queries; grid mapping, key splits and the merge pass as fa_kernel.
+__global__ __launch_bounds__(256, 1) void fa2_kernel(const __bf16* __restrict__ q, int ldq, int64_t q_bs, const __bf16* __restrict__ k,
+                                                     const __bf16* __restrict__ v, int ldk, int64_t kv_bs, __bf16* __restrict__ out, int ldo,
+                                                     int64_t o_bs, int Lq, int Lkv, float scale_log2e, int nsplit, float* __restrict__ po,
+                                                     float* __restrict__ plse, int heads, int batch FA_ABL_PARAM) {
+    constexpr int HD = 128, KS = 8, DT_ = 4, TILE = 32 * 256, NST = 6;
+    constexpr int VBASE = NST * TILE;  // LDS: the ring's K tiles, then its V tiles
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int qtiles = (Lq + 255) / 256, units = batch * heads * nsplit;
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int unit = (slot / qtiles) * 8 + xcd, qt = slot % qtiles;
+    if (unit >= units) return;  // (the grid is padded to a multiple of 8 units; uniform per workgroup, before any barrier)
+    const int split = unit % nsplit, bh = unit / nsplit, head = bh % heads, b = bh / heads;
+    const int q0 = qt * 256 + wave * 64;
+    // this lane's two query rows (clamped: rows past Lq compute on the last row and are not stored)
+    bf16x8 qfA[KS], qfB[KS];
+    {
+        const __bf16* qa = q + (size_t)b * q_bs + (size_t)min(q0 + r, Lq - 1) * ldq + head * HD + 8 * h;
+        const __bf16* qb = q + (size_t)b * q_bs + (size_t)min(q0 + 32 + r, Lq - 1) * ldq + head * HD + 8 * h;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            qfA[kk] = *reinterpret_cast<const bf16x8*>(qa + kk * 16);
+            qfB[kk] = *reinterpret_cast<const bf16x8*>(qb + kk * 16);
+        }
+    }
+    const __bf16* kb = k + (size_t)b * kv_bs + head * HD;
+    const __bf16* vb = v + (size_t)b * kv_bs + head * HD;
+    const unsigned bytes = (unsigned)(((size_t)(Lkv - 1) * ldk + HD) * 2);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(kb), 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(vb), 0, bytes, 0x00020000);
+    unsigned dvo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 4 + (lane >> 4), pos = lane & 15;
+        dvo[j] = (unsigned)row * (unsigned)ldk * 2u + 16u * (unsigned)(pos ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+    }
+    auto dma = [&](int t, int stage) {  // tile t -> ring buffer `stage`; 4 instructions per wave
+        const int soff = t * 32 * ldk * 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr)(smem + stage * TILE + (wave * 2 + j) * 1024), 16, dvo[j], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr)(smem + VBASE + stage * TILE + (wave * 2 + j) * 1024), 16, dvo[j], soff, 0, 0);
+        }
+    };
+    f32x16 otA[DT_], otB[DT_];
+#pragma unroll
+    for (int d = 0; d < DT_; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) otA[d][i] = 0.f, otB[d][i] = 0.f;
+    float mA = -INFINITY, lA = 0.f, mB = -INFINITY, lB = 0.f;  // (the row sums stay per lane - two lanes per query - and meet in the epilogue)
+    const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, gc = (lane >> 4) & 1;
+    const int ntiles = (Lkv + 31) / 32;
+    const int t0 = (int)((long long)split * ntiles / nsplit), nt = (int)((long long)(split + 1) * ntiles / nsplit);
+    dma(t0, 0);
+    dma(min(t0 + 1, nt - 1), 1);
+    dma(min(t0 + 2, nt - 1), 2);
+    dma(min(t0 + 3, nt - 1), 3);
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");  // tiles t0 .. t0 + 2 have landed, in every wave's part
+    const uint32_t s0 = (uint32_t)(uintptr_t)smem;
+    uint32_t ka[KS], va[DT_][2];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) ka[kk] = s0 + (uint32_t)fa_off(r, 2 * kk + h);
+#pragma unroll
+    for (int d = 0; d < DT_; ++d)
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) va[d][hi] = s0 + VBASE + (uint32_t)(fa_off(4 * h + 8 * hi + gq, 4 * d + 2 * gc + (gp >> 1)) + 8 * (gp & 1));
+
+    // ---- the pipeline ---------------------------------------------------------------------------------------------------------------
+    // With one wave per SIMD nothing else fills the gaps of this wave's MFMAs: a 32x32x16 MFMA occupies the matrix pipe for 32 cycles and
+    // holds vector issue for 8 of them, so ~5-6 vector instructions per MFMA ride for free and a run of MFMAs without vector work (or of
+    // vector work without MFMAs) is time lost (MI355X_MICROARCH.md, issue-cost rows).  Per tile a wave has 32 MFMAs and ~210 other
+    // instructions; the step below deals them out evenly - 16 slots per block-phase, each ONE MFMA plus one group of softmax work:
+    //   phase A (tile t): O_A^T += V(t-1)^T P_A(t-1)^T [8 MFMAs]  |  softmax of S_A(t) -> P_A(t)  |  S_A(t+1) = K(t+1) Q_A^T [8 chained MFMAs]
+    //   phase B (tile t): the same for block B; in its last slots the V fragments of tile t are read for the next step.
+    // So the O^T MFMAs lag the softmax by one tile (their operands are registers that phase's vector work does not touch), the chain for
+    // the next tile's S^T accumulates in a spare register set and only its LAST MFMA writes the set the exponentials have just been done
+    // with.  The K fragments of tile t + 2 are read at the END of step t (their registers are free once the chain's MFMAs are issued), a
+    // whole step before the chain that uses them, and the V fragments of tile t likewise: no step waits on the LDS reads it issued itself.
+    // LDS ring: V(t-1) (its reads may still be returning), tile t, t+1, t+2, t+3 (landed by the step's end), t+4 landing = 6 x 16 KiB.
+    f32x16 sA, sB, sn;
+    bf16x8 kf[KS];
+    s16x8 vv[2][DT_];
+    bf16x8 pfA[2], pfB[2];
+    {
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) asm volatile("ds_read_b128 %0, %1" : "=v"(kf[kk]) : "v"(ka[kk]));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) asm volatile("" : "+v"(kf[kk]));
+        fa2_mfma_s0(sA, kf[0], qfA[0]);
+        fa2_mfma_s0(sB, kf[0], qfB[0]);
+#pragma unroll
+        for (int kk = 1; kk < KS; ++kk) {
+            fa2_mfma_s(sA, kf[kk], qfA[kk]);
+            fa2_mfma_s(sB, kf[kk], qfB[kk]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[kk]) : "v"(ka[kk]), "n"(TILE));  // K(t0 + 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the first step's counted waits assume a whole step's reads in flight)
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {  // "tile t0 - 1": P = 0 against finite V
+            pfA[sx] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, pfB[sx] = pfA[sx];
+#pragma unroll
+            for (int d = 0; d < DT_; ++d) vv[sx][d] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    // Softmax against a REFERENCE maximum that moves in eras, not per tile: p = 2^(c s - c ref), and while a tile's maximum stays below
+    // ref + THR / c nothing is rescaled at all (p <= 2^THR: exact in fp32 sums, and bf16 keeps its 8 significant bits at any magnitude).
+    // Only when a query's scores jump past that does its block start a new era: ref := the new maximum, O^T and the sum scaled by
+    // 2^(c (old ref - new ref)).  That multiply is vector arithmetic on the accumulator file; written inside the tile loop it makes hipcc
+    // keep O^T in vector registers across the loop and copy all 128 registers to and fro every tile.  So the era change sits OUTSIDE the
+    // inner loop (the loop is left at the end of the step that saw the jump: the tile's own O^T MFMAs come a step later anyway), and
+    // inside it O^T is touched by the MFMAs alone.  The row sums stay per lane (two lanes per query); they meet in the epilogue.
+    constexpr float THR = 40.0f;
+    const float thr = THR / scale_log2e;
+    float cmA = 0.f, cmB = 0.f;                // -c ref
+    float mthA = -INFINITY, mthB = -INFINITY;  // ref + THR / c: a tile maximum above it starts an era
+    float alA = 1.0f, alB = 1.0f;
+    bool evA = false, evB = false;  // (scalar: the whole wave leaves the loop or none of it)
+    auto SB = [] { __builtin_amdgcn_sched_barrier(0); };
+    // (a sched_barrier fences the instruction scheduler only: LLVM's sinking passes still move pure arithmetic down to its first use,
+    // across any number of them.  A volatile asm that "uses" the value keeps its producer in the slot it was written in.)
+    auto pin1 = [](auto& x) { asm volatile("" : "+v"(x)); };
+    auto PIN = [&](auto&... x) { (pin1(x), ...); };
+    auto tile_max = [&](float m0, float m1) {  // over both lanes of the query
+        float a_, b_, mt;
+        asm volatile("v_max_f32 %0, %2, %3\n\tv_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "=&v"(a_), "=&v"(b_) : "v"(m0), "v"(m1));
+        asm volatile("v_max_f32 %0, %1, %2" : "=v"(mt) : "v"(a_), "v"(b_));
+        return mt;
+    };
+    auto new_era = [&](float mt, float& m, float& cm, float& mth, float& lsum, float& al, bool& ev) {
+        const float mn = fmaxf(m, mt);
+        ev = ev || __builtin_amdgcn_ballot_w64(m > -INFINITY) != 0;  // (a block's first tile: O^T and the sum are still zero)
+        al = m > -INFINITY ? __builtin_amdgcn_exp2f((m - mn) * scale_log2e) : 1.0f;
+        lsum *= al;
+        m = mn, cm = -mn * scale_log2e, mth = mn + thr;
+    };
+    // LDS offsets of the ring buffers this step works on (scalars, rotated per tile; one v_add per fragment address)
+    int oV = 0, oK = 2 * TILE, oD = 4 * TILE;  // tile t (its V, read for the next step) | tile t + 2 (K, likewise) | tile t + 4 (the DMA lands there)
+    auto phase = [&](int t, auto PH_, f32x16& sc, const bf16x8 (&qf)[KS], f32x16 (&ot)[DT_], bf16x8 (&pf)[2], float& m, float& cm, float& mth,
+                     float& lsum, float& al, bool& ev) {
+        constexpr int PH = decltype(PH_)::value;
+        auto PV = [&](int j) { if (!FA_ABL(16) && !(FA2_EXP & 32)) fa2_mfma_o(ot[j & 3], vv[j >> 2][j & 3], pf[j >> 2]); };
+        auto CH = [&](int kk) {
+            if (FA_ABL(32) || (FA2_EXP & 64)) return;
+            if (kk == 0) fa2_mfma_s0(sn, kf[0], qf[0]);
+            else if (kk < 7) fa2_mfma_s(sn, kf[kk], qf[kk]);
+            else fa2_mfma_sl(sc, kf[7], qf[7], sn);  // lands in the set the exponentials are done with
+        };
+        auto piece = [&](int j) {  // one K and one V piece of tile t + 4 (into the buffer of tile t - 2: its readers passed the last barrier)
+            if (FA_ABL(4) || (FA2_EXP & 2)) return;
+            const int soff = min(t + 4, nt - 1) * 32 * ldk * 2;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr)(smem + oD + (wave * 2 + j) * 1024), 16, dvo[j], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr)(smem + VBASE + oD + (wave * 2 + j) * 1024), 16, dvo[j], soff, 0, 0);
+        };
+        auto kread = [&](int kk) {  // K(t + 2) -> the next step's chains
+            if (FA_ABL(2) || (FA2_EXP & 4)) return;
+            const uint32_t ad = ka[kk] + (uint32_t)oK;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(kf[kk]) : "v"(ad));
+        };
+        auto vread = [&](int j) {  // V(t) -> the next step's O^T MFMAs
+            if (FA_ABL(2) || (FA2_EXP & 4)) return;
+            const int sx = j >> 2, d = j & 3;
+            s16x4 lo, hi;
+            const uint32_t ad0 = va[d][0] + (uint32_t)oV, ad1 = va[d][1] + (uint32_t)oV;
+            if (sx == 0) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ad0));
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(ad1));
+            } else {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(lo) : "v"(ad0));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(hi) : "v"(ad1));
+            }
+            vv[sx][d] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        // The 16 MFMAs of a phase, chain and O^T alternating (a chain link waits for its predecessor's result; the O^T ones are
+        // independent).  Phase B re-reads each fragment one slot after the MFMA that used it last: the LDS returns them in the order
+        // phase A of the next step consumes them, so that phase waits with falling counts, never for a read it has just issued.
+        //   slot:  0    1    2    3    4    5    6    7    8    9    10   11   12   13   14   15
+        //          CH0  PV0  CH1  PV1  CH2  PV2  CH3  PV3  PV4  CH4  PV5  CH5  PV6  CH6  PV7  CH7
+        auto M = [&](auto SLOT_) {
+            constexpr int S = decltype(SLOT_)::value;
+            constexpr bool is_ch = S < 8 ? !(S & 1) : (S & 1);
+            constexpr int idx = S < 8 ? (S >> 1) : (is_ch ? 4 + ((S - 9) >> 1) : 4 + ((S - 8) >> 1));
+            if constexpr (PH == 0) {
+                // LDS operations of the last step still allowed out when this slot's fragment is in (K: 1 operation, V: 2; slot order):
+                // 24 less those up to and including this slot's
+                constexpr int upto = S < 8 ? 3 * (S >> 1) + (is_ch ? 1 : 3) : 12 + (S == 8 ? 2 : 2 + 3 * ((S - 9) >> 1) + (is_ch ? 1 : 3));
+                constexpr int after = 24 - upto;
+                if constexpr (S == 0) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");  // (the counter's range; covers slots 0 .. 5)
+                else if constexpr (S >= 6) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(after) : "memory");
+            }
+            if constexpr (is_ch) CH(idx);
+            else PV(idx);
+        };
+        auto R = [&](auto SLOT_) {  // (phase B) the re-read of the fragment slot S's MFMA used
+            constexpr int S = decltype(SLOT_)::value;
+            constexpr bool is_ch = S < 8 ? !(S & 1) : (S & 1);
+            constexpr int idx = S < 8 ? (S >> 1) : (is_ch ? 4 + ((S - 9) >> 1) : 4 + ((S - 8) >> 1));
+            if constexpr (PH == 1) {
+                if constexpr (is_ch) kread(idx);
+                else vread(idx);
+            }
+        };
+#define SL(n) std::integral_constant<int, n> {}
+        if constexpr (PH == 0) asm volatile("s_nop 1" ::: "memory");  // (the P^T fragments were written by vector instructions)
+        SB();
+        // slots 0-2: the tile maximum over both lanes of the query; does the reference hold?
+        M(SL(0));
+        float m0, m1;
+        asm volatile("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max3_f32 %0, %0, %8, %9"
+                     : "=&v"(m0)
+                     : "v"(sc[0]), "v"(sc[1]), "v"(sc[2]), "v"(sc[3]), "v"(sc[4]), "v"(sc[5]), "v"(sc[6]), "v"(sc[7]), "v"(sc[8]));
+        SB();
+        M(SL(1));
+        R(SL(0));
+        asm volatile("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7"
+                     : "=&v"(m1)
+                     : "v"(sc[9]), "v"(sc[10]), "v"(sc[11]), "v"(sc[12]), "v"(sc[13]), "v"(sc[14]), "v"(sc[15]));
+        SB();
+        M(SL(2));
+        R(SL(1));
+        // Does the reference hold?  Asked per LANE (the two lanes of a query see different keys of the tile; a ballot covers both), and
+        // the answer is only looked at after the exponentials: they are computed against the old reference on speculation - a vector
+        // compare feeding a scalar branch right away stalls the wave's one instruction stream for the compare's whole latency.
+        float ml;
+        asm volatile("v_max_f32 %0, %1, %2" : "=v"(ml) : "v"(m0), "v"(m1));
+        const bool jump = !(FA2_EXP & 8) && __builtin_amdgcn_ballot_w64(ml > mth) != 0;
+        SB();
+        // slots 3-10: p = 2^(c s + cm), two pairs per slot
+        float e[16];
+        auto EX = [&](int g) {
+            const float z0 = __builtin_fmaf(sc[2 * g], scale_log2e, cm), z1 = __builtin_fmaf(sc[2 * g + 1], scale_log2e, cm);
+            e[2 * g] = (FA_ABL(1) || (FA2_EXP & 16)) ? z0 : __builtin_amdgcn_exp2f(z0), e[2 * g + 1] = (FA_ABL(1) || (FA2_EXP & 16)) ? z1 : __builtin_amdgcn_exp2f(z1);
+            PIN(e[2 * g], e[2 * g + 1]);
+        };
+        M(SL(3)), R(SL(2)), EX(0), SB();
+        M(SL(4)), R(SL(3)), EX(1), SB();
+        M(SL(5)), R(SL(4)), EX(2), SB();
+        M(SL(6)), R(SL(5)), EX(3), SB();
+        M(SL(7)), R(SL(6)), EX(4), SB();
+        M(SL(8)), R(SL(7)), EX(5), SB();
+        M(SL(9)), R(SL(8)), EX(6), SB();
+        M(SL(10)), R(SL(9)), EX(7), SB();
+        if (jump) {  // (rare, wave-uniform) a new era for this block: the tile's exponentials again, against the new reference
+            new_era(tile_max(m0, m1), m, cm, mth, lsum, al, ev);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) EX(g);
+        }
+        // slots 11-15: the row sum (per lane); the K and V pieces of tile t + 4 (phase A: this wave's first pair, phase B: its second)
+        M(SL(11));
+        R(SL(10));
+        float a0 = e[0] + e[1], a1 = e[2] + e[3], a2 = e[4] + e[5], a3 = e[6] + e[7];
+        PIN(a0, a1, a2, a3);
+        SB();
+        M(SL(12));
+        R(SL(11));
+        float a4 = e[8] + e[9], a5 = e[10] + e[11], a6 = e[12] + e[13], a7 = e[14] + e[15];
+        PIN(a4, a5, a6, a7);
+        piece(PH);
+        SB();
+        M(SL(13));
+        R(SL(12));
+        float b0 = a0 + a1, b1 = a2 + a3, b2 = a4 + a5, b3 = a6 + a7;
+        PIN(b0, b1, b2, b3);
+        SB();
+        M(SL(14));
+        R(SL(13));
+        lsum += (b0 + b1) + (b2 + b3);
+        PIN(lsum);
+        SB();
+        M(SL(15));  // (the chain's last link lands in the set the exponentials are done with)
+        R(SL(14));
+        // P^T(t) over P^T(t - 1), whose MFMAs are all issued
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) pf[0][k2] = (__bf16)e[k2];
+        PIN(pf[0]);
+        SB();
+        R(SL(15));
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) pf[1][k2] = (__bf16)e[8 + k2];
+        PIN(pf[1]);
+        SB();
+#undef SL
+    };
+    auto era = [&]() {  // (no barrier in here: the other waves just see this one arrive at the next one later)
+        asm volatile("s_nop 15" ::: "memory");
+        // One 16-register tile at a time, each in a basic block of its own (the conditions are opaque always-true scalars): hipcc
+        // assigns a register file per value per BLOCK, so a straight-line sweep wants all 128 accumulators in vector registers at once
+        // and spills everything that lives across it - the loop's fragment addresses among them, in the loop as well.
+        int yes;
+        asm volatile("s_mov_b32 %0, 1" : "=s"(yes));
+#pragma unroll
+        for (int d = 0; d < DT_; ++d) {
+            if (yes) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) otA[d][i] *= alA;
+                asm volatile("" : "+a"(otA[d]));
+            }
+            asm volatile("s_add_u32 %0, %0, 0" : "+s"(yes));
+            if (yes) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) otB[d][i] *= alB;
+                asm volatile("" : "+a"(otB[d]));
+            }
+            asm volatile("s_add_u32 %0, %0, 0" : "+s"(yes));
+        }
+        alA = alB = 1.0f;
+        evA = evB = false;
+    };
+    const int t_end = (nt == ntiles && (Lkv & 31)) ? nt - 1 : nt;  // at most the very last tile is ragged: it is finished off below
+    int t = t0;
+    while (t < t_end) {
+        for (; t < t_end;) {  // the hot loop: O^T is only ever an MFMA operand here
+            phase(t, std::integral_constant<int, 0>{}, sA, qfA, otA, pfA, mA, cmA, mthA, lA, alA, evA);
+            phase(t, std::integral_constant<int, 1>{}, sB, qfB, otB, pfB, mB, cmB, mthB, lB, alB, evB);
+            // one younger tile (4 instructions) may stay in flight: tile t + 2 has landed; then the hand-over barrier
+            if (FA_ABL(8) || ((FA2_EXP & 1) && (t & 1))) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+            ++t;
+            oV = oV == (NST - 1) * TILE ? 0 : oV + TILE, oK = oK == (NST - 1) * TILE ? 0 : oK + TILE, oD = oD == (NST - 1) * TILE ? 0 : oD + TILE;
+            if (evA || evB) break;
+        }
+        if (evA || evB) era();  // (rare; the tile's own O^T MFMAs come with the next step, against the new reference)
+    }
+    // the O^T MFMAs of the last whole tile
+    auto drain = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+            for (int d = 0; d < DT_; ++d) asm volatile("" : "+v"(vv[sx][d]));
+        asm volatile("s_nop 1" ::: "memory");
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+            for (int d = 0; d < DT_; ++d) {
+                fa2_mfma_o(otA[d], vv[sx][d], pfA[sx]);
+                fa2_mfma_o(otB[d], vv[sx][d], pfB[sx]);
+            }
+    };
+    drain();
+    if (t_end < nt) {  // the ragged tile, unpipelined: its S^T came out of the last step's chains (rows past Lkv: zeros from the buffer bounds)
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // every wave's pieces of it have landed
+        auto soft_plain = [&](f32x16& sc, bf16x8 (&pf)[2], float& m, float& cm, float& mth, float& lsum, float& al, bool& ev) {
+            asm volatile("s_nop 7" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (t_end * 32 + acc_row(i, h) >= Lkv) sc[i] = -INFINITY;
+            float m0 = sc[0], m1 = sc[8];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) m0 = fmaxf(m0, sc[i]), m1 = fmaxf(m1, sc[8 + i]);
+            const float mt = tile_max(m0, m1);
+            if (__builtin_amdgcn_ballot_w64(mt > mth) != 0) new_era(mt, m, cm, mth, lsum, al, ev);
+            float ps = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float ei = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[i], scale_log2e, cm));
+                ps += ei;
+                pf[i >> 3][i & 7] = (__bf16)ei;
+            }
+            lsum += ps;
+        };
+        soft_plain(sA, pfA, mA, cmA, mthA, lA, alA, evA);
+        soft_plain(sB, pfB, mB, cmB, mthB, lB, alB, evB);
+        if (evA || evB) era();
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+            for (int d = 0; d < DT_; ++d) {
+                s16x4 lo, hi;
+                const uint32_t ad0 = va[d][0] + (uint32_t)oV, ad1 = va[d][1] + (uint32_t)oV;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(ad0), "n"(16 * 256 * sx));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(ad1), "n"(16 * 256 * sx));
+                vv[sx][d] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        drain();
+    }
+    {  // the two lanes of a query hold the sums over their halves of each tile's keys
+        float a_ = lA, b_ = lA, c_ = lB, d_ = lB;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a_), "+v"(b_));
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c_), "+v"(d_));
+        lA = a_ + b_, lB = c_ + d_;
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // no DMA may land in an LDS allocation this workgroup has given up; the last O^T MFMAs have retired
+    // out[query][head * HD + dim]: this lane holds dims 32 d + 8 i4 + 4 h + e of its two queries
+    auto finish = [&](int qrow, const f32x16 (&ot)[DT_], float m, float lsum) {
+        if (qrow >= Lq) return;
+        const float inv = 1.0f / lsum;
+        if (nsplit > 1) {
+            const size_t row = (size_t)b * Lq + qrow, rows = (size_t)batch * Lq;
+            float* orow = po + ((size_t)split * rows + row) * (heads * HD) + head * HD;
+#pragma unroll
+            for (int d = 0; d < DT_; ++d)
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4)
+                    *reinterpret_cast<f32x4*>(orow + 32 * d + 8 * i4 + 4 * h) =
+                        f32x4{ot[d][4 * i4] * inv, ot[d][4 * i4 + 1] * inv, ot[d][4 * i4 + 2] * inv, ot[d][4 * i4 + 3] * inv};
+            if (h == 0) plse[((size_t)split * rows + row) * heads + head] = m * scale_log2e + __builtin_amdgcn_logf(lsum);
+            return;
+        }
+        __bf16* orow = out + (size_t)b * o_bs + (size_t)qrow * ldo + head * HD;
+#pragma unroll
+        for (int d = 0; d < DT_; ++d)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const bf16x4 o4 = {(__bf16)(ot[d][4 * i4] * inv), (__bf16)(ot[d][4 * i4 + 1] * inv), (__bf16)(ot[d][4 * i4 + 2] * inv),
+                                   (__bf16)(ot[d][4 * i4 + 3] * inv)};
+                *reinterpret_cast<bf16x4*>(orow + 32 * d + 8 * i4 + 4 * h) = o4;
+            }
+    };
+    finish(q0 + r, otA, mA, lA);
+    finish(q0 + 32 + r, otB, mB, lB);
+}
+
 // out[row][c] = sum_s w_s po[s][row][c] / sum_s w_s,  w_s = 2^(plse[s][row][head(c)] - max_s): the merge of fa128_kernel's key splits
 __global__ void fa128_combine_kernel(const float* __restrict__ po, const float* __restrict__ plse, __bf16* __restrict__ out, int ldo,
                                      int64_t o_bs, int64_t rows, int Lq, int heads, int nsplit, int hd) {
@@ -825,9 +1274,23 @@ int launch_fa(int hd, const void* q, int ldq, int64_t q_bs, const void* k, const
 #define FA_GO(HD, MW, LDS, DM)                                                                                                              \
     hipLaunchKernelGGL((fa_kernel<HD, MW, DM>), g, dim3(256), LDS, s, (const __bf16*)q, ldq, q_bs, (const __bf16*)k, (const __bf16*)v, ldk, kv_bs, \
                        (__bf16*)out, ldo, o_bs, Lq, Lkv, sc, nsplit, po, plse, heads, B, sample_major FA_ABL_ARG)
+    // head dim 128: fa2_kernel (64 queries per wave, one wave per SIMD) where it measures ahead - self-attention over >= 1024 keys:
+    // 165 / 596 / 1005 us against fa_kernel's 186 / 608 / 1033 at 4680 queries x 4680 / 18720 / 32760 keys, the 21-frame loop 1.168 s
+    // against 1.180 (profiles/r03_fa2_experiments.txt); the text cross-attention (512 keys) stays with fa_kernel (42 us against 50).
+    // FASTGEN_AMD_FA_WIDE = 0 | 1 forces one of them for every length.
+    static int wide = -2;
+    if (wide == -2) {
+        const char* e = getenv("FASTGEN_AMD_FA_WIDE");
+        wide = !e ? -1 : (e[0] == '1' ? 1 : 0);
+    }
+    const bool use_wide = wide == 1 || (wide == -1 && Lkv >= 1024);
     if (hd == 128) {
         if ((size_t)Lkv * ldk * 2 >= ((size_t)1 << 31)) return (int)hipErrorInvalidValue;  // (buffer-resource offsets are 32-bit)
-        if (!use_dma) FA_GO(128, 2, 32768, false);
+        if (use_wide && use_dma && !sample_major) {
+            const int qt2 = (Lq + 255) / 256;
+            hipLaunchKernelGGL(fa2_kernel, dim3((unsigned)(((units + 7) / 8) * 8 * qt2)), dim3(256), 6 * 16384, s, (const __bf16*)q, ldq, q_bs,
+                               (const __bf16*)k, (const __bf16*)v, ldk, kv_bs, (__bf16*)out, ldo, o_bs, Lq, Lkv, sc, nsplit, po, plse, heads, B FA_ABL_ARG);
+        } else if (!use_dma) FA_GO(128, 2, 32768, false);
         else if (minw == 3) FA_GO(128, 3, 65536, true);
         else FA_GO(128, 2, 65536, true);
     } else {

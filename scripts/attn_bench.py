@@ -14,6 +14,24 @@ SHAPES = [("wan self chunk 0", 1, 12, 128, 4680, 4680), ("wan self chunk 3", 1, 
           ("wan cross (text)", 1, 12, 128, 4680, 512), ("wan teacher-forcing chunk 6 of B=2", 2, 12, 128, 4680, 7 * 4680),
           ("DiT-XL/2 B=256", 256, 16, 72, 256, 256), ("DiT-XL/2 B=64", 64, 16, 72, 256, 256)]
 REPS = 4
+if os.environ.get("ATTN_SHAPES"):  # e.g. ATTN_SHAPES=2 : only "wan self chunk 6" (counter passes)
+    SHAPES = [SHAPES[int(i)] for i in os.environ["ATTN_SHAPES"].split(",")]
+
+if "--pmc" in sys.argv:  # per-kernel counter averages of a `rocprofv3 --pmc ... --output-format csv` directory
+    import csv
+    from collections import defaultdict
+
+    d = sys.argv[sys.argv.index("--pmc") + 1]
+    acc, cnt = defaultdict(float), defaultdict(int)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "fa_kernel" in r["Kernel_Name"] or "fa2_kernel" in r["Kernel_Name"]:
+                key = (r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])
+                acc[key] += float(r["Counter_Value"])
+                cnt[key] += 1
+    for key in sorted(acc):
+        print(f"{key[0]:42s} {key[1]:28s} {acc[key] / cnt[key]:16.0f}  (n={cnt[key]})")
+    sys.exit(0)
 
 if "--parse" in sys.argv:
     import csv
@@ -23,7 +41,7 @@ if "--parse" in sys.argv:
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         rows += list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    fa = [r for r in rows if "fa_kernel" in r["Kernel_Name"]]
+    fa = [r for r in rows if "fa_kernel" in r["Kernel_Name"] or "fa2_kernel" in r["Kernel_Name"]]
     cb = [r for r in rows if "fa128_combine" in r["Kernel_Name"]]
     assert len(fa) == REPS * len(SHAPES), (len(fa), len(SHAPES))
     ci = 0
@@ -48,6 +66,9 @@ import torch
 from fastgen_amd import _lib
 if os.environ.get("FA_TIMING_LIB") == "1":  # scripts/fa_ablate.sh: the FASTGEN_AMD_FA_ABL switches exist only in the timing library
     _lib.LIB_PATH = _lib.LIB_PATH.replace("libfastgen_amd.so", "libfastgen_amd_timing.so")
+
+if os.environ.get("FA_LIB"):  # an experimental build of the library (absolute or repo-relative path)
+    _lib.LIB_PATH = os.path.abspath(os.environ["FA_LIB"])
 
 L = _lib.lib()
 p = lambda t: ctypes.c_void_p(t.data_ptr())

@@ -88,6 +88,36 @@ def test_attention_matches_sdpa(B, H, hd, Lq, Lkv):
     assert torch.isfinite(out.float()).all() and _rel(out, want) < 1e-2, _rel(out, want)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["rising", "falling", "spikes"])
+def test_attention_when_the_scores_outgrow_the_running_reference(order):
+    """fa2_kernel (head dim 128, >= 1024 keys) exponentiates against a reference maximum that only moves when a tile's scores leave a
+    window of 2^40 above it, rescaling O and the row sum in a rarely taken block outside its tile loop.  Random keys of one scale never
+    take that block after the first tile; here the key norms grow (fall, spike) along the sequence so that it is taken again and again,
+    over a ragged last tile and over key splits."""
+    from fastgen_amd import _lib
+
+    B, H, hd, Lq, Lkv = 1, 2, 128, 300, 2000 + 13
+    g = torch.Generator().manual_seed(3)
+    q = (4.0 * torch.randn(B, Lq, H * hd, generator=g)).bfloat16().cuda()
+    k = torch.randn(B, Lkv, H * hd, generator=g)
+    ramp = torch.linspace(0.25, 8.0, Lkv)
+    if order == "falling":
+        ramp = ramp.flip(0)
+    elif order == "spikes":
+        ramp = torch.where(torch.arange(Lkv) % 97 == 5, 8.0, 0.5) * (1.0 + torch.arange(Lkv) / Lkv)
+    k = (k * ramp[None, :, None]).bfloat16().cuda()
+    v = torch.randn(B, Lkv, H * hd, generator=g).bfloat16().cuda()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    want = R.sdpa(q.float().view(B, Lq, H, hd), k.float().view(B, Lkv, H, hd), v.float().view(B, Lkv, H, hd))
+    for ns in (1, 4):
+        out = torch.full_like(q, float("nan"))
+        _lib.check(_lib.lib().fg_op_attention_split(p(q), p(k), p(v), p(out), B, H, hd, Lq, Lkv, ns,
+                                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all() and _rel(out, want) < 1e-2, (ns, _rel(out, want))
+
+
 def _nets(seed=7):
     from fastgen_amd.networks.Wan.network_causal import CausalWan
 
