@@ -1091,6 +1091,188 @@ __global__ __launch_bounds__(256, 1) void fa2_kernel(const __bf16* __restrict__ 
     finish(q0 + 32 + r, otB, mB, lB);
 }
 
+// compile-time loop (the LDS instructions below take their offsets as immediates) and LDS reads the compiler may not move or merge
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128(bf16x8& v, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr(s16x4& v, uint32_t addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait() {  // at most N LDS operations still out (they return in order)
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ---- attention, head dim 72, at most 256 keys: the whole key sequence in one pass ---------------------------------------------------
+// DiT-XL/2's shape (256 tokens, 16 heads x 72: fastgen/networks/DiT/network.py:168, 191).  fa_kernel<72> walks its 8 key tiles through a
+// two-buffer ring with a barrier per tile and an online softmax whose per-tile bookkeeping (maximum exchange, rescale factor, ballot)
+// costs as much as the tile's exponentials: 16.8 vector instructions per MFMA, 18 % of the matrix pipe (profiles/r03_dit_attn_pmc_*).
+// With so few keys none of that is needed: a workgroup brings ALL of K and V of its (sample, head) into LDS with 72 LDS-DMA
+// instructions (144-byte rows back to back, exactly as they lie in memory: 2 x 36 KiB, two workgroups per CU), each wave computes its 32
+// queries' S^T against all 256 keys (8 accumulator tiles = 128 registers), takes the exact row maximum once, exponentiates, sums, and
+// multiplies by V.  One barrier per workgroup; no rescale exists.  The second workgroup of the CU computes while this one loads.
+// The third 32-wide tile of output dims (72 .. 95) is computed from the 24 bytes that follow each 144-byte row (the next row's start:
+// finite) and never stored; the fifth 16-deep step of q k^T is half empty on the q side (zeros) as in fa_kernel<72>.
+__global__ __launch_bounds__(256, 2) void fa72_seq_kernel(const __bf16* __restrict__ q, int ldq, int64_t q_bs, const __bf16* __restrict__ k,
+                                                          const __bf16* __restrict__ v, int ldk, int64_t kv_bs, __bf16* __restrict__ out, int ldo,
+                                                          int64_t o_bs, int Lq, int Lkv, float scale_log2e, int heads, int batch) {
+    constexpr int HD = 72, KS = 5, DT_ = 3, RP = 144, NKT = 8, MAT = 256 * RP;  // bytes of one matrix in LDS
+    extern __shared__ __attribute__((aligned(16))) char smem[];                // K | V | 64 bytes of slack behind V's last row
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    // all heads of a sample on one XCD (fa_kernel's sample-major mapping: a head's 144-byte rows straddle its neighbours' cache lines)
+    const int qtiles = (Lq + 127) / 128;
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int qt = slot % qtiles, u = slot / qtiles;
+    const int b = (u / heads) * 8 + xcd, head = u % heads;
+    if (b >= batch) return;  // (uniform per workgroup, before the barrier)
+    const __bf16* kb = k + (size_t)b * kv_bs + head * HD;
+    const __bf16* vb = v + (size_t)b * kv_bs + head * HD;
+    {
+        const unsigned bytes = (unsigned)(((size_t)(Lkv - 1) * ldk + HD) * 2);  // rows past Lkv are out of range: they read as zeros
+        const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(kb), 0, bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(vb), 0, bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < ((FA2_EXP & 256) ? 0 : 9); ++i) {  // a wave instruction fills 1 KiB = 64 consecutive 16-byte chunks of the row-major image
+            const int g = (wave * 9 + i) * 64 + lane, row = g / 9, c = g - 9 * row;
+            const unsigned src = (unsigned)row * (unsigned)ldk * 2u + 16u * (unsigned)c;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr)(smem + (wave * 9 + i) * 1024), 16, src, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr)(smem + MAT + (wave * 9 + i) * 1024), 16, src, 0, 0, 0);
+        }
+    }
+    const int q0 = qt * 128 + wave * 32;
+    // this lane's query row (clamped: rows past Lq compute on the last row and are not stored)
+    const __bf16* qrow = q + (size_t)b * q_bs + (size_t)min(q0 + r, Lq - 1) * ldq + head * HD + 8 * h;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        qf[kk] = bf16x8{};
+        if (kk * 16 + 8 * h < HD) qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + kk * 16);
+    }
+    if (tid < 4) *reinterpret_cast<fg_u32x4*>(smem + 2 * MAT + 16 * tid) = fg_u32x4{0, 0, 0, 0};  // (finite bytes behind V's last row)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // S^T[key][query], all keys.  A tile's five K fragments are read two tiles ahead of their MFMAs (three register sets, counted waits:
+    // left to itself hipcc puts each read right in front of the MFMA that uses it - an LDS round trip per MFMA)
+    f32x16 s[NKT];
+    const uint32_t ka = (uint32_t)(uintptr_t)smem + (uint32_t)(r * RP + 16 * h);
+    bf16x8 kf[3][KS];
+    static_for<0, 2>([&](auto T_) {
+        constexpr int T = decltype(T_)::value;
+        static_for<0, KS>([&](auto K_) { constexpr int K = decltype(K_)::value; lds_read_b128<32 * T * RP + 32 * K>(kf[T][K], ka); });
+    });
+    static_for<0, ((FA2_EXP & 512) ? 1 : NKT)>([&](auto T_) {
+        constexpr int T = decltype(T_)::value;
+        if constexpr (T + 2 < NKT)
+            static_for<0, KS>([&](auto K_) { constexpr int K = decltype(K_)::value; lds_read_b128<32 * (T + 2) * RP + 32 * K>(kf[(T + 2) % 3][K], ka); });
+        lds_wait<(T + 2 < NKT ? 2 : NKT - 1 - T) * KS>();
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) asm volatile("" : "+v"(kf[T % 3][kk]));  // (the MFMAs depend on the wait, not only on the reads)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[T][i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) s[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[T % 3][kk], qf[kk], s[T], 0, 0, 0);
+    });
+    if (Lkv < 32 * NKT) {  // (uniform) keys past Lkv
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (32 * kt + acc_row(i, h) >= Lkv) s[kt][i] = -INFINITY;
+    }
+    // the exact row maximum (the query's keys lie in this lane and in lane ^ 32), p = 2^(c (s - max)), the row sum
+    float m = s[0][0];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m = fmaxf(m, s[kt][i]);
+    {
+        float a_ = m, b_ = m;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a_), "+v"(b_));
+        m = fmaxf(a_, b_);
+    }
+    const float mc = m * scale_log2e;
+    float ls[4] = {0.f, 0.f, 0.f, 0.f};
+    bf16x8 pf[NKT][2];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][i], scale_log2e, -mc));
+            ls[i & 3] += e;
+            pf[kt][i >> 3][i & 7] = (__bf16)e;
+        }
+    float lsum = (ls[0] + ls[1]) + (ls[2] + ls[3]);
+    {
+        float a_ = lsum, b_ = lsum;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a_), "+v"(b_));
+        lsum = a_ + b_;
+    }
+    // O^T[dim][query] = V^T[dim][key] P^T[key][query]; transposed-read lane addresses as in fa_kernel: group (h, c = (lane >> 4) & 1),
+    // lane 4 q + p of the group supplies row r0 + q, 16-byte chunk c0 + (p >> 1), half p & 1; r0 = 32 kt + 16 sx + 4 h (+ 8), c0 = 4 d + 2 c
+    const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, gc = (lane >> 4) & 1;
+    const uint32_t va = (uint32_t)(uintptr_t)smem + (uint32_t)(MAT + (4 * h + gq) * RP + 16 * (2 * gc + (gp >> 1)) + 8 * (gp & 1));
+    f32x16 ot[DT_];
+#pragma unroll
+    for (int d = 0; d < DT_; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ot[d][i] = 0.f;
+    // the twelve transposed reads of a key tile (two 16-key steps x three dim tiles x two row blocks) go out a tile ahead of its six MFMAs
+    s16x4 vl[2][2][DT_], vh[2][2][DT_];
+    auto vread = [&](auto T_) {
+        constexpr int T = decltype(T_)::value;
+        static_for<0, 2>([&](auto X_) {
+            constexpr int X = decltype(X_)::value;
+            static_for<0, DT_>([&](auto D_) {
+                constexpr int D = decltype(D_)::value;
+                lds_read_tr<(32 * T + 16 * X) * RP + 64 * D>(vl[T & 1][X][D], va);
+                lds_read_tr<(32 * T + 16 * X + 8) * RP + 64 * D>(vh[T & 1][X][D], va);
+            });
+        });
+    };
+    vread(std::integral_constant<int, 0>{});
+    static_for<0, ((FA2_EXP & 512) ? 1 : NKT)>([&](auto T_) {
+        constexpr int T = decltype(T_)::value;
+        if constexpr (T + 1 < NKT) vread(std::integral_constant<int, T + 1>{});
+        lds_wait<(T + 1 < NKT) ? 12 : 0>();
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+            for (int d = 0; d < DT_; ++d) {
+                asm volatile("" : "+v"(vl[T & 1][sx][d]), "+v"(vh[T & 1][sx][d]));
+                const s16x4 lo = vl[T & 1][sx][d], hi = vh[T & 1][sx][d];
+                const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[T][sx], ot[d], 0, 0, 0);
+            }
+    });
+    // out[query][head * HD + dim]: this lane holds dims 32 d + 8 i4 + 4 h + e of its query
+    if (q0 + r < Lq) {
+        const float inv = 1.0f / lsum;
+        __bf16* orow = out + (size_t)b * o_bs + (size_t)(q0 + r) * ldo + head * HD;
+#pragma unroll
+        for (int d = 0; d < DT_; ++d)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4)
+                if (32 * d + 8 * i4 + 4 * h < HD) {
+                    const bf16x4 o4 = {(__bf16)(ot[d][4 * i4] * inv), (__bf16)(ot[d][4 * i4 + 1] * inv), (__bf16)(ot[d][4 * i4 + 2] * inv),
+                                       (__bf16)(ot[d][4 * i4 + 3] * inv)};
+                    *reinterpret_cast<bf16x4*>(orow + 32 * d + 8 * i4 + 4 * h) = o4;
+                }
+    }
+}
+
 // out[row][c] = sum_s w_s po[s][row][c] / sum_s w_s,  w_s = 2^(plse[s][row][head(c)] - max_s): the merge of fa128_kernel's key splits
 __global__ void fa128_combine_kernel(const float* __restrict__ po, const float* __restrict__ plse, __bf16* __restrict__ out, int ldo,
                                      int64_t o_bs, int64_t rows, int Lq, int heads, int nsplit, int hd) {
@@ -1270,6 +1452,11 @@ int launch_fa(int hd, const void* q, int ldq, int64_t q_bs, const void* k, const
         const char* e = getenv("FASTGEN_AMD_FA_WAVES");
         minw = (e && e[0] == '3') ? 3 : 2;
     }
+    static int seq72 = -1;  // head dim 72, <= 256 keys: the whole-sequence kernel (1, default) | fa_kernel<72> (0): FASTGEN_AMD_FA_SEQ72
+    if (seq72 < 0) {
+        const char* e = getenv("FASTGEN_AMD_FA_SEQ72");
+        seq72 = (e && e[0] == '0') ? 0 : 1;
+    }
     const float sc = 1.44269504088896341f / sqrtf((float)hd);
 #define FA_GO(HD, MW, LDS, DM)                                                                                                              \
     hipLaunchKernelGGL((fa_kernel<HD, MW, DM>), g, dim3(256), LDS, s, (const __bf16*)q, ldq, q_bs, (const __bf16*)k, (const __bf16*)v, ldk, kv_bs, \
@@ -1293,6 +1480,10 @@ int launch_fa(int hd, const void* q, int ldq, int64_t q_bs, const void* k, const
         } else if (!use_dma) FA_GO(128, 2, 32768, false);
         else if (minw == 3) FA_GO(128, 3, 65536, true);
         else FA_GO(128, 2, 65536, true);
+    } else if (Lkv <= 256 && !force_split && seq72) {
+        const int qt = (Lq + 127) / 128;
+        hipLaunchKernelGGL(fa72_seq_kernel, dim3((unsigned)(((B + 7) / 8) * 8 * heads * qt)), dim3(256), 2 * 256 * 144 + 64, s, (const __bf16*)q, ldq,
+                           q_bs, (const __bf16*)k, (const __bf16*)v, ldk, kv_bs, (__bf16*)out, ldo, o_bs, Lq, Lkv, sc, heads, B);
     } else {
         if (minw == 3) FA_GO(72, 3, 2 * (32 * 144 + 32 * 192), false);
         else FA_GO(72, 2, 2 * (32 * 144 + 32 * 192), false);

@@ -25,7 +25,7 @@ if "--pmc" in sys.argv:  # per-kernel counter averages of a `rocprofv3 --pmc ...
     acc, cnt = defaultdict(float), defaultdict(int)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "fa_kernel" in r["Kernel_Name"] or "fa2_kernel" in r["Kernel_Name"]:
+            if any(n in r["Kernel_Name"] for n in ("fa_kernel", "fa2_kernel", "fa72_seq_kernel")):
                 key = (r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])
                 acc[key] += float(r["Counter_Value"])
                 cnt[key] += 1
@@ -41,7 +41,7 @@ if "--parse" in sys.argv:
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         rows += list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    fa = [r for r in rows if "fa_kernel" in r["Kernel_Name"] or "fa2_kernel" in r["Kernel_Name"]]
+    fa = [r for r in rows if any(n in r["Kernel_Name"] for n in ("fa_kernel", "fa2_kernel", "fa72_seq_kernel"))]
     cb = [r for r in rows if "fa128_combine" in r["Kernel_Name"]]
     assert len(fa) == REPS * len(SHAPES), (len(fa), len(SHAPES))
     ci = 0

@@ -1,4 +1,4 @@
-export PYTHONPATH=$PWD ATTN_SHAPES=2
+export PYTHONPATH=$PWD ATTN_SHAPES=${ATTN_SHAPES:-2}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for W in ${FA_PMC_W:-0 1}; do
 export FASTGEN_AMD_FA_WIDE=$W
