@@ -669,10 +669,12 @@ __device__ __forceinline__ void fa2_mfma_o(f32x16& d, const VT& vv, const bf16x8
 // fa_kernel<128> is bound by instruction issue, not by the matrix pipe (profiles/r02_fa_ablation.txt): per 32-key tile a wave issues 16 MFMAs
 // beside ~90 vector instructions, 24 LDS fragment reads and 4 LDS-DMA pieces, and the two waves of a SIMD share one issue port.  Here a wave
 // owns TWO 32-query blocks (64 queries) and the whole 512-register file (one wave per SIMD, one 256-thread workgroup per CU): every K / V
-// fragment read and every DMA piece feeds two MFMAs, so per query only the softmax arithmetic is left as it was.  Same tiles, same LDS
-// image and ring (4 x 16 KiB by LDS-DMA, three tiles ahead), same software pipelining as fa_kernel's pipelined step - S^T of tile t + 1 (for
-// both blocks: sixteen chained MFMAs) is issued between the pieces of tile t's two softmaxes, then O += V P for both blocks off ONE set
-// of V fragments.  Workgroup = 4 waves = 256 queries; grid mapping, key splits and the merge pass as fa_kernel.
+// fragment read and every DMA piece feeds two MFMAs - 16 % less issue time per query (profiles/r03_fa2_experiments.txt, 2.).  The price is
+// that nothing else fills this wave's stalls, so the step is laid out by hand (see "the pipeline" below): the O^T MFMAs lag the softmax
+// by a tile and are dealt out, one per slot, between its pieces; fragments are re-read a step before their use; the reference maximum
+// moves in eras with the rescale outside the tile loop; the reference check is speculative.  Same tiles and LDS image as fa_kernel
+// (K tiles and V tiles in two rings of 6 x 8 KiB, LDS-DMA four tiles ahead); workgroup = 4 waves = 256 queries; grid mapping, key splits
+// and the merge pass as fa_kernel.  Used for self-attention over >= 1024 keys (launch_fa).
 __global__ __launch_bounds__(256, 1) void fa2_kernel(const __bf16* __restrict__ q, int ldq, int64_t q_bs, const __bf16* __restrict__ k,
                                                      const __bf16* __restrict__ v, int ldk, int64_t kv_bs, __bf16* __restrict__ out, int ldo,
                                                      int64_t o_bs, int Lq, int Lkv, float scale_log2e, int nsplit, float* __restrict__ po,
