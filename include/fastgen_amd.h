@@ -298,7 +298,7 @@ typedef struct fg_dit fg_dit; /* opaque */
 FG_API int fg_dit_create(const fg_dit_config* cfg, fg_dit** out);
 FG_API void fg_dit_destroy(fg_dit* h);
 /* State-dict view: the reference's names and shapes (restated timm attribute names for the patch embedding / attention / MLP
- * layers), `pos_embed` (a persistent buffer there) included.  bind + pack: unlike fg_edm (which borrows its parameters' memory until
+ * layers), `pos_embed` (a persistent buffer there) included.  bind + pack: unlike the fg_edm handle (it borrows its parameters' memory until
  * the next pack) this engine copies at pack time - see fg_dit_pack_group. */
 FG_API int fg_dit_num_params(const fg_dit* h);
 FG_API int fg_dit_param_info(const fg_dit* h, int index, const char** name, int* ndim, int64_t shape[4]);
