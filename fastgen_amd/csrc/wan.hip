@@ -678,7 +678,7 @@ __device__ __forceinline__ void fa2_mfma_o(f32x16& d, const VT& vv, const bf16x8
 __global__ __launch_bounds__(256, 1) void fa2_kernel(const __bf16* __restrict__ q, int ldq, int64_t q_bs, const __bf16* __restrict__ k,
                                                      const __bf16* __restrict__ v, int ldk, int64_t kv_bs, __bf16* __restrict__ out, int ldo,
                                                      int64_t o_bs, int Lq, int Lkv, float scale_log2e, int nsplit, float* __restrict__ po,
-                                                     float* __restrict__ plse, int heads, int batch FA_ABL_PARAM) {
+                                                     float* __restrict__ plse, int heads, int batch, int t_cut FA_ABL_PARAM) {
     constexpr int HD = 128, KS = 8, DT_ = 4, TILE = 32 * 256, NST = 6;
     constexpr int VBASE = NST * TILE;  // LDS: the ring's K tiles, then its V tiles
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -688,10 +688,27 @@ __global__ __launch_bounds__(256, 1) void fa2_kernel(const __bf16* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int qtiles = (Lq + 255) / 256, units = batch * heads * nsplit;
-    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-    const int unit = (slot / qtiles) * 8 + xcd, qt = slot % qtiles;
-    if (unit >= units) return;  // (the grid is padded to a multiple of 8 units; uniform per workgroup, before any barrier)
-    const int split = unit % nsplit, bh = unit / nsplit, head = bh % heads, b = bh / heads;
+    int split, bh, qt;
+    if (t_cut > 0) {
+        // Uneven two-way key split for grids of fewer workgroups than CUs (one sample of the video DiT: 12 heads x 19 query tiles = 228
+        // for 256 CUs).  Every (head, query tile) is cut at key tile t_cut: the long pieces [0, t_cut) are dispatched first, one per CU,
+        // and the CUs left over work through the short pieces [t_cut, ntiles) meanwhile (launch_fa sizes t_cut so that they just
+        // manage) - the launch ends with the long pieces instead of after a whole extra round.  Pieces are dealt to the XCDs in
+        // contiguous runs of the (head, tile) order: equal counts per XCD, a head's K / V in at most two L2s.
+        const int P = batch * heads * qtiles, per = (P + 7) / 8;
+        split = (int)blockIdx.x >= 8 * per ? 1 : 0;
+        const int lb = (int)blockIdx.x - split * 8 * per, xcd = lb & 7, slot = lb >> 3;
+        const int j = (int)((long long)xcd * P / 8) + slot;
+        if (j >= (int)((long long)(xcd + 1) * P / 8)) return;  // (padding of the XCD's run; uniform per workgroup, before any barrier)
+        bh = j / qtiles, qt = j - bh * qtiles;
+    } else {
+        const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+        const int unit = (slot / qtiles) * 8 + xcd;
+        qt = slot % qtiles;
+        if (unit >= units) return;  // (the grid is padded to a multiple of 8 units; uniform per workgroup, before any barrier)
+        split = unit % nsplit, bh = unit / nsplit;
+    }
+    const int head = bh % heads, b = bh / heads;
     const int q0 = qt * 256 + wave * 64;
     // this lane's two query rows (clamped: rows past Lq compute on the last row and are not stored)
     bf16x8 qfA[KS], qfB[KS];
@@ -731,7 +748,8 @@ __global__ __launch_bounds__(256, 1) void fa2_kernel(const __bf16* __restrict__ 
     float mA = -INFINITY, lA = 0.f, mB = -INFINITY, lB = 0.f;  // (the row sums stay per lane - two lanes per query - and meet in the epilogue)
     const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, gc = (lane >> 4) & 1;
     const int ntiles = (Lkv + 31) / 32;
-    const int t0 = (int)((long long)split * ntiles / nsplit), nt = (int)((long long)(split + 1) * ntiles / nsplit);
+    const int t0 = t_cut > 0 ? (split ? t_cut : 0) : (int)((long long)split * ntiles / nsplit);
+    const int nt = t_cut > 0 ? (split ? ntiles : t_cut) : (int)((long long)(split + 1) * ntiles / nsplit);
     dma(t0, 0);
     dma(min(t0 + 1, nt - 1), 1);
     dma(min(t0 + 2, nt - 1), 2);
@@ -1477,8 +1495,28 @@ int launch_fa(int hd, const void* q, int ldq, int64_t q_bs, const void* k, const
         if ((size_t)Lkv * ldk * 2 >= ((size_t)1 << 31)) return (int)hipErrorInvalidValue;  // (buffer-resource offsets are 32-bit)
         if (use_wide && use_dma && !sample_major) {
             const int qt2 = (Lq + 255) / 256;
-            hipLaunchKernelGGL(fa2_kernel, dim3((unsigned)(((units + 7) / 8) * 8 * qt2)), dim3(256), 6 * 16384, s, (const __bf16*)q, ldq, q_bs,
-                               (const __bf16*)k, (const __bf16*)v, ldk, kv_bs, (__bf16*)out, ldo, o_bs, Lq, Lkv, sc, nsplit, po, plse, heads, B FA_ABL_ARG);
+            // fewer workgroups than CUs (one per CU: 256): the uneven two-way split (fa2_kernel) - the long pieces last f of the keys with
+            // f = P (L + c) / (L CUs), c ~ 6 tiles of prologue / epilogue per piece: then the CUs - P spare CUs get through the P short
+            // pieces while the long ones run
+            const long long P = (long long)B * heads * qt2;
+            int t_cut = 0;
+            unsigned grid = (unsigned)(((units + 7) / 8) * 8 * qt2);
+            static int cut = -1;  // FASTGEN_AMD_FA_CUT = 0: even splits by the cost model above instead (A / B)
+            if (cut < 0) {
+                const char* e = getenv("FASTGEN_AMD_FA_CUT");
+                cut = (e && e[0] == '0') ? 0 : 1;
+            }
+            if (cut && force_split == 0 && scratch && P <= 248 && ktiles >= 32) {
+                const double f = (double)P * (ktiles + 6) / ((double)ktiles * 256.0);
+                if (f < 0.97) {
+                    t_cut = (int)(f * ktiles) + 1;
+                    if (t_cut < (ktiles + 1) / 2) t_cut = (ktiles + 1) / 2;
+                    nsplit = 2;
+                    grid = (unsigned)(2 * 8 * ((P + 7) / 8));
+                }
+            }
+            hipLaunchKernelGGL(fa2_kernel, dim3(grid), dim3(256), 6 * 16384, s, (const __bf16*)q, ldq, q_bs, (const __bf16*)k, (const __bf16*)v, ldk,
+                               kv_bs, (__bf16*)out, ldo, o_bs, Lq, Lkv, sc, nsplit, po, plse, heads, B, t_cut FA_ABL_ARG);
         } else if (!use_dma) FA_GO(128, 2, 32768, false);
         else if (minw == 3) FA_GO(128, 3, 65536, true);
         else FA_GO(128, 2, 65536, true);
