@@ -70,10 +70,12 @@ def test_module_state_dict_matches_the_restated_key_list():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,H,hd,Lq,Lkv", [(1, 2, 128, 128, 128), (2, 3, 128, 200, 333), (1, 12, 128, 96, 1000), (1, 2, 128, 48, 17),
-                                            (1, 1, 128, 4680, 4680), (3, 16, 72, 256, 256), (1, 2, 72, 100, 77), (2, 4, 72, 300, 1000)])
+                                            (1, 1, 128, 4680, 4680), (2, 3, 128, 200, 1100), (3, 16, 72, 256, 256), (1, 2, 72, 100, 77),
+                                            (2, 4, 72, 300, 250), (2, 4, 72, 300, 1000)])
 def test_attention_matches_sdpa(B, H, hd, Lq, Lkv):
-    """head dim 128: the video DiT (one sample takes the key-split path); 72: DiT-XL/2 (half-empty contraction step, output tile
-    computed from row spill-over)."""
+    """head dim 128: the video DiT (one sample takes the key-split path; >= 1024 keys: fa2_kernel with its uneven two-way split, here also
+    for two samples, a ragged query tile and a ragged key tile); 72: DiT-XL/2 (half-empty contraction step, output tile computed from
+    row spill-over; <= 256 keys: the whole-sequence kernel, also with masked keys and three query tiles)."""
     from fastgen_amd import _lib
 
     g = torch.Generator().manual_seed(Lq + Lkv)
