@@ -10,6 +10,9 @@ from fastgen_amd import _lib
 
 M = next((int(a) for a in sys.argv[1:] if not a.startswith("--")), 65536)
 ORDERS = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--order=")] or [16 + 1, 32 + 1]
+import os
+if os.environ.get("FA_LIB"):  # an experimental build of the library (A / B runs)
+    _lib.LIB_PATH = os.path.abspath(os.environ["FA_LIB"])
 L = _lib.lib()
 p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
