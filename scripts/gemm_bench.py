@@ -1,6 +1,9 @@
 """Time `fg_op_gemm_bf16` (fastgen_amd/csrc/gemm.hip) on the DiT-XL/2 block shapes (hidden 1152, MLP 4608) and the 1.3B video DiT's
 (hidden 1536, MLP 8960), random bf16 operands, against the 2.5 PFLOP/s dense bf16 roof.
-    python scripts/gemm_bench.py [tokens] [--order=0|1|2|4|8]"""
+    python scripts/gemm_bench.py [tokens] [--order=N ...]
+--order is fg_op_gemm_bf16's tile_order: low bits = tile order (1 XCD-aware), + 16 forces the register-staged gemm_bf16_kernel, + 32 the
+8-wave ping-pong gemm_bf16_pp_kernel, + 256 the narrow-tile gemm_bf16_pp2_kernel (default: 17 and 33, i.e. register-staged, then ping-pong).
+FA_LIB=<path> loads another build of the library (A / B runs)."""
 import ctypes
 import sys
 
