@@ -1157,20 +1157,6 @@ __global__ __launch_bounds__(256, 2) void fa72_seq_kernel(const __bf16* __restri
     const int qt = slot % qtiles, u = slot / qtiles;
     const int b = (u / heads) * 8 + xcd, head = u % heads;
     if (b >= batch) return;  // (uniform per workgroup, before the barrier)
-    const __bf16* kb = k + (size_t)b * kv_bs + head * HD;
-    const __bf16* vb = v + (size_t)b * kv_bs + head * HD;
-    {
-        const unsigned bytes = (unsigned)(((size_t)(Lkv - 1) * ldk + HD) * 2);  // rows past Lkv are out of range: they read as zeros
-        const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(kb), 0, bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(vb), 0, bytes, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < ((FA2_EXP & 256) ? 0 : 9); ++i) {  // a wave instruction fills 1 KiB = 64 consecutive 16-byte chunks of the row-major image
-            const int g = (wave * 9 + i) * 64 + lane, row = g / 9, c = g - 9 * row;
-            const unsigned src = (unsigned)row * (unsigned)ldk * 2u + 16u * (unsigned)c;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr)(smem + (wave * 9 + i) * 1024), 16, src, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr)(smem + MAT + (wave * 9 + i) * 1024), 16, src, 0, 0, 0);
-        }
-    }
     const int q0 = qt * 128 + wave * 32;
     // this lane's query row (clamped: rows past Lq compute on the last row and are not stored)
     const __bf16* qrow = q + (size_t)b * q_bs + (size_t)min(q0 + r, Lq - 1) * ldq + head * HD + 8 * h;
@@ -1180,9 +1166,32 @@ __global__ __launch_bounds__(256, 2) void fa72_seq_kernel(const __bf16* __restri
         qf[kk] = bf16x8{};
         if (kk * 16 + 8 * h < HD) qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + kk * 16);
     }
+    // (the query loads are issued before the DMA below: the counter that is waited on retires in order)
+    const __bf16* kb = k + (size_t)b * kv_bs + head * HD;
+    const __bf16* vb = v + (size_t)b * kv_bs + head * HD;
+    {
+        const unsigned bytes = (unsigned)(((size_t)(Lkv - 1) * ldk + HD) * 2);  // rows past Lkv are out of range: they read as zeros
+        const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(kb), 0, bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(vb), 0, bytes, 0x00020000);
+        // (a wave instruction fills 1 KiB = 64 consecutive 16-byte chunks of the row-major image; all of K first: the S^T phase
+        // starts when K is in, V lands behind it)
+        unsigned src[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int g = (wave * 9 + i) * 64 + lane, row = g / 9, c = g - 9 * row;
+            src[i] = (unsigned)row * (unsigned)ldk * 2u + 16u * (unsigned)c;
+        }
+#pragma unroll
+        for (int i = 0; i < ((FA2_EXP & 256) ? 0 : 9); ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr)(smem + (wave * 9 + i) * 1024), 16, src[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < ((FA2_EXP & 256) ? 0 : 9); ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr)(smem + MAT + (wave * 9 + i) * 1024), 16, src[i], 0, 0, 0);
+    }
     if (tid < 4) *reinterpret_cast<fg_u32x4*>(smem + 2 * MAT + 16 * tid) = fg_u32x4{0, 0, 0, 0};  // (finite bytes behind V's last row)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // the query fragments were loaded FIRST (below the DMA in program order would put them behind V in the in-order counter)
+    // K is in (this wave's part; the 9 V pieces may still be out), then the workgroup's barrier (not __syncthreads(): it drains the counter)
+    asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     // S^T[key][query], all keys.  A tile's five K fragments are read two tiles ahead of their MFMAs (three register sets, counted waits:
     // left to itself hipcc puts each read right in front of the MFMA that uses it - an LDS round trip per MFMA)
@@ -1249,6 +1258,7 @@ __global__ __launch_bounds__(256, 2) void fa72_seq_kernel(const __bf16* __restri
     for (int d = 0; d < DT_; ++d)
 #pragma unroll
         for (int i = 0; i < 16; ++i) ot[d][i] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // V is in: this wave's part, then every wave's
     // the twelve transposed reads of a key tile (two 16-key steps x three dim tiles x two row blocks) go out a tile ahead of its six MFMAs
     s16x4 vl[2][2][DT_], vh[2][2][DT_];
     auto vread = [&](auto T_) {
