@@ -1263,18 +1263,18 @@ int fg_op_attention(const void* q, const void* k, const void* v, void* out, int 
 int fg_op_gemm_bf16(const void* a, const void* w, const float* bias, void* out, int m, int n, int k, int act, const float* gate,
                     int gate_stride, int gate_rows, const void* resid, int tile_order, void* stream) {
 #ifdef FG_TIMING_BUILD
-    const int act_ok = 1 | 4 | 8, order_ok = 511;  // + act 4 / 8: no stores / no epilogue; tile_order 128: cycle stamps (gemm.hip, GM_TIMING)
+    const int act_ok = 1 | 4 | 8, order_ok = 1023;  // + act 4 / 8: no stores / no epilogue; tile_order 128: cycle stamps (gemm.hip, GM_TIMING)
 #else
-    const int act_ok = 1, order_ok = 127 | 256;
+    const int act_ok = 1, order_ok = 127 | 256 | 512;
 #endif
     if (act < 0 || (act & ~act_ok)) return fail(FG_EINVAL, "fg_op_gemm_bf16: act must be 0 (none) or 1 (GELU tanh), got %d", act);
     if (tile_order < 0 || (tile_order & ~order_ok)) return fail(FG_EINVAL, "fg_op_gemm_bf16: bad tile_order %d", tile_order);
-    if (((tile_order >> 4) & 1) + ((tile_order >> 5) & 1) + ((tile_order >> 8) & 1) > 1)
-        return fail(FG_EINVAL, "fg_op_gemm_bf16: tile_order bits 16, 32 and 256 exclude each other");
+    if (((tile_order >> 4) & 1) + ((tile_order >> 5) & 1) + ((tile_order >> 8) & 1) + ((tile_order >> 9) & 1) > 1)
+        return fail(FG_EINVAL, "fg_op_gemm_bf16: tile_order bits 16, 32, 256 and 512 exclude each other");
     GemmArgs g;
     g.A = a; g.W = w; g.bias = bias; g.out = out; g.M = m; g.N = n; g.K = k; g.act = act;
     g.gate = gate; g.gate_stride = gate_stride; g.gate_rows = gate_rows > 0 ? gate_rows : 1; g.resid = resid; g.xn = tile_order & 15;
-    g.variant = (tile_order & 16) ? 0 : (tile_order & 32) ? 1 : (tile_order & 256) ? 2 : -1;
+    g.variant = (tile_order & 16) ? 0 : (tile_order & 32) ? 1 : (tile_order & 256) ? 2 : (tile_order & 512) ? 3 : -1;
     if (!gemm_bf16_supported(g)) return fail(FG_EINVAL, "fg_op_gemm_bf16: unsupported shape (k %% 64, n %% 16, pointers)");
     HIP_TRY(launch_gemm_bf16(g, (hipStream_t)stream, true));
     // one scratch allocation, released on every path once the stream has drained (a test entry point, not a hot path)

@@ -32,6 +32,10 @@
 #include "common.h"
 #include "misc.h"
 
+#ifndef W4_EXP
+#define W4_EXP 0  // gemm_bf16_w4_kernel timing experiments (wrong results): 1 no LDS-DMA in the K-loop, 2 no fragment reads
+#endif
+
 namespace {
 
 constexpr int GM_NTHR = 512;
@@ -772,6 +776,336 @@ __global__ __launch_bounds__(GM_NTHR) void gemm_bf16_pp_kernel(const GemmArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may land in an LDS allocation this workgroup has given up
 }
 
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {  // compile-time loop (instruction offsets / register indices as constants)
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// ---- one wave per SIMD: 4 waves x (128 tokens x 128 outputs) --------------------------------------------------------------------
+// hipBLASLt's kernel for these shapes keeps the matrix pipe 70 % busy where the 8-wave ping-pong above keeps it 51 % busy, with the same
+// instruction mix per MFMA (profiles/r03_gemm_vs_hipblaslt_pmc.txt): its wave owns a 128 x 128 output tile - all 512 registers of a
+// one-wave-per-SIMD kernel, 256 of them accumulators - so a K-step of 64 is 128 MFMAs fed by 32 fragment reads (the 128 x 64 wave
+// tile: 64 MFMAs per 24 reads), and there is no partner wave to be paced against with two barriers per phase.  This is that shape on
+// this file's LDS image and LDS-DMA staging: tile 256 x 256, waves 2 x 2, K-step = two sub-steps of 32 (64 MFMAs each, fragments of
+// the next sub-step read while this one's MFMAs run), ONE barrier per K-step: the DMA of K-step t + 1 is issued at the start of step
+// t into the buffer step t - 1 left, waited for (vmcnt(0)) and handed over before the last 16 MFMAs of step t, behind which the first
+// fragments of step t + 1 are read.  Token epilogue only (GM_EPI_TOK).
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(const GemmArgs a) {
+    constexpr int TN = 256, EPI = GM_EPI_TOK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;  // token half, output half
+    const int col = lane & 15, g = lane >> 4;
+    // ---- this workgroup's tiles (as gemm_bf16_kernel) ----------------------------------------------------------------
+    const int Mt = (a.M + GM_TM - 1) / GM_TM, Nt = (a.N + TN - 1) / TN;
+    int mlo = 0, nlo = 0, nx = Nt, first, stride, count;
+    if ((gridDim.x & 7) == 0 && a.xn > 0) {
+        const int x = (int)blockIdx.x & 7, xm = 8 / a.xn, xi = x / a.xn, xj = x - xi * a.xn;
+        mlo = (int)((long long)xi * Mt / xm);
+        const int mhi = (int)((long long)(xi + 1) * Mt / xm);
+        nlo = xj * Nt / a.xn;
+        nx = (xj + 1) * Nt / a.xn - nlo;
+        first = (int)blockIdx.x >> 3;
+        stride = (int)gridDim.x >> 3;
+        count = (mhi - mlo) * nx;
+    } else {
+        first = (int)blockIdx.x;
+        stride = (int)gridDim.x;
+        count = Mt * Nt;
+    }
+    // split-K (EPI == GM_EPI_RAW): a work item is (tile, split); the ks splits of a tile are neighbours in the enumeration (same
+    // XCD: they read the same A rows and W rows at different k) and leave fp32 partial sums for gemm_splitk_finish_kernel
+    const int ks = 1;
+    count *= ks;
+    const int my_tiles = first < count ? (count - first + stride - 1) / stride : 0;  // work items of this workgroup
+    if (my_tiles == 0) return;
+    auto tile_origin = [&](int i, int& m0, int& n0) {
+        const int lt = (first + min(i, my_tiles - 1) * stride) / ks;  // (cursors running past the end re-read the last tile)
+        const int q = lt / nx;
+        m0 = min((mlo + q) * GM_TM, a.M - GM_TM);
+        n0 = min((nlo + (lt - q * nx)) * TN, a.N - TN);
+    };
+    auto item_split = [&](int i) { return (first + min(i, my_tiles - 1) * stride) % ks; };
+    // where the tile would start without the shift: rows / columns below are the neighbour tile's and are not stored again
+    auto tile_keep_from = [&](int i, int& mk, int& nk_) {
+        const int lt = (first + min(i, my_tiles - 1) * stride) / ks;
+        const int q = lt / nx;
+        mk = (mlo + q) * GM_TM;
+        nk_ = (nlo + (lt - q * nx)) * TN;
+    };
+    const int nk = (a.K / GM_KC) / ks;  // K-steps per work item
+    const int S = my_tiles * nk;
+    // row pitches in bytes (split-bf16 flavour: A rows hold [hi | lo] = 2 K1 elements, W rows [hi | lo | hi] = 3 K1 = K elements)
+    const int KA2 = (a.lda ? a.lda : a.K) * 2, KW2 = (a.ldw ? a.ldw : a.K) * 2;
+    // ---- DMA: wave w moves the 8-row groups 4 w .. 4 w + 3 of every half-tile; lane -> (row lane >> 3 of the group, LDS octet
+    // position lane & 7, which holds k-octet position ^ ((row >> 1) & 7)) ------------------------------------------------
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.A), rsW = make_rsrc(a.W);
+    unsigned voffA[4], voffW[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + (lane >> 3);
+        const unsigned sw = (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+        voffA[j] = (unsigned)row * (unsigned)KA2 + sw;
+        voffW[j] = (unsigned)row * (unsigned)KW2 + sw;
+    }
+    // regions of buffer b: A half h at b * 65536 + h * 16384, W half h at b * 65536 + 32768 + h * 16384
+    // (the scalar offset through v_readfirstlane: the cursors are uniform by construction, but hipcc kept the A cursor in a VGPR and
+    // wrapped each of its DMA instructions in a waterfall loop - readfirstlane, compare, exec mask, branch - inside the K-loop)
+    // one piece = one wave instruction = 1 KiB = 8 rows of a half-tile; a half-tile is 16 pieces, 4 per wave
+    auto pieceA = [&](int region, int so, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(smem + region + (wave * 4 + j) * 1024), 16, voffA[j], so, 0, 0);
+    };
+    auto pieceW = [&](int region, int so, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(smem + region + (wave * 4 + j) * 1024), 16, voffW[j], so, 0, 0);
+    };
+    // cursors over the flat K-steps t + 1 and t + 2: scalar byte offsets of their A / W tiles' first row at their k
+    struct Cur {
+        int ti, kk, sa, sw;
+    };
+    auto cur_set = [&](Cur& c) {
+        int m0, n0;
+        tile_origin(c.ti, m0, n0);
+        const int ks_ = item_split(c.ti) * nk + c.kk;                       // K-step of the (virtual) contraction
+        const int ka = (a.a_wrap && ks_ >= a.a_wrap) ? ks_ - a.a_wrap : ks_;  // split-bf16: A' = [hi | hi | lo] read out of [hi | lo]
+        c.sa = __builtin_amdgcn_readfirstlane(m0 * KA2 + ka * (GM_KC * 2));  // (uniform by construction; keeps the cursor arithmetic on the scalar unit)
+        c.sw = __builtin_amdgcn_readfirstlane(n0 * KW2 + ks_ * (GM_KC * 2));
+    };
+    auto cur_next = [&](Cur& c) {
+        if (++c.kk == nk) c.kk = 0, ++c.ti;
+        cur_set(c);
+    };
+
+
+    // ---- fragments: 16-row group m of this wave's A half / W half, k-substep j ----------------------------------------------------
+    const int lrow0 = col * 128 + ((g ^ ((col >> 1) & 7)) * 16), lrow1 = lrow0 ^ 64;
+    const int fxa = wr * 16384, fwb = 32768 + wc * 16384;
+    bf16x8 X[8], W[2][8];  // X: one set, refilled in place row by row; W: one set per k-substep
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // staging registers: this wave's 16 pieces (16 bytes per lane each) of one K-step, global -> VGPR -> LDS.  (LDS-DMA, which the other
+    // kernels of this file stage with, takes 60-100 cycles of the wave's instruction stream per piece: with one wave per SIMD that is
+    // 36 % of a K-step - measured, W4_EXP = 1 - where the 8-wave kernel hides it behind the partner wave's MFMAs.)
+    fg_u32x4 G[16];
+    const uint32_t wl = (uint32_t)(uintptr_t)smem + (uint32_t)((wave * 4) * 1024 + lane * 16);  // LDS address of this lane's 16 bytes of piece j = 0
+    // ---- epilogue of one 64-token x 32-output quadrant (MH, NH), as in gemm_bf16_pp_kernel (GM_EPI_TOK) ----------------------------
+    int ep_m0 = 0, ep_n0 = 0, ep_mk = 0, ep_nk = 0;
+    const int lane_c8 = wc * 128 + 16 * (g & 1) + 8 * (g >> 1);
+    const int vo_out = ((wr * 128 + col) * a.N + lane_c8) * 2;
+    const __amdgpu_buffer_rsrc_t rsO = make_rsrc(a.out), rsR = make_rsrc(a.resid), rsG = make_rsrc(a.gate);
+    auto slice = [&](auto MH_, auto NH_, f32x4 be, f32x4 bo) {
+        constexpr int MH = decltype(MH_)::value, NH = decltype(NH_)::value;
+        const int m0 = ep_m0, n0 = ep_n0, mk = ep_mk, nk_ = ep_nk;
+        const bool edge = (mk != m0) || (nk_ != n0);
+        const int c8 = n0 + lane_c8 + 32 * NH;
+        f32x4 g0e = {1.f, 1.f, 1.f, 1.f}, g0o = g0e, g1e = g0e, g1o = g0e;
+        int bnd = 0x7fffffff;
+        if (a.gate) {
+            const int gi0 = (a.row0 + m0) / a.gate_rows;
+            bnd = (gi0 + 1) * a.gate_rows - a.row0;
+            const int gso = __builtin_amdgcn_readfirstlane((gi0 * a.gate_stride + n0 + 32 * NH) * 4);
+            g0e = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4, gso, 0));
+            g0o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4, gso + 16, 0));
+            g1e = g0e, g1o = g0o;
+            if (bnd < m0 + GM_TM) {
+                g1e = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4, gso + a.gate_stride * 4, 0));
+                g1o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4, gso + a.gate_stride * 4 + 16, 0));
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int rb = (MH * 4 + m) * 16;
+            const int row = m0 + wr * 128 + rb + col;
+            f32x4 ve = acc[MH * 4 + m][NH * 2] + be, vo = acc[MH * 4 + m][NH * 2 + 1] + bo;
+            acc[MH * 4 + m][NH * 2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[MH * 4 + m][NH * 2 + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.act & 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ve[e] = gm_gelu_tanh(ve[e]), vo[e] = gm_gelu_tanh(vo[e]);
+            }
+            {
+                float e0 = ve[0], e1 = ve[1], e2 = ve[2], e3 = ve[3], o0 = vo[0], o1 = vo[1], o2 = vo[2], o3 = vo[3];
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %6\n\t"
+                             "v_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                             : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));
+                ve = f32x4{e0, e1, e2, e3};
+                vo = f32x4{o0, o1, o2, o3};
+            }
+            if (edge && !(row >= mk && c8 >= nk_)) continue;
+            if (a.gate) {
+                const bool nx_ = row >= bnd;
+                ve *= nx_ ? g1e : g0e;
+                vo *= nx_ ? g1o : g0o;
+            }
+            const int so = __builtin_amdgcn_readfirstlane(((m0 + rb) * a.N + n0 + 32 * NH) * 2);
+            if (a.resid) {
+                const bf16x8 r8 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsR, vo_out, so, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ve[e] += (float)r8[e], vo[e] += (float)r8[4 + e];
+            }
+            bf16x8 o8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o8[e] = (__bf16)ve[e], o8[4 + e] = (__bf16)vo[e];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fg_u32x4, o8), rsO, vo_out, so, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- staging: piece p of a K-step = (region p >> 2: A rows 0-127 | A rows 128-255 | W rows 0-127 | W rows 128-255, 8-row group p & 3) ----
+    Cur c2{0, 0, 0, 0};  // the K-step the next loads fetch
+    cur_set(c2);
+    int g_sa0 = 0, g_sa1 = 0, g_sw0 = 0, g_sw1 = 0;
+    auto g_cur = [&]() {
+        if ((W4_EXP & 4) && g_sa1 != 0) return;  // (experiment: every K-step re-reads the first one's operands - cache-resident)
+        g_sa0 = c2.sa, g_sa1 = __builtin_amdgcn_readfirstlane(c2.sa + 128 * KA2), g_sw0 = c2.sw, g_sw1 = __builtin_amdgcn_readfirstlane(c2.sw + 128 * KW2);
+    };
+    auto g_load = [&](auto P_) {
+        constexpr int P = decltype(P_)::value, R = P >> 2, J = P & 3;
+        if (W4_EXP & 1) return;
+        if constexpr (R == 0) G[P] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA[J], g_sa0, 0);
+        else if constexpr (R == 1) G[P] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA[J], g_sa1, 0);
+        else if constexpr (R == 2) G[P] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voffW[J], g_sw0, 0);
+        else G[P] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voffW[J], g_sw1, 0);
+    };
+    auto g_store = [&](auto P_, uint32_t base) {  // base = wl + buffer * 65536
+        constexpr int P = decltype(P_)::value;
+        if (W4_EXP & 1) return;
+        const fg_u32x4& gp = G[P];
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(base), "v"(gp), "n"((P >> 2) * 16384 + (P & 3) * 1024) : "memory");
+    };
+    auto rd_x = [&](auto M_, uint32_t base) {  // base = buffer * 65536 + fxa + lrow(j)
+        constexpr int M = decltype(M_)::value;
+        if (W4_EXP & 2) return;
+        bf16x8& xr = X[M];
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xr) : "v"(base), "n"(M * 2048));
+    };
+    auto rd_w = [&](int set, auto N_, uint32_t base) {
+        constexpr int N = decltype(N_)::value;
+        if (W4_EXP & 2) return;
+        bf16x8& wr_ = W[set][N];
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wr_) : "v"(base), "n"(N * 2048));
+    };
+    auto SBAR = [] { __builtin_amdgcn_sched_barrier(0); };
+#define SL(n) std::integral_constant<int, n> {}
+
+    // ---- prologue: K-step 0 into buffer 0 through the registers, the loads of K-step 1 in flight, first fragments read --------------------
+    g_cur();
+    static_for<0, 16>([&](auto P_) { g_load(P_); });
+    if (S > 1) cur_next(c2);
+    static_for<0, 16>([&](auto P_) { g_store(P_, wl); });  // (the compiler waits for each load in front of its store)
+    g_cur();
+    static_for<0, 16>([&](auto P_) { g_load(P_); });      // K-step 1
+    if (S > 2) cur_next(c2);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    {
+        const uint32_t bx = (uint32_t)(uintptr_t)smem + fxa + lrow0, bw = (uint32_t)(uintptr_t)smem + fwb + lrow0;
+        static_for<0, 8>([&](auto I_) { rd_w(0, I_, bw); });
+        static_for<0, 8>([&](auto I_) { rd_x(I_, bx); });
+    }
+
+    // One K-step = 128 MFMAs in two sub-steps of 8 rows x 8 output groups, ONE other instruction in (almost) every MFMA's shadow:
+    //   sub-step 0: reads W(t, sub 1) [slots 0-7]; after a row's last MFMA its X register is refilled with (t, sub 1) [slots 8 m + 7];
+    //               the staged K-step t + 1 is written to the other LDS buffer [16 ds_write_b128, slots 16-31]; then the loads of K-step
+    //               t + 2 go out into the same registers [slots 32-62, every other]
+    //   sub-step 1: after row 5 the writes are waited for and handed over (the one barrier of the step); W(t + 1, sub 0) and the X
+    //               registers of finished rows are read behind it [slots 48-63]
+    auto kstep = [&](int t) {
+        const int cb = t & 1, nb = cb ^ 1;
+        const uint32_t s0 = (uint32_t)(uintptr_t)smem;
+        const uint32_t bx1 = s0 + cb * 65536 + fxa + lrow1, bw1 = s0 + cb * 65536 + fwb + lrow1;    // this step, sub-step 1
+        const uint32_t bx0n = s0 + nb * 65536 + fxa + lrow0, bw0n = s0 + nb * 65536 + fwb + lrow0;  // next step, sub-step 0
+        const uint32_t wnb = wl + nb * 65536;
+        asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");  // all but the two youngest reads (X rows 6, 7): W(t, sub 0) and X rows 0-5 are in
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(W[0][i]));
+#pragma unroll
+        for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(X[i]));
+        SBAR();
+        static_for<0, 64>([&](auto S_) {
+            constexpr int SI = decltype(S_)::value, M = SI >> 3, NT = SI & 7;
+            if constexpr (SI == 48) {
+                asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");  // X rows 6, 7 of this step: everything but the 15 youngest LDS operations
+                asm volatile("" : "+v"(X[6]), "+v"(X[7]));
+                SBAR();
+            }
+            acc[M][NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[0][NT], X[M], acc[M][NT], 0, 0, 0);
+            if constexpr (SI < 8) rd_w(1, std::integral_constant<int, SI>{}, bw1);
+            if constexpr (NT == 7) rd_x(std::integral_constant<int, M>{}, bx1);
+            if constexpr (SI >= 16 && SI < 32 && !(W4_EXP & 8)) g_store(std::integral_constant<int, SI - 16>{}, wnb);
+            if constexpr (SI == 31) g_cur();
+            if constexpr (SI >= 32 && (SI & 1) == 0) g_load(std::integral_constant<int, ((SI - 32) >> 1)>{});
+            SBAR();
+        });
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // W(t, sub 1), the writes and X rows 0-3 are in (rows 4-7 may still be out)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(W[1][i]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(X[i]));
+        SBAR();
+        static_for<0, 64>([&](auto S_) {
+            constexpr int SI = decltype(S_)::value, M = SI >> 3, NT = SI & 7;
+            if constexpr (SI == 32) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (issued 32 MFMAs ago at the latest)
+                asm volatile("" : "+v"(X[4]), "+v"(X[5]), "+v"(X[6]), "+v"(X[7]));
+                SBAR();
+            }
+            if constexpr (SI == 48) {
+                // K-step t + 1 is in LDS: this wave's 16 pieces (lgkmcnt(0) above: nothing was issued since), then everybody's
+                asm volatile("s_barrier" ::: "memory");
+                SBAR();
+            }
+            acc[M][NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[1][NT], X[M], acc[M][NT], 0, 0, 0);
+            if constexpr (SI >= 48 && SI < 56) rd_w(0, std::integral_constant<int, SI - 48>{}, bw0n);
+            if constexpr (SI >= 56 && SI < 62) rd_x(std::integral_constant<int, SI - 56>{}, bx0n);  // rows 0-5: their MFMAs are all issued
+            if constexpr (SI == 62) rd_x(std::integral_constant<int, 6>{}, bx0n);                  // row 6: its last MFMA was slot 55
+            SBAR();
+        });
+        rd_x(std::integral_constant<int, 7>{}, bx0n);
+        SBAR();
+    };
+    int t = 0;
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        for (int kk = 0; kk + 1 < nk; ++kk) {
+            kstep(t);
+            if (t + 3 < S) cur_next(c2);
+            ++t;
+        }
+        tile_origin(ti, ep_m0, ep_n0);
+        tile_keep_from(ti, ep_mk, ep_nk);
+        f32x4 bq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+            const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.bias);
+            const int bo_ = __builtin_amdgcn_readfirstlane((ep_n0 + wc * 128) * 4);
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int bl = (ln >> 4) * 16;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bl, bo_ + 64 * i, 0));
+        }
+        kstep(t);
+        if (t + 3 < S) cur_next(c2);
+        ++t;
+        typedef std::integral_constant<int, 0> I0;
+        typedef std::integral_constant<int, 1> I1;
+        typedef std::integral_constant<int, 2> I2;
+        typedef std::integral_constant<int, 3> I3;
+        slice(I0{}, I0{}, bq[0], bq[1]); slice(I0{}, I1{}, bq[2], bq[3]); slice(I0{}, I2{}, bq[4], bq[5]); slice(I0{}, I3{}, bq[6], bq[7]);
+        slice(I1{}, I0{}, bq[0], bq[1]); slice(I1{}, I1{}, bq[2], bq[3]); slice(I1{}, I2{}, bq[4], bq[5]); slice(I1{}, I3{}, bq[6], bq[7]);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#undef SL
+}
+
 // ---- the narrow tile: 256 tokens x 128 outputs, for SHORT token counts ---------------------------------------------------------
 // One sample of the causal video DiT hands the block linears M = 4 680 tokens (a chunk of 3 latent frames): 19 token tiles.  With
 // 256-wide tiles N = 1 536 gives 114 tiles for 256 CUs; the kernel above then cuts K in two (fp32 partial sums through HBM + a finishing
@@ -1188,6 +1522,43 @@ int launch_pp(const GemmArgs& a, hipStream_t s, bool prepare_only) {
 }
 
 // the narrow-tile kernel (256 x 128): token epilogue only
+// the one-wave-per-SIMD kernel (256 x 256 tiles, 4 waves): token epilogue only
+int launch_w4(const GemmArgs& a, hipStream_t s, bool prepare_only) {
+    constexpr int LDS = 131072;
+    const int dev = fg_device_slot();
+    if (dev < 0) return (int)hipErrorInvalidDevice;
+    static bool attr_done[16] = {};
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_w4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done[dev] = true;
+    }
+    if (!g_gm_cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return (int)hipErrorUnknown;
+        g_gm_cus[dev] = n;
+    }
+    if (prepare_only) return 0;
+    const int Mt = (a.M + GM_TM - 1) / GM_TM, Nt = (a.N + 255) / 256;
+    GemmArgs b = a;
+    int grid = g_gm_cus[dev];
+    const long long items = (long long)Mt * Nt;
+    if (items < grid) grid = (int)items, b.xn = 0;
+    if (grid & 7) b.xn = 0;
+    if (b.xn > 0) {
+        int xn = 1;
+        for (int c = 8; c >= 1; c >>= 1)
+            if (Nt % c == 0 && Mt / (8 / c) >= 4) {
+                xn = c;
+                break;
+            }
+        if (a.xn <= 8 && (a.xn & (a.xn - 1)) == 0 && Nt % a.xn == 0 && a.xn != 1) xn = a.xn;
+        b.xn = xn;
+    }
+    hipLaunchKernelGGL(gemm_bf16_w4_kernel, dim3(grid), dim3(256), LDS, s, b);
+    return (int)hipGetLastError();
+}
+
 int launch_pp2(const GemmArgs& a, hipStream_t s, bool prepare_only) {
     constexpr int LDS = 3 * 49152;
     const int dev = fg_device_slot();
@@ -1307,11 +1678,17 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t s, bool prepare_only) {
         b.A = reinterpret_cast<const __bf16*>(a.A) + (size_t)r0 * a.K;
         if (a.out) b.out = reinterpret_cast<__bf16*>(a.out) + (size_t)r0 * a.N;
         if (a.resid) b.resid = reinterpret_cast<const __bf16*>(a.resid) + (size_t)r0 * a.N;
-        const bool pp = (a.variant < 0 ? gm_variant() : (a.variant == 2 ? 1 : a.variant)) == 1 && b.M >= GM_TM && a.N >= 256 && a.K >= 2 * GM_KC &&
+        const bool pp = (a.variant < 0 ? gm_variant() : (a.variant >= 2 ? 1 : a.variant)) == 1 && b.M >= GM_TM && a.N >= 256 && a.K >= 2 * GM_KC &&
                         (!a.gate || a.gate_rows >= GM_TM);  // (the ping-pong kernel's token epilogue: a tile spans at most two gate rows)
         if (pp && !heads && !a.out_f32 && rows_max >= a.M) {
             const int dev = fg_device_slot();
             const int cus = dev >= 0 && g_gm_cus[dev] ? g_gm_cus[dev] : 256;
+            if (a.variant == 3) {  // (experimental: one wave per SIMD)
+                if (b.M < GM_TM || b.N < 256) return (int)hipErrorInvalidValue;
+                const int rc4 = launch_w4(b, s, false);
+                if (rc4) return rc4;
+                continue;
+            }
             if (a.variant == 2 || (a.variant < 0 && gm_narrow_enabled() && gm_use_narrow(b, cus))) {
                 const int rc0 = launch_pp2(b, s, false);
                 if (rc0) return rc0;

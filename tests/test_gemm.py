@@ -135,6 +135,39 @@ def test_narrow_tile_kernel(m, n, k):
     assert (x.float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-3
 
 
+@pytest.mark.parametrize("m,n,k", [(4680, 1536, 1536), (1024, 1152, 4608), (300, 256, 128), (1000, 1152, 1152), (513, 400, 256)])
+def test_one_wave_per_simd_kernel(m, n, k):
+    """tile_order bit 512: gemm_bf16_w4_kernel (4 waves x 128 x 128 outputs, accumulators in the accumulator file, one barrier per K-step):
+    every token epilogue, ragged token and output counts (shifted last tiles), gate periods that straddle a tile, in place."""
+    g = torch.Generator().manual_seed(m + n + k + 1)
+    a = torch.randn(m, k, generator=g).bfloat16().cuda()
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).bfloat16().cuda()
+    bias = torch.randn(n, generator=g).cuda()
+    rows = 1560 if m > 2000 else 256
+    gate = torch.randn((m + rows - 1) // rows, n, generator=g).cuda()
+    resid = torch.randn(m, n, generator=g).bfloat16().cuda()
+    want = _ref(a, w, bias, gate=gate, gate_rows=rows, resid=resid)
+    got = _run(a, w, bias, gate=gate, gate_rows=rows, resid=resid, order=512 + 1)
+    assert torch.isfinite(got.float()).all()
+    assert (got.float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-3
+    assert torch.equal(got, _run(a, w, bias, gate=gate, gate_rows=rows, resid=resid, order=512 + 1))
+    want = _ref(a, w, bias, act=1)
+    got = _run(a, w, bias, act=1, order=512 + 0)
+    assert (got.float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-3
+    got = _run(a, w, order=512 + 1)
+    want = _ref(a, w)
+    assert (got.float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-6
+    from fastgen_amd import _lib
+
+    want = _ref(a, w, bias, gate=gate, gate_rows=rows, resid=resid)
+    x = resid.clone()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(_lib.lib().fg_op_gemm_bf16(p(a), p(w), p(bias), p(x), m, n, k, 0, p(gate), n, rows, p(x), 512 + 1,
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert (x.float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-3
+
+
 def test_unsupported_shapes_are_refused():
     from fastgen_amd import _lib
 
