@@ -458,7 +458,8 @@ FG_API int fg_op_attention_split(const void* q, const void* k, const void* v, vo
  * act(sum_k a[m][k] w[n][k] + bias[n]) with a [m][k], w [n][k], resid / out [m][n] in bf16, fp32 accumulation, bias / gate fp32;
  * act 0 none, 1 GELU(tanh) (anything else: FG_EINVAL); bias, gate, resid nullable.  k % 64 == 0, n % 16 == 0.  tile_order: 0 linear, 1 XCD-aware (launcher's
  * choice), 2 / 4 / 8 XCD columns over n; + 16 forces the register-staged kernel, + 32 the LDS-DMA ping-pong kernel (default: the
- * latter where m, n >= 256), + 256 its narrow-tile form (256 x 128: what short token counts - one sample of the video DiT - take), + 64 lets grids of fewer tiles than
+ * latter where m, n >= 256), + 256 its narrow-tile form (256 x 128: what short token counts - one sample of the video DiT - take), + 512 the experimental
+ * one-wave-per-SIMD kernel (token epilogue, m, n >= 256; no engine uses it), + 64 lets grids of fewer tiles than
  * half the CUs split K (fp32 partial sums + a finishing pass).  Exposed for the parity tests and scripts/gemm_bench.py. */
 FG_API int fg_op_gemm_bf16(const void* a, const void* w, const float* bias, void* out, int m, int n, int k, int act, const float* gate,
                            int gate_stride, int gate_rows, const void* resid, int tile_order, void* stream);
