@@ -182,7 +182,7 @@ def test_unsupported_shapes_are_refused():
     for act in (2, 4, 8, 16, 5, -1):
         with pytest.raises(_lib.FastGenAMDError, match="act must be"):
             _run(a, w, act=act)
-    for order in (128, 128 + 33, 16 + 32, 512, 256 + 32):
+    for order in (128, 128 + 33, 16 + 32, 1024, 256 + 32, 512 + 32, 512 + 256):
         with pytest.raises(_lib.FastGenAMDError, match="tile_order"):
             _run(a, w, order=order)
     assert torch.equal(_run(a, w, act=1), torch.zeros(256, 256, dtype=torch.bfloat16, device="cuda"))
