@@ -219,6 +219,49 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
         }
     }
 }
+// The reference's configs (4 latent channels, patch 2; D % 64 == 0): a wave's 64 threads are 64 output dims of the SAME four tokens, so the
+// tokens' 64 inputs are scalar loads (8 consecutive floats per (channel, patch row)) and the 64 multiply-adds are straight-line code -
+// the generic form above walks (c, py, px) in runtime loops with an address computation and a vector load per term (559 us at B = 256).
+template <typename ST>
+__global__ __launch_bounds__(256) void patch_embed_c4p2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, const float* __restrict__ pos,
+                                                               ST* __restrict__ out, int B, int grid, int D) {
+    const int tpi = grid * grid, res = grid * 2;
+    const int64_t total = (int64_t)B * (tpi / 4) * D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int tg = __builtin_amdgcn_readfirstlane((int)(i / D));  // (uniform per wave: D % 64 == 0, waves start at multiples of 64)
+        const int d = (int)(i - (int64_t)tg * D);
+        const int t0 = (tg % (tpi / 4)) * 4, n = tg / (tpi / 4);
+        const int gy = t0 / grid, gx0 = t0 - gy * grid;
+        float wr[16];
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(w + (size_t)d * 16 + k);
+            wr[k] = q[0], wr[k + 1] = q[1], wr[k + 2] = q[2], wr[k + 3] = q[3];
+        }
+        float xs[4][2][8];  // [channel][patch row][2 j + px]
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const float* row = x + (((size_t)n * 4 + c) * res + gy * 2 + py) * res + gx0 * 2;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xs[c][py][e] = row[e];
+            }
+        const float bd = bias[d];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = bd + pos[(size_t)(t0 + j) * D + d];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int py = 0; py < 2; ++py)
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) a = fmaf(wr[(c * 2 + py) * 2 + px], xs[c][py][2 * j + px], a);
+            out[((size_t)n * tpi + t0 + j) * D + d] = (ST)a;
+        }
+    }
+}
 // (any other K: one thread per output element)
 template <typename ST>
 __global__ __launch_bounds__(256) void patch_embed_any_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
@@ -534,7 +577,10 @@ int launch_dit_patch_embed(int dtype, const float* x, const float* w, const floa
     const int64_t total = k16 ? (int64_t)B * (grid * grid / 4) * D : (int64_t)B * grid * grid * D;
     const int64_t blocks = (total + 255) / 256;
     dim3 g((unsigned)(blocks > 262144 ? 262144 : blocks));
-    if (k16) {
+    if (k16 && C == 4 && (D % 64) == 0) {
+        if (dtype) hipLaunchKernelGGL(patch_embed_c4p2_kernel<__bf16>, g, dim3(256), 0, s, x, w, bias, pos, (__bf16*)out, B, grid, D);
+        else hipLaunchKernelGGL(patch_embed_c4p2_kernel<float>, g, dim3(256), 0, s, x, w, bias, pos, (float*)out, B, grid, D);
+    } else if (k16) {
         if (dtype) hipLaunchKernelGGL((patch_embed_kernel<__bf16, 16>), g, dim3(256), 0, s, x, w, bias, pos, (__bf16*)out, B, C, grid, p, D);
         else hipLaunchKernelGGL((patch_embed_kernel<float, 16>), g, dim3(256), 0, s, x, w, bias, pos, (float*)out, B, C, grid, p, D);
     } else {

@@ -682,7 +682,6 @@ __global__ __launch_bounds__(256, 1) void fa2_kernel(const __bf16* __restrict__ 
     constexpr int HD = 128, KS = 8, DT_ = 4, TILE = 32 * 256, NST = 6;
     constexpr int VBASE = NST * TILE;  // LDS: the ring's K tiles, then its V tiles
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
