@@ -882,70 +882,88 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(const GemmArgs a) 
     };
 
 
-    // ---- fragments: 16-row group m of this wave's A half / W half, k-substep j ----------------------------------------------------
-    const int lrow0 = col * 128 + ((g ^ ((col >> 1) & 7)) * 16), lrow1 = lrow0 ^ 64;
+    // ---- fragments (v_mfma_f32_32x32x16_bf16: a 32-cycle MFMA hides ONE memory instruction completely - a 16x16x32 one, 16 cycles, does
+    // not: measured 15-20 cycles of matrix-pipe idle per LDS / VMEM instruction placed behind it).  Fragment (32-row group g, 16-deep
+    // sub-step ks): lane (r = lane & 31, kh = lane >> 5) reads the 16 bytes at row g * 32 + r, k-octet 2 ks + kh of the half-tile. ----------
+    const int r32 = lane & 31, kh = lane >> 5;
+    uint32_t la[4];  // lane address inside a half-tile at 32-row group 0, per sub-step (the octet swizzle depends on the row pair only)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) la[ks] = (uint32_t)(r32 * 128 + (((2 * ks + kh) ^ ((r32 >> 1) & 7)) * 16));
     const int fxa = wr * 16384, fwb = 32768 + wc * 16384;
-    bf16x8 X[8], W[2][8];  // X: one set, refilled in place row by row; W: one set per k-substep
-    f32x4 acc[8][8];
+    bf16x8 X[2][4], W[2][4];  // [register set = sub-step parity][32-row group]
+    f32x16 acc[4][4];         // [token group][output group]: D[output][token] of W X^T
 #pragma unroll
-    for (int m = 0; m < 8; ++m)
+    for (int mg = 0; mg < 4; ++mg)
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ng = 0; ng < 4; ++ng)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mg][ng][e] = 0.f;
     // staging registers: this wave's 16 pieces (16 bytes per lane each) of one K-step, global -> VGPR -> LDS.  (LDS-DMA, which the other
     // kernels of this file stage with, takes 60-100 cycles of the wave's instruction stream per piece: with one wave per SIMD that is
-    // 36 % of a K-step - measured, W4_EXP = 1 - where the 8-wave kernel hides it behind the partner wave's MFMAs.)
+    // 36 % of a K-step - measured, profiles/r03_gemm_w4_experiments.txt - where the 8-wave kernel hides it behind the partner wave.)
     fg_u32x4 G[16];
     const uint32_t wl = (uint32_t)(uintptr_t)smem + (uint32_t)((wave * 4) * 1024 + lane * 16);  // LDS address of this lane's 16 bytes of piece j = 0
-    // ---- epilogue of one 64-token x 32-output quadrant (MH, NH), as in gemm_bf16_pp_kernel (GM_EPI_TOK) ----------------------------
+
+    // ---- epilogue of one 32-token x 32-output accumulator tile (mg, ng).  Lane (token r, half h) holds outputs 8 q + 4 h + (0..3), q = 0..3;
+    // v_permlane32_swap of group 2 P with group 2 P + 1 leaves lane h = 0 with outputs 16 P .. 16 P + 7 and lane h = 1 with 16 P + 8 .. + 15
+    // of its token: one 16-byte store each, bias / GELU / gate / residual on the eight consecutive outputs as in gemm_bf16_pp_kernel. ------
     int ep_m0 = 0, ep_n0 = 0, ep_mk = 0, ep_nk = 0;
-    const int lane_c8 = wc * 128 + 16 * (g & 1) + 8 * (g >> 1);
-    const int vo_out = ((wr * 128 + col) * a.N + lane_c8) * 2;
-    const __amdgpu_buffer_rsrc_t rsO = make_rsrc(a.out), rsR = make_rsrc(a.resid), rsG = make_rsrc(a.gate);
-    auto slice = [&](auto MH_, auto NH_, f32x4 be, f32x4 bo) {
-        constexpr int MH = decltype(MH_)::value, NH = decltype(NH_)::value;
+    const int lane_c8 = wc * 128 + 8 * kh;
+    const int vo_out = ((wr * 128 + r32) * a.N + lane_c8) * 2;
+    const __amdgpu_buffer_rsrc_t rsO = make_rsrc(a.out), rsR = make_rsrc(a.resid), rsG = make_rsrc(a.gate), rsB = make_rsrc(a.bias);
+    auto tile_out = [&](auto MG_, auto NG_) {
+        constexpr int MG = decltype(MG_)::value, NG = decltype(NG_)::value;
         const int m0 = ep_m0, n0 = ep_n0, mk = ep_mk, nk_ = ep_nk;
         const bool edge = (mk != m0) || (nk_ != n0);
-        const int c8 = n0 + lane_c8 + 32 * NH;
-        f32x4 g0e = {1.f, 1.f, 1.f, 1.f}, g0o = g0e, g1e = g0e, g1o = g0e;
-        int bnd = 0x7fffffff;
+        const int row = m0 + wr * 128 + MG * 32 + r32;
+        int bnd = 0x7fffffff, gso = 0;
         if (a.gate) {
             const int gi0 = (a.row0 + m0) / a.gate_rows;
             bnd = (gi0 + 1) * a.gate_rows - a.row0;
-            const int gso = __builtin_amdgcn_readfirstlane((gi0 * a.gate_stride + n0 + 32 * NH) * 4);
-            g0e = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4, gso, 0));
-            g0o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4, gso + 16, 0));
-            g1e = g0e, g1o = g0o;
-            if (bnd < m0 + GM_TM) {
-                g1e = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4, gso + a.gate_stride * 4, 0));
-                g1o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4, gso + a.gate_stride * 4 + 16, 0));
-            }
+            gso = __builtin_amdgcn_readfirstlane((gi0 * a.gate_stride + n0 + 32 * NG) * 4);
+        }
+        if (W4_EXP & 16) {  // (experiment: no epilogue)
+            asm volatile("" : "+a"(acc[MG][NG]));
+            return;
+        }
+        // (the tile leaves the accumulator file through explicit reads: as plain vector arithmetic on acc[][] hipcc moves ALL sixteen tiles
+        //  into vector registers for the epilogue - 256 of them - and spills the staging registers, in the K-loop as well)
+        float tv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(tv[e]) : "a"(acc[MG][NG][e]));
+        {
+            f32x16 z;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) z[e] = 0.f;
+            asm volatile("s_nop 0" ::: "memory");
+            acc[MG][NG] = z;
+            asm volatile("" : "+a"(acc[MG][NG]));
         }
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int rb = (MH * 4 + m) * 16;
-            const int row = m0 + wr * 128 + rb + col;
-            f32x4 ve = acc[MH * 4 + m][NH * 2] + be, vo = acc[MH * 4 + m][NH * 2 + 1] + bo;
-            acc[MH * 4 + m][NH * 2] = f32x4{0.f, 0.f, 0.f, 0.f};
-            acc[MH * 4 + m][NH * 2 + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int P = 0; P < 2; ++P) {
+            float e0 = tv[8 * P], e1 = tv[8 * P + 1], e2 = tv[8 * P + 2], e3 = tv[8 * P + 3];
+            float o0 = tv[8 * P + 4], o1 = tv[8 * P + 5], o2 = tv[8 * P + 6], o3 = tv[8 * P + 7];
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\t"
+                         "v_permlane32_swap_b32 %3, %7\n\ts_nop 1"
+                         : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));
+            f32x4 ve = {e0, e1, e2, e3}, vo = {o0, o1, o2, o3};
+            const int c8 = n0 + lane_c8 + 32 * NG + 16 * P;
+            if (a.bias) {
+                const int bo_ = __builtin_amdgcn_readfirstlane((n0 + 32 * NG + 16 * P) * 4);
+                ve += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, lane_c8 * 4, bo_, 0));
+                vo += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, lane_c8 * 4, bo_ + 16, 0));
+            }
             if (a.act & 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ve[e] = gm_gelu_tanh(ve[e]), vo[e] = gm_gelu_tanh(vo[e]);
             }
-            {
-                float e0 = ve[0], e1 = ve[1], e2 = ve[2], e3 = ve[3], o0 = vo[0], o1 = vo[1], o2 = vo[2], o3 = vo[3];
-                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %6\n\t"
-                             "v_permlane16_swap_b32 %3, %7\n\ts_nop 1"
-                             : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));
-                ve = f32x4{e0, e1, e2, e3};
-                vo = f32x4{o0, o1, o2, o3};
-            }
             if (edge && !(row >= mk && c8 >= nk_)) continue;
             if (a.gate) {
-                const bool nx_ = row >= bnd;
-                ve *= nx_ ? g1e : g0e;
-                vo *= nx_ ? g1o : g0o;
+                const int go = gso + 64 * P + (row >= bnd ? a.gate_stride * 4 : 0);
+                ve *= __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4 + go - gso, gso, 0));
+                vo *= __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, lane_c8 * 4 + go - gso + 16, gso, 0));
             }
-            const int so = __builtin_amdgcn_readfirstlane(((m0 + rb) * a.N + n0 + 32 * NH) * 2);
+            const int so = __builtin_amdgcn_readfirstlane(((m0 + MG * 32) * a.N + n0 + 32 * NG + 16 * P) * 2);
             if (a.resid) {
                 const bf16x8 r8 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsR, vo_out, so, 0));
 #pragma unroll
@@ -981,20 +999,20 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(const GemmArgs a) 
         const fg_u32x4& gp = G[P];
         asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(base), "v"(gp), "n"((P >> 2) * 16384 + (P & 3) * 1024) : "memory");
     };
-    auto rd_x = [&](auto M_, uint32_t base) {  // base = buffer * 65536 + fxa + lrow(j)
-        constexpr int M = decltype(M_)::value;
-        if (W4_EXP & 2) return;
-        bf16x8& xr = X[M];
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xr) : "v"(base), "n"(M * 2048));
-    };
-    auto rd_w = [&](int set, auto N_, uint32_t base) {
-        constexpr int N = decltype(N_)::value;
-        if (W4_EXP & 2) return;
-        bf16x8& wr_ = W[set][N];
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wr_) : "v"(base), "n"(N * 2048));
-    };
     auto SBAR = [] { __builtin_amdgcn_sched_barrier(0); };
-#define SL(n) std::integral_constant<int, n> {}
+    // fragment i of a sub-step: i = 0..3 token groups, 4..7 output groups
+    auto rd_f = [&](int set, auto I_, uint32_t xb, uint32_t wb) {  // xb / wb = buffer + half-tile + la[ks]
+        constexpr int I = decltype(I_)::value;
+        if (W4_EXP & 2) return;
+        if constexpr (I < 4) {
+            bf16x8& f = X[set][I];
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(xb), "n"(I * 4096));
+        } else {
+            bf16x8& f = W[set][I - 4];
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(wb), "n"((I - 4) * 4096));
+        }
+    };
+    const uint32_t s0 = (uint32_t)(uintptr_t)smem;
 
     // ---- prologue: K-step 0 into buffer 0 through the registers, the loads of K-step 1 in flight, first fragments read --------------------
     g_cur();
@@ -1005,105 +1023,55 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(const GemmArgs a) 
     static_for<0, 16>([&](auto P_) { g_load(P_); });      // K-step 1
     if (S > 2) cur_next(c2);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    {
-        const uint32_t bx = (uint32_t)(uintptr_t)smem + fxa + lrow0, bw = (uint32_t)(uintptr_t)smem + fwb + lrow0;
-        static_for<0, 8>([&](auto I_) { rd_w(0, I_, bw); });
-        static_for<0, 8>([&](auto I_) { rd_x(I_, bx); });
-    }
+    static_for<0, 8>([&](auto I_) { rd_f(0, I_, s0 + fxa + la[0], s0 + fwb + la[0]); });
 
-    // One K-step = 128 MFMAs in two sub-steps of 8 rows x 8 output groups, ONE other instruction in (almost) every MFMA's shadow:
-    //   sub-step 0: reads W(t, sub 1) [slots 0-7]; after a row's last MFMA its X register is refilled with (t, sub 1) [slots 8 m + 7];
-    //               the staged K-step t + 1 is written to the other LDS buffer [16 ds_write_b128, slots 16-31]; then the loads of K-step
-    //               t + 2 go out into the same registers [slots 32-62, every other]
-    //   sub-step 1: after row 5 the writes are waited for and handed over (the one barrier of the step); W(t + 1, sub 0) and the X
-    //               registers of finished rows are read behind it [slots 48-63]
+    // One K-step of 64 = four sub-steps of 16 MFMAs (4 token groups x 4 output groups), ONE memory instruction behind every MFMA:
+    //   slots 0-7 of sub-step ks: the eight fragments of sub-step ks + 1 (of the NEXT K-step, other buffer, for ks = 3)
+    //   slots 8-15: ks = 0, 1: the staged K-step t + 1 goes into the other LDS buffer (2 x 8 ds_write_b128)
+    //               ks = 2, 3: the loads of K-step t + 2 into the same registers (2 x 8)
+    //   between ks = 2 and 3: this wave's writes are done (lgkmcnt(0)), then the one barrier of the step
     auto kstep = [&](int t) {
         const int cb = t & 1, nb = cb ^ 1;
-        const uint32_t s0 = (uint32_t)(uintptr_t)smem;
-        const uint32_t bx1 = s0 + cb * 65536 + fxa + lrow1, bw1 = s0 + cb * 65536 + fwb + lrow1;    // this step, sub-step 1
-        const uint32_t bx0n = s0 + nb * 65536 + fxa + lrow0, bw0n = s0 + nb * 65536 + fwb + lrow0;  // next step, sub-step 0
-        const uint32_t wnb = wl + nb * 65536;
-        asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");  // all but the two youngest reads (X rows 6, 7): W(t, sub 0) and X rows 0-5 are in
-#pragma unroll
-        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(W[0][i]));
-#pragma unroll
-        for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(X[i]));
-        SBAR();
-        static_for<0, 64>([&](auto S_) {
-            constexpr int SI = decltype(S_)::value, M = SI >> 3, NT = SI & 7;
-            if constexpr (SI == 48) {
-                asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");  // X rows 6, 7 of this step: everything but the 15 youngest LDS operations
-                asm volatile("" : "+v"(X[6]), "+v"(X[7]));
-                SBAR();
+        const uint32_t xcb = s0 + cb * 65536 + fxa, wcb = s0 + cb * 65536 + fwb, xnb = s0 + nb * 65536 + fxa, wnb_ = s0 + nb * 65536 + fwb;
+        const uint32_t wst = wl + nb * 65536;
+        static_for<0, 4>([&](auto KS_) {
+            constexpr int KS = decltype(KS_)::value, SET = KS & 1;
+            // this sub-step's fragments (read in slots 0-7 of the previous one; behind them at most its 8 LDS writes)
+            if constexpr (KS == 1 || KS == 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (KS == 3) {
+                asm volatile("s_barrier" ::: "memory");  // K-step t + 1 is in LDS, in every wave's part
             }
-            acc[M][NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[0][NT], X[M], acc[M][NT], 0, 0, 0);
-            if constexpr (SI < 8) rd_w(1, std::integral_constant<int, SI>{}, bw1);
-            if constexpr (NT == 7) rd_x(std::integral_constant<int, M>{}, bx1);
-            if constexpr (SI >= 16 && SI < 32 && !(W4_EXP & 8)) g_store(std::integral_constant<int, SI - 16>{}, wnb);
-            if constexpr (SI == 31) g_cur();
-            if constexpr (SI >= 32 && (SI & 1) == 0) g_load(std::integral_constant<int, ((SI - 32) >> 1)>{});
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(X[SET][i]), "+v"(W[SET][i]));
             SBAR();
-        });
-        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // W(t, sub 1), the writes and X rows 0-3 are in (rows 4-7 may still be out)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(W[1][i]));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(X[i]));
-        SBAR();
-        static_for<0, 64>([&](auto S_) {
-            constexpr int SI = decltype(S_)::value, M = SI >> 3, NT = SI & 7;
-            if constexpr (SI == 32) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (issued 32 MFMAs ago at the latest)
-                asm volatile("" : "+v"(X[4]), "+v"(X[5]), "+v"(X[6]), "+v"(X[7]));
+            if constexpr (KS == 2) g_cur();
+            static_for<0, 16>([&](auto I_) {
+                constexpr int I = decltype(I_)::value, MG = I >> 2, NG = I & 3;
+                acc[MG][NG] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[SET][NG], X[SET][MG], acc[MG][NG], 0, 0, 0);
+                if constexpr (I < 8) {
+                    if constexpr (KS < 3) rd_f(SET ^ 1, I_, xcb + la[KS < 3 ? KS + 1 : 0], wcb + la[KS < 3 ? KS + 1 : 0]);
+                    else rd_f(SET ^ 1, I_, xnb + la[0], wnb_ + la[0]);
+                } else {
+                    if constexpr (KS < 2) g_store(std::integral_constant<int, 8 * KS + I - 8>{}, wst);
+                    else g_load(std::integral_constant<int, 8 * (KS - 2) + I - 8>{});
+                }
                 SBAR();
-            }
-            if constexpr (SI == 48) {
-                // K-step t + 1 is in LDS: this wave's 16 pieces (lgkmcnt(0) above: nothing was issued since), then everybody's
-                asm volatile("s_barrier" ::: "memory");
-                SBAR();
-            }
-            acc[M][NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[1][NT], X[M], acc[M][NT], 0, 0, 0);
-            if constexpr (SI >= 48 && SI < 56) rd_w(0, std::integral_constant<int, SI - 48>{}, bw0n);
-            if constexpr (SI >= 56 && SI < 62) rd_x(std::integral_constant<int, SI - 56>{}, bx0n);  // rows 0-5: their MFMAs are all issued
-            if constexpr (SI == 62) rd_x(std::integral_constant<int, 6>{}, bx0n);                  // row 6: its last MFMA was slot 55
-            SBAR();
+            });
         });
-        rd_x(std::integral_constant<int, 7>{}, bx0n);
-        SBAR();
     };
     int t = 0;
     for (int ti = 0; ti < my_tiles; ++ti) {
-        for (int kk = 0; kk + 1 < nk; ++kk) {
-            kstep(t);
+        for (int kk = 0; kk < nk; ++kk) {  // (ONE copy of the K-step in the kernel: a second, peeled one gets its own accumulator registers
+            kstep(t);                      //  and 240 accumulator-to-accumulator moves to reconcile them)
             if (t + 3 < S) cur_next(c2);
             ++t;
         }
         tile_origin(ti, ep_m0, ep_n0);
         tile_keep_from(ti, ep_mk, ep_nk);
-        f32x4 bq[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) bq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.bias) {
-            const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.bias);
-            const int bo_ = __builtin_amdgcn_readfirstlane((ep_n0 + wc * 128) * 4);
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            const int bl = (ln >> 4) * 16;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) bq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bl, bo_ + 64 * i, 0));
-        }
-        kstep(t);
-        if (t + 3 < S) cur_next(c2);
-        ++t;
-        typedef std::integral_constant<int, 0> I0;
-        typedef std::integral_constant<int, 1> I1;
-        typedef std::integral_constant<int, 2> I2;
-        typedef std::integral_constant<int, 3> I3;
-        slice(I0{}, I0{}, bq[0], bq[1]); slice(I0{}, I1{}, bq[2], bq[3]); slice(I0{}, I2{}, bq[4], bq[5]); slice(I0{}, I3{}, bq[6], bq[7]);
-        slice(I1{}, I0{}, bq[0], bq[1]); slice(I1{}, I1{}, bq[2], bq[3]); slice(I1{}, I2{}, bq[4], bq[5]); slice(I1{}, I3{}, bq[6], bq[7]);
+        static_for<0, 16>([&](auto I_) { tile_out(std::integral_constant<int, (decltype(I_)::value >> 2)>{}, std::integral_constant<int, (decltype(I_)::value & 3)>{}); });
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#undef SL
 }
 
 // ---- the narrow tile: 256 tokens x 128 outputs, for SHORT token counts ---------------------------------------------------------
